@@ -1,0 +1,686 @@
+// snail_oracle.cpp -- CPU ORACLE for the Snail hot path.  TEST INFRASTRUCTURE ONLY (see snail_oracle.h).
+//
+// A scalar-per-lane restatement of the reference's packet algorithm.  Every function cites the
+// reference file:line it follows (paths relative to /root/reference).  All arithmetic is IEEE fp32
+// with one rounding per operation: build with -ffp-contract=off and WITHOUT -mfma/-march=native.
+// Min/Max follow veclib: Min(a,b) = a<b ? a : b, Max(a,b) = a>b ? a : b (veclib/vecbase.h:75-76; the
+// SSE minps/maxps used for f32x4 have the same "second operand on NaN" behaviour, veclib/sse/f32.h:104-105).
+//
+// parity unpinned (strict sense): see the header comment of snail_oracle.h.
+
+#include "snail_oracle.h"
+
+#include <xmmintrin.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <thread>
+#include <vector>
+
+namespace {
+
+const float kInf = std::numeric_limits<float>::infinity();
+
+inline float Min(float a, float b) { return a < b ? a : b; }
+inline float Max(float a, float b) { return a > b ? a : b; }
+
+// ---- the two approximate operations -------------------------------------------------------------
+// IEEE: veclib/vecbase.h:53-55.  SSE: veclib/sse/base.h:84-92 (rcpps / rsqrtps + one Newton step).
+template <int MODE> inline float Inv(float x);
+template <> inline float Inv<ORC_MODE_IEEE>(float x) { return 1.0f / x; }
+template <> inline float Inv<ORC_MODE_SSE>(float x) {
+	float t = _mm_cvtss_f32(_mm_rcp_ps(_mm_set1_ps(x)));
+	return (t + t) - ((x * t) * t);
+}
+template <int MODE> inline float RSqrt(float x);
+template <> inline float RSqrt<ORC_MODE_IEEE>(float x) { return 1.0f / sqrtf(x); }
+template <> inline float RSqrt<ORC_MODE_SSE>(float x) {
+	float t = _mm_cvtss_f32(_mm_rsqrt_ps(_mm_set1_ps(x)));
+	return (0.5f * t) * (3.0f - ((x * t) * t));
+}
+
+struct V3 {
+	float x, y, z;
+	float operator[](int i) const { return i == 0 ? x : i == 1 ? y : z; }
+};
+inline V3 mk(const float *p) { return V3{p[0], p[1], p[2]}; }
+inline V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator*(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+inline V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+// veclib/vec3.h:92-106: dot is ((x*x' + y*y') + z*z'); cross as written there
+inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(V3 b, V3 c) { return V3{b.y * c.z - b.z * c.y, b.z * c.x - b.x * c.z, b.x * c.y - b.y * c.x}; }
+inline V3 VMin(V3 a, V3 b) { return V3{Min(a.x, b.x), Min(a.y, b.y), Min(a.z, b.z)}; }
+inline V3 VMax(V3 a, V3 b) { return V3{Max(a.x, b.x), Max(a.y, b.y), Max(a.z, b.z)}; }
+
+struct Box { V3 mn, mx; };
+// src/triangle.h:35-37,62-70: P2 = ba + a, P3 = ca + a; BoundMin = VMin(P1, VMin(P2, P3))
+inline Box triBox(const OrcTri &t) {
+	V3 p1 = mk(t.a), p2 = mk(t.ba) + mk(t.a), p3 = mk(t.ca) + mk(t.a);
+	return Box{VMin(p1, VMin(p2, p3)), VMax(p1, VMax(p2, p3))};
+}
+inline void grow(Box &b, const Box &o) { b.mn = VMin(b.mn, o.mn); b.mx = VMax(b.mx, o.mx); } // bounding_box.h:21-25
+
+// ---- BVH builder: src/bvh/tree.cpp:7-19 (OrderTris), :45-47 (BoxSA), :51-159 (FindSplitSweep) ----
+struct OrderTris {
+	const OrcTri *tris; int axis;
+	bool operator()(int i1, int i2) const {
+		const OrcTri &a = tris[i1], &b = tris[i2];
+		return a.a[axis] * 3.0f + a.ba[axis] + a.ca[axis] < b.a[axis] * 3.0f + b.ba[axis] + b.ca[axis];
+	}
+};
+inline float BoxSA(const Box &b) {
+	float w = b.mx.x - b.mn.x, h = b.mx.y - b.mn.y, d = b.mx.z - b.mn.z;
+	return (w * (d + h) + d * h) * 2.0f;
+}
+inline int MaxAxis(V3 v) { return v.y > v.x ? (v.z > v.y ? 2 : 1) : (v.z > v.x ? 2 : 0); } // src/rtbase.h:136-138
+
+struct Builder {
+	OrcTri *tris; int32_t *perm; OrcNode *nodes; int nNodes = 0; int depth = 0;
+	enum { maxDepth = 64 };
+
+	void setBox(int n, const Box &b) {
+		nodes[n].bmin[0] = b.mn.x; nodes[n].bmin[1] = b.mn.y; nodes[n].bmin[2] = b.mn.z;
+		nodes[n].bmax[0] = b.mx.x; nodes[n].bmax[1] = b.mx.y; nodes[n].bmax[2] = b.mx.z;
+	}
+	Box getBox(int n) const { return Box{mk(nodes[n].bmin), mk(nodes[n].bmax)}; }
+
+	void split(int nNode, int first, int count, int sdepth) {
+		Box bbox = getBox(nNode);
+		bool leaf = count <= 4 || sdepth == maxDepth - 1;
+		int minIdx = count / 2, minAxis = 0;
+
+		if(!leaf) {
+			minAxis = MaxAxis(bbox.mx - bbox.mn);
+			std::vector<int> indices(count);
+			float minCost = kInf;
+			float noSplitCost = 1.0f * count * BoxSA(bbox);
+
+			for(int axis = 0; axis <= 2; axis++) {
+				for(int n = 0; n < count; n++) indices[n] = first + n;
+				std::sort(indices.begin(), indices.begin() + count, OrderTris{tris, axis});
+
+				std::vector<float> leftSA(count), rightSA(count);
+				rightSA[count - 1] = BoxSA(triBox(tris[indices[count - 1]]));
+				leftSA[0] = BoxSA(triBox(tris[indices[0]]));
+				Box last = triBox(tris[indices[0]]);
+				for(size_t n = 1; n < (size_t)count; n++) { grow(last, triBox(tris[indices[n]])); leftSA[n] = BoxSA(last); }
+				last = triBox(tris[indices[count - 1]]);
+				for(int n = count - 2; n >= 0; n--) { grow(last, triBox(tris[indices[n]])); rightSA[n] = BoxSA(last); }
+
+				for(size_t n = 1; n < (size_t)count; n++) {
+					float cost = leftSA[n - 1] * n + rightSA[n] * (count - n);
+					if(cost < minCost) { minCost = cost; minIdx = (int)n; minAxis = axis; }
+				}
+			}
+			minCost = 0.0f + 1.0f * minCost;
+			if(noSplitCost < minCost) leaf = true;
+
+			if(!leaf) {
+				if(minAxis != 2) {
+					for(int n = 0; n < count; n++) indices[n] = first + n;
+					std::nth_element(indices.begin(), indices.begin() + minIdx, indices.end(), OrderTris{tris, minAxis});
+				}
+				std::vector<OrcTri> ttemp(count);
+				for(int n = 0; n < count; n++) ttemp[n] = tris[indices[n]];
+				for(int n = 0; n < count; n++) tris[first + n] = ttemp[n];
+				if(perm) {
+					std::vector<int32_t> ptemp(count);
+					for(int n = 0; n < count; n++) ptemp[n] = perm[indices[n]];
+					for(int n = 0; n < count; n++) perm[first + n] = ptemp[n];
+				}
+			}
+		}
+
+		if(leaf) { // tree.cpp:54-62
+			Box b = triBox(tris[first]);
+			for(int n = 1; n < count; n++) grow(b, triBox(tris[first + n]));
+			setBox(nNode, b);
+			depth = std::max(depth, sdepth);
+			nodes[nNode].sub = (uint32_t)first | 0x80000000u;
+			nodes[nNode].aux = count;
+			return;
+		}
+
+		Box leftBox = triBox(tris[first]), rightBox = triBox(tris[first + count - 1]);
+		for(int n = 1; n < minIdx; n++) grow(leftBox, triBox(tris[first + n]));
+		for(int n = minIdx; n < count; n++) grow(rightBox, triBox(tris[first + n]));
+
+		int subNode = nNodes;
+		nodes[nNode].sub = (uint32_t)subNode;
+		// tree.cpp:148-151 -- the second assignment of firstNode wins
+		int firstNode = leftBox.mn[minAxis] == rightBox.mn[minAxis] ? (leftBox.mx[minAxis] < rightBox.mx[minAxis] ? 0 : 1) : 0;
+		nodes[nNode].aux = (minAxis & 0xffff) | (firstNode << 16);
+		setBox(nNodes++, leftBox);
+		setBox(nNodes++, rightBox);
+
+		split(subNode + 0, first, minIdx, sdepth + 1);
+		split(subNode + 1, first + minIdx, count - minIdx, sdepth + 1);
+	}
+};
+
+// ---- packet views ---------------------------------------------------------------------------------
+// Vec3q memory layout: per quad {x[4], y[4], z[4]} (12 floats).
+struct Rays {
+	int size; bool shared;
+	const float *origin, *dir, *idir; const uint8_t *mask;
+	float O(int q, int c, int l) const { return origin[(shared ? 0 : q) * 12 + c * 4 + l]; }
+	float D(int q, int c, int l) const { return dir[q * 12 + c * 4 + l]; }
+	float I(int q, int c, int l) const { return idir[q * 12 + c * 4 + l]; }
+	V3 org0() const { return V3{origin[0], origin[4], origin[8]}; } // ExtractN(Origin(0), 0)
+};
+
+struct Interval { V3 minDir, maxDir, minIDir, maxIDir, minOrigin, maxOrigin; };
+
+// src/rtbase.cpp:61-121 -- three ComputeMinMax overloads; `active(q,l)` selects the variant.
+template <class Active>
+void computeMinMax(const float *vec, int size, bool anyMask, Active active, V3 *outMin, V3 *outMax) {
+	float mn[3][4], mx[3][4];
+	int q0 = 0;
+	if(!anyMask) {
+		for(int c = 0; c < 3; c++) for(int l = 0; l < 4; l++) mn[c][l] = mx[c][l] = vec[c * 4 + l];
+		q0 = 1;
+	} else {
+		auto anyLane = [&](int q) { return active(q, 0) || active(q, 1) || active(q, 2) || active(q, 3); };
+		while(q0 < size && !anyLane(q0)) q0++;
+		if(q0 == size) { *outMin = *outMax = V3{0.0f, 0.0f, 0.0f}; return; }
+		for(int k = 0; k < 4; k++) if(active(q0, k)) {
+			for(int c = 0; c < 3; c++) for(int l = 0; l < 4; l++) mn[c][l] = mx[c][l] = vec[q0 * 12 + c * 4 + k];
+			break;
+		}
+	}
+	for(int q = q0; q < size; q++)
+		for(int c = 0; c < 3; c++) for(int l = 0; l < 4; l++) {
+			if(anyMask && !active(q, l)) continue;
+			float v = vec[q * 12 + c * 4 + l];
+			mn[c][l] = Min(mn[c][l], v);
+			mx[c][l] = Max(mx[c][l], v);
+		}
+	float omn[3], omx[3];
+	for(int c = 0; c < 3; c++) { // Minimize/Maximize, src/rtbase_math.h:63-64
+		omn[c] = Min(Min(mn[c][0], mn[c][1]), Min(mn[c][2], mn[c][3]));
+		omx[c] = Max(Max(mx[c][0], mx[c][1]), Max(mx[c][2], mx[c][3]));
+	}
+	*outMin = mk(omn); *outMax = mk(omx);
+}
+
+// src/ray_group.h:296-333 (RayInterval ctors)
+Interval makeInterval(const Rays &r, const float *distMask) {
+	Interval i;
+	if(distMask) {
+		auto act = [&](int q, int l) { return distMask[q * 4 + l] >= 0.0f; };
+		computeMinMax(r.dir, r.size, true, act, &i.minDir, &i.maxDir);
+		computeMinMax(r.idir, r.size, true, act, &i.minIDir, &i.maxIDir);
+		i.minOrigin = i.maxOrigin = r.org0();
+		return i;
+	}
+	auto act = [&](int q, int l) { return r.mask ? ((r.mask[q] >> l) & 1) != 0 : true; };
+	bool m = r.mask != nullptr;
+	computeMinMax(r.dir, r.size, m, act, &i.minDir, &i.maxDir);
+	computeMinMax(r.idir, r.size, m, act, &i.minIDir, &i.maxIDir);
+	if(r.shared) i.minOrigin = i.maxOrigin = r.org0();
+	else computeMinMax(r.origin, r.size, m, act, &i.minOrigin, &i.maxOrigin);
+	return i;
+}
+
+// src/bounding_box.cpp:208-236
+bool boxTestInterval(const OrcNode &n, const Interval &i) {
+	float lmin = 0, lmax = 0;
+	for(int k = 0; k < 3; k++) {
+		float l1 = i.minIDir[k] * (n.bmin[k] - i.maxOrigin[k]);
+		float l2 = i.maxIDir[k] * (n.bmin[k] - i.maxOrigin[k]);
+		float l3 = i.minIDir[k] * (n.bmax[k] - i.minOrigin[k]);
+		float l4 = i.maxIDir[k] * (n.bmax[k] - i.minOrigin[k]);
+		float lo = Min(Min(l1, l2), Min(l3, l4)), hi = Max(Max(l1, l2), Max(l3, l4));
+		if(k == 0) { lmin = lo; lmax = hi; }
+		else { lmin = Max(lmin, lo); lmax = Min(lmax, hi); }
+	}
+	return lmax >= 0.0f && lmin <= lmax;
+}
+
+// one lane of the slab test; src/bounding_box.cpp:75-99 (primary) and :151-169 (shadow operand order)
+template <bool SHADOW>
+inline bool lanePasses(const OrcNode &n, const Rays &r, const float *tmin, const float *tmax, int q, int l, float dist) {
+	float lmin = 0, lmax = 0;
+	for(int k = 0; k < 3; k++) {
+		float id = r.I(q, k, l);
+		float l1 = id * (r.shared ? tmin[k] : n.bmin[k] - r.O(q, k, l));
+		float l2 = id * (r.shared ? tmax[k] : n.bmax[k] - r.O(q, k, l));
+		if(k == 0) { lmin = Min(l1, l2); lmax = Max(l1, l2); }
+		else if(SHADOW) { lmin = Max(Min(l1, l2), lmin); lmax = Min(Max(l1, l2), lmax); }
+		else { lmin = Max(lmin, Min(l1, l2)); lmax = Min(lmax, Max(l1, l2)); }
+	}
+	if(SHADOW) return lmax >= 0.0f && lmin <= Min(lmax, dist);
+	return !(lmax < 0.0f || lmin > Min(lmax, dist));
+}
+
+// src/bounding_box.cpp:61-142 and :144-200 -- shrinks [first,last] in place
+template <bool SHADOW>
+bool boxTest(const OrcNode &n, const Rays &r, const float *dist, int &first, int &last) {
+	bool ret = false;
+	float tmin[3] = {0, 0, 0}, tmax[3] = {0, 0, 0};
+	if(r.shared) {
+		V3 o = r.org0();
+		for(int k = 0; k < 3; k++) { tmin[k] = n.bmin[k] - o[k]; tmax[k] = n.bmax[k] - o[k]; }
+	}
+	auto quadPasses = [&](int q) {
+		bool any = false;
+		for(int l = 0; l < 4; l++) any |= lanePasses<SHADOW>(n, r, tmin, tmax, q, l, dist[q * 4 + l]);
+		return any;
+	};
+	for(int q = first; q <= last; q++) if(quadPasses(q)) { first = q; ret = true; break; }
+	for(int q = last; q >= first; q--) if(quadPasses(q)) { last = q; ret = true; break; }
+	return ret;
+}
+
+// src/triangle.cpp:110-167 with the hard-wired `enum { sharedOrigin = 1 }` branch (:122-129)
+bool triTestInterval(const OrcTri &t, const Interval &i) {
+	V3 nrm = mk(t.plane);
+	float det = (nrm.x < 0.0f ? i.minDir.x : i.maxDir.x) * nrm.x + (nrm.y < 0.0f ? i.minDir.y : i.maxDir.y) * nrm.y +
+				(nrm.z < 0.0f ? i.minDir.z : i.maxDir.z) * nrm.z;
+	if(det < 0.0f) return true;
+	V3 tvec = i.minOrigin - mk(t.a);
+	V3 c1 = cross(mk(t.ba), tvec), c2 = cross(tvec, mk(t.ca));
+	V3 c1a = i.minDir * c1, c1b = i.maxDir * c1, c2a = i.minDir * c2, c2b = i.maxDir * c2;
+	float u0 = Min(c1a.x, c1b.x) + Min(c1a.y, c1b.y) + Min(c1a.z, c1b.z);
+	float u1 = Max(c1a.x, c1b.x) + Max(c1a.y, c1b.y) + Max(c1a.z, c1b.z);
+	float v0 = Min(c2a.x, c2b.x) + Min(c2a.y, c2b.y) + Min(c2a.z, c2b.z);
+	float v1 = Max(c2a.x, c2b.x) + Max(c2a.y, c2b.y) + Max(c2a.z, c2b.z);
+	return Min(u1, v1) >= 0.0f && u0 + v0 <= det * t.t0;
+}
+
+// src/triangle.cpp:3-63 (closest hit).  Per-lane; the quad-level ForAny() there only skips work.
+template <int MODE>
+void collidePrimary(const OrcTri &t, const Rays &r, float *dist, int32_t *obj, float *bary, int idx, int first, int last) {
+	V3 nrm = mk(t.plane), a = mk(t.a), ba = mk(t.ba), ca = mk(t.ca);
+	V3 tvec0{0, 0, 0}, tvec1{0, 0, 0};
+	float tmulS = 0;
+	if(r.shared) {
+		V3 tvec = r.org0() - a;
+		tvec0 = cross(ba, tvec) * t.it0;
+		tvec1 = cross(tvec, ca) * t.it0;
+		tmulS = -dot(tvec, nrm);
+	}
+	for(int q = first; q <= last; q++)
+		for(int l = 0; l < 4; l++) {
+			V3 d{r.D(q, 0, l), r.D(q, 1, l), r.D(q, 2, l)};
+			float det = dot(d, nrm), u, v, tmul;
+			if(r.shared) { v = dot(d, tvec0); u = dot(d, tvec1); tmul = tmulS; }
+			else {
+				V3 tvec = V3{r.O(q, 0, l), r.O(q, 1, l), r.O(q, 2, l)} - a;
+				V3 tv0 = cross(ba, tvec), tv1 = cross(tvec, ca);
+				tmul = -dot(tvec, nrm);
+				v = dot(d, tv0) * t.it0;
+				u = dot(d, tv1) * t.it0;
+			}
+			float duv = det - u - v;
+			float uvmin = Min(u, Min(v, duv)), uvmax = Max(u, Max(v, duv));
+			bool test = uvmax <= 0.0f || uvmin >= 0.0f;
+			if(r.mask) test = test && ((r.mask[q] >> l) & 1);
+			if(!test) continue;
+			float idet = Inv<MODE>(det);
+			float d2 = idet * tmul;
+			if(d2 < dist[q * 4 + l] && d2 > 0.0f) {
+				dist[q * 4 + l] = d2;
+				obj[q * 4 + l] = idx;
+				bary[q * 8 + l] = u * idet;
+				bary[q * 8 + 4 + l] = v * idet;
+			}
+		}
+}
+
+// src/triangle.cpp:65-102 (any hit)
+bool collideShadow(const OrcTri &t, const Rays &r, float *dist, int first, int last) {
+	bool full = (last - first + 1) == r.size;
+	V3 nrm = mk(t.plane), a = mk(t.a);
+	V3 tvec = r.org0() - a;
+	V3 tvec0 = cross(mk(t.ba), tvec) * t.it0, tvec1 = cross(tvec, mk(t.ca)) * t.it0;
+	float tmul = -dot(tvec, nrm);
+	for(int q = first; q <= last; q++)
+		for(int l = 0; l < 4; l++) {
+			V3 d{r.D(q, 0, l), r.D(q, 1, l), r.D(q, 2, l)};
+			float det = dot(d, nrm), v = dot(d, tvec0), u = dot(d, tvec1);
+			bool test = Min(u, v) >= 0.0f && u + v <= det;
+			test = test && tmul > 0.0f && tmul < dist[q * 4 + l] * det;
+			full &= test;
+			if(test) dist[q * 4 + l] = -kInf;
+		}
+	return full;
+}
+
+struct Stats { uint64_t intersects = 0, iters = 0, rays = 0, skips = 0; };
+
+struct StackElem { int node; short first, last; };
+
+// src/bvh/traverse.cpp:14-80
+template <int MODE>
+void traversePrimary(const OrcNode *nodes, const OrcTri *tris, const Rays &r, float *dist, int32_t *obj, float *bary, Stats &st) {
+	StackElem stack[64 + 2]; int sp = 0;
+	stack[sp++] = StackElem{0, 0, (short)(r.size - 1)};
+	int sign[3] = {r.D(0, 0, 0) < 0.0f, r.D(0, 1, 0) < 0.0f, r.D(0, 2, 0) < 0.0f};
+	Interval iv = makeInterval(r, nullptr);
+
+	while(sp) {
+		int nNode = stack[--sp].node, first = stack[sp].first, last = stack[sp].last;
+		for(;;) {
+			st.iters++;
+			const OrcNode &n = nodes[nNode];
+			if(n.sub & 0x80000000u) {
+				int count = n.aux, firstTri = (int)(n.sub & 0x7fffffffu);
+				if(!boxTestInterval(n, iv)) break;
+				if(boxTest<false>(n, r, dist, first, last))
+					for(int k = 0; k < count; k++) {
+						const OrcTri &t = tris[firstTri + k];
+						if(r.shared ? triTestInterval(t, iv) : true) {
+							collidePrimary<MODE>(t, r, dist, obj, bary, firstTri + k, first, last);
+							st.intersects += (uint64_t)(last - first + 1);
+						}
+					}
+				break;
+			}
+			if(!boxTestInterval(n, iv)) break;
+			if(!boxTest<false>(n, r, dist, first, last)) break;
+			int child = (int)n.sub, axis = n.aux & 0xffff, firstNode = (n.aux >> 16) ^ sign[axis];
+			stack[sp++] = StackElem{child + (firstNode ^ 1), (short)first, (short)last};
+			nNode = child + firstNode;
+		}
+	}
+}
+
+// src/bvh/traverse.cpp:82-149
+void traverseShadow(const OrcNode *nodes, const OrcTri *tris, const Rays &r, float *dist, Stats &st) {
+	StackElem stack[64 + 2]; int sp = 0;
+	stack[sp++] = StackElem{0, 0, (short)(r.size - 1)};
+	int sign[3] = {r.D(0, 0, 0) < 0.0f, r.D(0, 1, 0) < 0.0f, r.D(0, 2, 0) < 0.0f};
+	Interval iv = makeInterval(r, dist);
+
+	while(sp) {
+		int nNode = stack[--sp].node, first = stack[sp].first, last = stack[sp].last;
+		for(;;) {
+			st.iters++;
+			const OrcNode &n = nodes[nNode];
+			if(n.sub & 0x80000000u) {
+				int count = n.aux, firstTri = (int)(n.sub & 0x7fffffffu);
+				if(!boxTestInterval(n, iv)) break;
+				if(boxTest<true>(n, r, dist, first, last))
+					for(int k = 0; k < count; k++) {
+						const OrcTri &t = tris[firstTri + k];
+						if(triTestInterval(t, iv)) {
+							if(collideShadow(t, r, dist, first, last)) { st.skips++; return; }
+							st.intersects += (uint64_t)(last - first + 1);
+						}
+					}
+				break;
+			}
+			if(!boxTestInterval(n, iv)) break;
+			if(!boxTest<true>(n, r, dist, first, last)) break;
+			int child = (int)n.sub, axis = n.aux & 0xffff, firstNode = (n.aux >> 16) ^ sign[axis];
+			stack[sp++] = StackElem{child + (firstNode ^ 1), (short)first, (short)last};
+			nNode = child + firstNode;
+		}
+	}
+}
+
+// ---- primary ray generator: src/ray_generator.cpp:4-15 (ctor), :23-47 (Generate, level 3) ---------
+struct RayGen { V3 tright, tup; float txyz[3][4]; };
+
+RayGen makeRayGen(const OrcCamera &cam, int w, int h) {
+	RayGen g;
+	float invW = 1.0f / float(w), invH = 1.0f / float(h);
+	invW *= float(w) / float(h);
+	const float ax[4] = {0.0f, 1.0f, 0.0f, 1.0f}, ay[4] = {0.0f, 0.0f, 1.0f, 1.0f};
+	g.tright = mk(cam.right) * invW;
+	g.tup = mk(cam.up) * invH;
+	V3 fp = mk(cam.front) * cam.plane_dist;
+	for(int l = 0; l < 4; l++) {
+		float taddx = ax[l] - w * 0.5f, taddy = ay[l] - h * 0.5f;
+		g.txyz[0][l] = g.tright.x * taddx + g.tup.x * taddy + fp.x;
+		g.txyz[1][l] = g.tright.y * taddx + g.tup.y * taddy + fp.y;
+		g.txyz[2][l] = g.tright.z * taddx + g.tup.z * taddy + fp.z;
+	}
+	return g;
+}
+
+template <int MODE>
+void genPacket(const RayGen &g, int x, int y, float *dir, float *idir) {
+	const float xoff[4] = {float(x + 0), float(x + 0), float(x + 2), float(x + 2)};
+	const float yoff[4] = {float(y + 0), float(y + 0), float(y - 1), float(y - 1)};
+	for(int ty = 0; ty < 16; ty++)
+		for(int k = 0; k < 4; k++) {
+			int q = ty * 4 + k;
+			for(int l = 0; l < 4; l++) {
+				float tposx = float(4 * k) + xoff[l];
+				float tposy = float(ty) + yoff[l];
+				float px = g.tright.x * tposx + (g.tup.x * tposy + g.txyz[0][l]);
+				float py = g.tright.y * tposx + (g.tup.y * tposy + g.txyz[1][l]);
+				float pz = g.tright.z * tposx + (g.tup.z * tposy + g.txyz[2][l]);
+				float rs = RSqrt<MODE>(px * px + py * py + pz * pz);
+				float d[3] = {px * rs, py * rs, pz * rs};
+				for(int c = 0; c < 3; c++) {
+					dir[q * 12 + c * 4 + l] = d[c];
+					idir[q * 12 + c * 4 + l] = Inv<MODE>(d[c] + 0.00000001f); // SafeInv, src/rtbase.h:117-120
+				}
+			}
+		}
+}
+
+// ---- single-ray accounting walk ------------------------------------------------
+template <int MODE>
+void accountRay(const OrcNode *nodes, const OrcTri *tris, V3 o, V3 d, V3 id, uint64_t &vn, uint64_t &vt, uint64_t &hits) {
+	int stack[66]; int sp = 0;
+	stack[sp++] = 0;
+	int sign[3] = {d.x < 0.0f, d.y < 0.0f, d.z < 0.0f};
+	float dist = kInf;
+	while(sp) {
+		int nNode = stack[--sp];
+		for(;;) {
+			const OrcNode &n = nodes[nNode];
+			vn++;
+			float lmin = 0, lmax = 0;
+			for(int k = 0; k < 3; k++) {
+				float l1 = id[k] * (n.bmin[k] - o[k]), l2 = id[k] * (n.bmax[k] - o[k]);
+				if(k == 0) { lmin = Min(l1, l2); lmax = Max(l1, l2); }
+				else { lmin = Max(lmin, Min(l1, l2)); lmax = Min(lmax, Max(l1, l2)); }
+			}
+			if(lmax < 0.0f || lmin > Min(lmax, dist)) break;
+			if(n.sub & 0x80000000u) {
+				int count = n.aux, firstTri = (int)(n.sub & 0x7fffffffu);
+				for(int k = 0; k < count; k++) {
+					const OrcTri &t = tris[firstTri + k];
+					vt++;
+					V3 nrm = mk(t.plane), tvec = o - mk(t.a);
+					V3 tvec0 = cross(mk(t.ba), tvec) * t.it0, tvec1 = cross(tvec, mk(t.ca)) * t.it0;
+					float tmul = -dot(tvec, nrm);
+					float det = dot(d, nrm), v = dot(d, tvec0), u = dot(d, tvec1), duv = det - u - v;
+					float uvmin = Min(u, Min(v, duv)), uvmax = Max(u, Max(v, duv));
+					if(!(uvmax <= 0.0f || uvmin >= 0.0f)) continue;
+					float t2 = Inv<MODE>(det) * tmul;
+					if(t2 < dist && t2 > 0.0f) dist = t2;
+				}
+				break;
+			}
+			int child = (int)n.sub, axis = n.aux & 0xffff, firstNode = (n.aux >> 16) ^ sign[axis];
+			stack[sp++] = child + (firstNode ^ 1);
+			nNode = child + firstNode;
+		}
+	}
+	if(dist < kInf) hits++;
+}
+
+template <class F>
+void parallelFor(int n, int threads, F f) {
+	if(threads <= 1) { for(int i = 0; i < n; i++) f(i, 0); return; }
+	std::atomic<int> next{0};
+	std::vector<std::thread> pool;
+	for(int t = 0; t < threads; t++)
+		pool.emplace_back([&, t] { for(int i; (i = next.fetch_add(1)) < n;) f(i, t); });
+	for(auto &th : pool) th.join();
+}
+
+template <int MODE>
+void renderPrimary(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam, int resx, int resy, int x0, int y0, int w, int h,
+				   float *ot, float *ou, float *ov, int32_t *oid, uint64_t *stats, int threads) {
+	RayGen g = makeRayGen(*cam, resx, resy);
+	int pw = (w + 15) / 16, ph = (h + 15) / 16;
+	threads = std::max(threads, 1);
+	std::vector<Stats> tstats(threads);
+	float origin[12];
+	for(int c = 0; c < 3; c++) for(int l = 0; l < 4; l++) origin[c * 4 + l] = cam->pos[c];
+
+	parallelFor(pw * ph, threads, [&](int p, int tid) {
+		int px = x0 + (p % pw) * 16, py = y0 + (p / pw) * 16;
+		float dir[768], idir[768], dist[256], bary[512];
+		int32_t obj[256];
+		genPacket<MODE>(g, px, py, dir, idir);
+		for(int i = 0; i < 256; i++) { dist[i] = kInf; obj[i] = 0; }   // src/scene_trace.cpp:112-115
+		memset(bary, 0, sizeof(bary));
+		Rays r{64, true, origin, dir, idir, nullptr};
+		Stats &st = tstats[tid];
+		st.rays += 256;                                                 // src/scene_trace.cpp:116-117
+		traversePrimary<MODE>(nodes, tris, r, dist, obj, bary, st);
+		for(int q = 0; q < 64; q++) {
+			int yy = py + (q >> 2);
+			if(yy >= resy || yy >= y0 + h) continue;
+			for(int l = 0; l < 4; l++) {
+				int xx = px + (q & 3) * 4 + l;
+				if(xx >= resx || xx >= x0 + w) continue;
+				size_t o = (size_t)yy * resx + xx;
+				if(ot) ot[o] = dist[q * 4 + l];
+				if(ou) ou[o] = bary[q * 8 + l];
+				if(ov) ov[o] = bary[q * 8 + 4 + l];
+				if(oid) oid[o] = obj[q * 4 + l];
+			}
+		}
+	});
+	if(stats) for(auto &s : tstats) { stats[0] += s.intersects; stats[1] += s.iters; stats[2] += s.rays; stats[3] += s.skips; }
+}
+
+template <int MODE>
+void accountPrimary(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam, int resx, int resy, int x0, int y0, int w, int h,
+					uint64_t *out, int threads) {
+	RayGen g = makeRayGen(*cam, resx, resy);
+	int pw = (w + 15) / 16, ph = (h + 15) / 16;
+	threads = std::max(threads, 1);
+	std::vector<uint64_t> acc((size_t)threads * 4, 0);
+	parallelFor(pw * ph, threads, [&](int p, int tid) {
+		int px = x0 + (p % pw) * 16, py = y0 + (p / pw) * 16;
+		float dir[768], idir[768];
+		genPacket<MODE>(g, px, py, dir, idir);
+		uint64_t *a = &acc[(size_t)tid * 4];
+		for(int q = 0; q < 64; q++) for(int l = 0; l < 4; l++) {
+			V3 d{dir[q * 12 + l], dir[q * 12 + 4 + l], dir[q * 12 + 8 + l]};
+			V3 id{idir[q * 12 + l], idir[q * 12 + 4 + l], idir[q * 12 + 8 + l]};
+			a[0]++;
+			accountRay<MODE>(nodes, tris, mk(cam->pos), d, id, a[1], a[2], a[3]);
+		}
+	});
+	for(int t = 0; t < threads; t++) for(int k = 0; k < 4; k++) out[k] += acc[(size_t)t * 4 + k];
+}
+
+uint64_t fnv1a(uint64_t h, const void *p, size_t n) {
+	const unsigned char *b = (const unsigned char *)p;
+	for(size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001b3ull; }
+	return h;
+}
+
+} // namespace
+
+extern "C" {
+
+void orc_tris_from_verts(const float *verts, int n, OrcTri *out) {
+	for(int i = 0; i < n; i++) {
+		V3 v0 = mk(verts + i * 9), v1 = mk(verts + i * 9 + 3), v2 = mk(verts + i * 9 + 6);
+		V3 ba = v1 - v0, ca = v2 - v0;
+		V3 nrm = cross(ba, ca);
+		float len = sqrtf(dot(nrm, nrm));
+		float inv = 1.0f / len;                        // Vec3::operator/=(base), veclib/vec3.h:47-51
+		nrm = nrm * inv;
+		OrcTri &t = out[i];
+		t.a[0] = v0.x; t.a[1] = v0.y; t.a[2] = v0.z;
+		t.ba[0] = ba.x; t.ba[1] = ba.y; t.ba[2] = ba.z;
+		t.ca[0] = ca.x; t.ca[1] = ca.y; t.ca[2] = ca.z;
+		t.t0 = len; t.it0 = 1.0f / len; t.pad = 0;
+		t.plane[0] = nrm.x; t.plane[1] = nrm.y; t.plane[2] = nrm.z; t.plane[3] = dot(nrm, v0);
+	}
+}
+
+int orc_bvh_build(OrcTri *tris, int n, OrcNode *nodes, int *depth, int32_t *perm) {
+	if(n <= 0) return 0;
+	if(perm) for(int i = 0; i < n; i++) perm[i] = i;
+	Builder b{tris, perm, nodes};
+	Box bbox = triBox(tris[0]);
+	for(int i = 1; i < n; i++) grow(bbox, triBox(tris[i]));
+	b.setBox(0, bbox);
+	b.nNodes = 1;
+	nodes[0].sub = 0; nodes[0].aux = 0;
+	b.split(0, 0, n, 0);
+	if(depth) *depth = b.depth;
+	return b.nNodes;
+}
+
+uint64_t orc_fnv_nodes(const OrcNode *nodes, int n) { return fnv1a(0xcbf29ce484222325ull, nodes, (size_t)n * sizeof(OrcNode)); }
+uint64_t orc_fnv_tris(const OrcTri *tris, int n) {
+	uint64_t h = 0xcbf29ce484222325ull;
+	for(int i = 0; i < n; i++) {
+		h = fnv1a(h, &tris[i], 44);
+		h = fnv1a(h, (const char *)&tris[i] + 48, 16);
+	}
+	return h;
+}
+
+void orc_gen_packet(const OrcCamera *cam, int resx, int resy, int px, int py, int mode, float *dir, float *idir) {
+	RayGen g = makeRayGen(*cam, resx, resy);
+	if(mode == ORC_MODE_SSE) genPacket<ORC_MODE_SSE>(g, px, py, dir, idir);
+	else genPacket<ORC_MODE_IEEE>(g, px, py, dir, idir);
+}
+
+void orc_trace_rays(const OrcNode *nodes, const OrcTri *tris, int npackets, int size, int sharedOrigin, const float *origin,
+					const float *dir, const float *idir, const uint8_t *mask, float *distance, int32_t *object, float *bary,
+					uint64_t *stats, int mode) {
+	Stats st;
+	for(int p = 0; p < npackets; p++) {
+		size_t qo = (size_t)p * size;
+		Rays r{size, sharedOrigin != 0, origin + (sharedOrigin ? (size_t)p * 12 : qo * 12), dir + qo * 12, idir + qo * 12,
+			   mask ? mask + qo : nullptr};
+		if(mode == ORC_MODE_SSE) traversePrimary<ORC_MODE_SSE>(nodes, tris, r, distance + qo * 4, object + qo * 4, bary + qo * 8, st);
+		else traversePrimary<ORC_MODE_IEEE>(nodes, tris, r, distance + qo * 4, object + qo * 4, bary + qo * 8, st);
+	}
+	if(stats) { stats[0] += st.intersects; stats[1] += st.iters; stats[2] += st.rays; stats[3] += st.skips; }
+}
+
+void orc_trace_shadow(const OrcNode *nodes, const OrcTri *tris, int npackets, int size, const float *origin, const float *dir,
+					  const float *idir, float *distance, uint64_t *stats, int mode) {
+	(void)mode; // no approximate operation on the any-hit path (src/triangle.cpp:94-95: no division)
+	Stats st;
+	for(int p = 0; p < npackets; p++) {
+		size_t qo = (size_t)p * size;
+		float org[12];
+		for(int c = 0; c < 3; c++) for(int l = 0; l < 4; l++) org[c * 4 + l] = origin[p * 3 + c];
+		Rays r{size, true, org, dir + qo * 12, idir + qo * 12, nullptr};
+		traverseShadow(nodes, tris, r, distance + qo * 4, st);
+	}
+	if(stats) { stats[0] += st.intersects; stats[1] += st.iters; stats[2] += st.rays; stats[3] += st.skips; }
+}
+
+void orc_render_primary(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam, int resx, int resy, int x0, int y0, int w,
+						int h, float *t, float *u, float *v, int32_t *triId, uint64_t *stats, int mode, int threads) {
+	if(mode == ORC_MODE_SSE) renderPrimary<ORC_MODE_SSE>(nodes, tris, cam, resx, resy, x0, y0, w, h, t, u, v, triId, stats, threads);
+	else renderPrimary<ORC_MODE_IEEE>(nodes, tris, cam, resx, resy, x0, y0, w, h, t, u, v, triId, stats, threads);
+}
+
+void orc_account_primary(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam, int resx, int resy, int x0, int y0, int w,
+						 int h, uint64_t *out, int mode, int threads) {
+	if(mode == ORC_MODE_SSE) accountPrimary<ORC_MODE_SSE>(nodes, tris, cam, resx, resy, x0, y0, w, h, out, threads);
+	else accountPrimary<ORC_MODE_IEEE>(nodes, tris, cam, resx, resy, x0, y0, w, h, out, threads);
+}
+
+float orc_inv(float x, int mode) { return mode == ORC_MODE_SSE ? Inv<ORC_MODE_SSE>(x) : Inv<ORC_MODE_IEEE>(x); }
+float orc_rsqrt(float x, int mode) { return mode == ORC_MODE_SSE ? RSqrt<ORC_MODE_SSE>(x) : RSqrt<ORC_MODE_IEEE>(x); }
+float orc_min(float a, float b) { return Min(a, b); }
+float orc_max(float a, float b) { return Max(a, b); }
+
+} // extern "C"

@@ -1,0 +1,104 @@
+/*
+ * snail_oracle.h -- C-ABI of the CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * This library is a CPU restatement of the hot path of nadult/Snail (packetised SAH-BVH
+ * traversal + ray/triangle intersection).  It exists only so that tests/, __graft_entry__.smoke()
+ * and bench.py's `cpu_baseline` leg can CHECK the HIP path; nothing under snail_amd/ may import,
+ * link or call it.
+ *
+ * PARITY STATUS: "parity unpinned" in the strict sense of the build contract -- the reference has no
+ * tests/golden vectors for this path and its translation units cannot be
+ * compiled here without a stand-in for the absent libfwk submodule (which the contract forbids).
+ * What IS pinned: (1) the arithmetic primitives (Inv/RSqrt/Min/Max/Condition, Vec3 dot/cross) against
+ * the reference's own header-only veclib compiled from /root/reference/veclib (oracle/_ref/veclib_probe);
+ * (2) the digests SURVEY.md section 8(c) recorded from the reference during the survey session
+ * (box / lancia / feline / barracks tree hashes and hit sums), checked by tests/test_survey_digests.py.
+ *
+ * Two arithmetic modes for the two approximate operations of the path (Inv, RSqrt):
+ *   ORC_MODE_IEEE (0): veclib's scalar definitions  Inv(x)=1.0f/x, RSqrt(x)=1.0f/sqrtf(x)
+ *                      (veclib/vecbase.h:53-55) -- bit-reproducible on any IEEE machine incl. gfx950.
+ *   ORC_MODE_SSE  (1): veclib's SSE definitions     rcpps/rsqrtps + one Newton step
+ *                      (veclib/sse/base.h:84-92)    -- what the reference executes on x86; the raw
+ *                      approximations are CPU-vendor specific.
+ */
+#ifndef SNAIL_ORACLE_H
+#define SNAIL_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORC_MODE_IEEE = 0, ORC_MODE_SSE = 1 };
+
+/* 64-byte triangle record, identical to the reference's `Triangle` (src/triangle.h:133-135):
+ * a, ba, ca, t0, it0, pad, plane(nx,ny,nz,n.a) */
+typedef struct OrcTri { float a[3], ba[3], ca[3]; float t0, it0; int32_t pad; float plane[4]; } OrcTri;
+
+/* 32-byte node record, identical to `BVH::Node` (src/bvh/tree.h:60-72), little-endian variant:
+ * bbox min,max; subNode|first (bit31 = leaf); {short axis, short firstNode} union int count */
+typedef struct OrcNode { float bmin[3], bmax[3]; uint32_t sub; int32_t aux; } OrcNode;
+
+/* camera as the reference's `Camera` (src/camera.h:7-14) flattened: pos, right, up, front, plane_dist */
+typedef struct OrcCamera { float pos[3], right[3], up[3], front[3], plane_dist; } OrcCamera;
+
+/* Triangle::Triangle + ComputeData (src/triangle.h:16-21,123-131). verts = n*9 floats (v0,v1,v2). */
+void orc_tris_from_verts(const float *verts, int n, OrcTri *out);
+
+/* BVH::Construct with flags = useSah (src/bvh/tree.cpp:293-328 -> FindSplitSweep :51-159).
+ * Permutes `tris` in place (this defines triId). `perm[i]` = original index of the triangle now at i
+ * (may be NULL). `nodes` must have room for 2*n entries. Returns node count; *depth as BVH::depth. */
+int orc_bvh_build(OrcTri *tris, int n, OrcNode *nodes, int *depth, int32_t *perm);
+
+/* FNV-1a 64 over node bytes / over triangle bytes skipping the uninitialised pad word (bytes 44..47) */
+uint64_t orc_fnv_nodes(const OrcNode *nodes, int n);
+uint64_t orc_fnv_tris(const OrcTri *tris, int n);
+
+/* RayGenerator ctor + Generate(level 3) + SafeInv (src/ray_generator.cpp:4-47, src/rtbase.h:117-120).
+ * dir/idir: 64 quads x {x[4],y[4],z[4]} = 768 floats each (the Vec3q memory layout). */
+void orc_gen_packet(const OrcCamera *cam, int resx, int resy, int px, int py, int mode,
+                    float *dir, float *idir);
+
+/* BVH::TraversePrimaryN<sharedOrigin,hasMask> (src/bvh/traverse.cpp:14-80) over `npackets` packets of
+ * `size` quads each.  Layouts are the reference's Context arrays: origin {x[4],y[4],z[4]} per quad
+ * (one quad total per packet when shared), dir/idir likewise, mask = 1 byte per quad (low 4 bits) or
+ * NULL, distance[4]/object[4] per quad, bary {u[4],v[4]} per quad.  In/out: distance, object, bary
+ * must be initialised by the caller as Scene::RayTrace does (src/scene_trace.cpp:112-115).
+ * stats[4] += {intersects, iters, rays(unchanged), skips}. */
+void orc_trace_rays(const OrcNode *nodes, const OrcTri *tris, int npackets, int size, int sharedOrigin,
+                    const float *origin, const float *dir, const float *idir, const uint8_t *mask,
+                    float *distance, int32_t *object, float *bary, uint64_t *stats, int mode);
+
+/* BVH::TraverseShadow (src/bvh/traverse.cpp:82-149). origin = 3 floats per packet (light position). */
+void orc_trace_shadow(const OrcNode *nodes, const OrcTri *tris, int npackets, int size,
+                      const float *origin, const float *dir, const float *idir,
+                      float *distance, uint64_t *stats, int mode);
+
+/* RenderTask::Work restricted to traversal (src/render.cpp:58-62,67-68,112-115 +
+ * src/scene_trace.cpp:106-120): every 16x16 packet whose top-left lies in [x0,x0+w) x [y0,y0+h)
+ * (x0,y0,w,h multiples of 16 except at the image edge). Outputs row-major resx*resy planes (only the
+ * rect is written); pixels outside the image are traced (they are part of their packet) but not
+ * stored. miss = (+inf, 0, 0, 0). stats[4] += {intersects, iters, rays, skips}. threads>=1. */
+void orc_render_primary(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam,
+                        int resx, int resy, int x0, int y0, int w, int h,
+                        float *t, float *u, float *v, int32_t *triId, uint64_t *stats,
+                        int mode, int threads);
+
+/* Single-ray, cache-less accounting walk of SURVEY.md section 8(d): for every pixel of the rect (padded
+ * to whole packets as above) walk the tree with that ray alone (child order from its own direction
+ * signs, strict-< closest-hit pruning) and count V_n (node boxes tested) and V_t (triangles tested).
+ * out[0] += rays, out[1] += sum V_n, out[2] += sum V_t, out[3] += hits. */
+void orc_account_primary(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam,
+                         int resx, int resy, int x0, int y0, int w, int h, uint64_t *out,
+                         int mode, int threads);
+
+/* arithmetic primitives exposed for the veclib pin test */
+float orc_inv(float x, int mode);
+float orc_rsqrt(float x, int mode);
+float orc_min(float a, float b);
+float orc_max(float a, float b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

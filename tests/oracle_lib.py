@@ -1,0 +1,125 @@
+"""ctypes binding of oracle/liboracle.so -- TEST INFRASTRUCTURE (the checker, never the product)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+
+MODE_IEEE, MODE_SSE = 0, 1
+
+TRI_DTYPE = np.dtype([("a", "<f4", 3), ("ba", "<f4", 3), ("ca", "<f4", 3), ("t0", "<f4"), ("it0", "<f4"),
+                      ("pad", "<i4"), ("plane", "<f4", 4)])
+NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("sub", "<u4"), ("aux", "<i4")])
+assert TRI_DTYPE.itemsize == 64 and NODE_DTYPE.itemsize == 32
+
+_lib = None
+
+
+def build():
+    src = os.path.join(ORACLE_DIR, "snail_oracle.cpp")
+    if (not os.path.exists(LIB_PATH)) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        vp, i32, u64p = C.c_void_p, C.c_int, C.c_void_p
+        L.orc_tris_from_verts.argtypes = [vp, i32, vp]
+        L.orc_bvh_build.argtypes = [vp, i32, vp, vp, vp]
+        L.orc_bvh_build.restype = i32
+        L.orc_fnv_nodes.argtypes = [vp, i32]
+        L.orc_fnv_nodes.restype = C.c_uint64
+        L.orc_fnv_tris.argtypes = [vp, i32]
+        L.orc_fnv_tris.restype = C.c_uint64
+        L.orc_gen_packet.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
+        L.orc_trace_rays.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, u64p, i32]
+        L.orc_trace_shadow.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, u64p, i32]
+        L.orc_render_primary.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, u64p, i32, i32]
+        L.orc_account_primary.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, u64p, i32, i32]
+        for f in (L.orc_inv, L.orc_rsqrt):
+            f.argtypes = [C.c_float, i32]
+            f.restype = C.c_float
+        for f in (L.orc_min, L.orc_max):
+            f.argtypes = [C.c_float, C.c_float]
+            f.restype = C.c_float
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def tris_from_verts(tri_verts: np.ndarray) -> np.ndarray:
+    tv = np.ascontiguousarray(tri_verts, dtype=np.float32).reshape(-1, 9)
+    out = np.zeros(len(tv), dtype=TRI_DTYPE)
+    lib().orc_tris_from_verts(_p(tv), len(tv), _p(out))
+    return out
+
+
+class OracleScene:
+    """tris (BVH order), nodes, depth, perm (BVH index -> input index)."""
+
+    def __init__(self, tri_verts: np.ndarray):
+        self.tris = tris_from_verts(tri_verts)
+        n = len(self.tris)
+        nodes = np.zeros(2 * n + 2, dtype=NODE_DTYPE)
+        self.perm = np.zeros(n, dtype=np.int32)
+        depth = C.c_int(0)
+        nn = lib().orc_bvh_build(_p(self.tris), n, _p(nodes), C.byref(depth), _p(self.perm))
+        self.nodes = np.ascontiguousarray(nodes[:nn])
+        self.depth = depth.value
+
+    def fnv_nodes(self) -> int:
+        return lib().orc_fnv_nodes(_p(self.nodes), len(self.nodes))
+
+    def fnv_tris(self) -> int:
+        return lib().orc_fnv_tris(_p(self.tris), len(self.tris))
+
+    def render_primary(self, cam13: np.ndarray, resx, resy, rect=None, mode=MODE_IEEE, threads=8):
+        x0, y0, w, h = rect if rect else (0, 0, resx, resy)
+        cam = np.ascontiguousarray(cam13, dtype=np.float32)
+        t = np.full((resy, resx), np.nan, dtype=np.float32)
+        u = np.zeros((resy, resx), dtype=np.float32)
+        v = np.zeros((resy, resx), dtype=np.float32)
+        tid = np.zeros((resy, resx), dtype=np.int32)
+        stats = np.zeros(4, dtype=np.uint64)
+        lib().orc_render_primary(_p(self.nodes), _p(self.tris), _p(cam), resx, resy, x0, y0, w, h,
+                                 _p(t), _p(u), _p(v), _p(tid), _p(stats), mode, threads)
+        return t, u, v, tid, stats
+
+    def account_primary(self, cam13, resx, resy, rect=None, mode=MODE_IEEE, threads=8):
+        x0, y0, w, h = rect if rect else (0, 0, resx, resy)
+        cam = np.ascontiguousarray(cam13, dtype=np.float32)
+        out = np.zeros(4, dtype=np.uint64)
+        lib().orc_account_primary(_p(self.nodes), _p(self.tris), _p(cam), resx, resy, x0, y0, w, h, _p(out), mode, threads)
+        return out
+
+    def trace_rays(self, origin, dir, idir, mask, distance, obj, bary, npackets, size, shared, mode=MODE_IEEE):
+        stats = np.zeros(4, dtype=np.uint64)
+        lib().orc_trace_rays(_p(self.nodes), _p(self.tris), npackets, size, int(shared), _p(origin), _p(dir), _p(idir),
+                             _p(mask), _p(distance), _p(obj), _p(bary), _p(stats), mode)
+        return stats
+
+    def trace_shadow(self, origin, dir, idir, distance, npackets, size, mode=MODE_IEEE):
+        stats = np.zeros(4, dtype=np.uint64)
+        lib().orc_trace_shadow(_p(self.nodes), _p(self.tris), npackets, size, _p(origin), _p(dir), _p(idir), _p(distance),
+                               _p(stats), mode)
+        return stats
+
+
+def gen_packet(cam13, resx, resy, px, py, mode=MODE_IEEE):
+    cam = np.ascontiguousarray(cam13, dtype=np.float32)
+    d = np.zeros(768, dtype=np.float32)
+    i = np.zeros(768, dtype=np.float32)
+    lib().orc_gen_packet(_p(cam), resx, resy, px, py, mode, _p(d), _p(i))
+    return d, i
