@@ -1,0 +1,119 @@
+/*
+ * snail_hip.h -- C-ABI of libsnailhip.so: the MI355X (gfx950) replacement for the hot path of
+ * nadult/Snail: packetised SAH-BVH traversal + ray/triangle intersection.
+ *
+ * The reference has no FFI layer; its seam is the compile-time `AccStruct` concept of
+ * `template <class AccStruct> class Scene` (src/scene.h:26-58) and, one level up, the tile API of
+ * src/render.h:16-28.  A per-packet GPU call (256 rays) would be launch-latency bound, so this
+ * boundary sits at frame / tile / packet-batch granularity; include/snail_adapter.hpp re-exposes the
+ * reference's own shapes (an AccStruct-conforming class and Render(...) overloads) on top of it.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success and a non-zero
+ * status on failure with the text available from snail_last_error() (the reference aborts through
+ * FATAL/ASSERT, src/rtbase.h:13 -- the adapter turns non-zero into that behaviour).  Buffers are
+ * caller-owned.  `*_dev` entry points take DEVICE pointers and a hipStream_t (as void*), never
+ * synchronise and are graph-capturable; the un-suffixed entry points take HOST pointers, run on the
+ * scene's device and return after the results are in the host buffers.
+ *
+ * Record layouts are the reference's own:
+ *   node  = 32 B  `BVH::Node`  (src/bvh/tree.h:60-72): bbox min[3], max[3]; subNode|first (bit 31 =
+ *                 leaf); {short axis, short firstNode} (inner) or int count (leaf)
+ *   tri   = 64 B  `Triangle`   (src/triangle.h:133-135): a, ba, ca, t0, it0, pad, plane(n, n.a)
+ *   quad arrays  = the memory layout of `Vec3q[]`, `floatq[]`, `i32x4[]`, `Vec2q[]`:
+ *                 dir/idir/origin: per quad {x[4], y[4], z[4]} (12 floats); distance/object: 4 per quad;
+ *                 barycentric: per quad {u[4], v[4]} (8 floats); mask: 1 byte per quad, low 4 bits.
+ *   stats[4]     = {intersects, loop iterations, traced rays, skips}: TreeStats data[0], [1], [2], [9]
+ *                 (src/tree_stats.h:86-113); counters are ADDED to.
+ */
+#ifndef SNAIL_HIP_H
+#define SNAIL_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct SnailScene SnailScene;
+
+#define SNAIL_PACKET_QUADS 64   /* 16x16 pixels = 64 SSE quads = 256 rays (src/render.cpp:50-53)   */
+#define SNAIL_MAX_DEPTH    64   /* BVH::maxDepth (src/bvh/tree.h:33)                               */
+
+/* ---- errors -------------------------------------------------------------------------------------- */
+const char *snail_last_error(void);
+/* Non-zero when the library was built with device code for the running GPU and a HIP device exists. */
+int snail_device_count(void);
+
+/* ---- host-side scene construction (stays on the CPU, exactly as in the reference) --------------- */
+/* Triangle::Triangle + ComputeData (src/triangle.h:16-21,123-131). verts9: n x (v0,v1,v2). */
+int snail_tris_from_verts(const float *verts9, int n, void *tris64);
+/* BVH::Construct(scene, BVH::useSah) -> FindSplitSweep (src/bvh/tree.cpp:293-328, 51-159).
+ * Permutes tris64 in place (this ordering DEFINES triId).  nodes32 must hold 2*nTris records.
+ * perm (optional) receives, per final slot, the index the triangle had on input. */
+int snail_bvh_build(void *tris64, int nTris, void *nodes32, int *nNodes, int *depth, int32_t *perm);
+
+/* ---- device scene -------------------------------------------------------------------------------- */
+/* Mirrors the public BVH::nodes / BVH::tris / BVH::depth (src/bvh/tree.h:86-92), i.e. what the
+ * reference ships to a render node in SendBVH (src/server.cpp:144-164).  Copies to `device`. */
+SnailScene *snail_scene_create(const void *nodes32, int nNodes, const void *tris64, int nTris, int depth, int device);
+void snail_scene_destroy(SnailScene *);
+int snail_scene_info(const SnailScene *, int *nNodes, int *nTris, int *depth, int *device);
+
+/* ---- primary packets: RayGenerator + SafeInv + TraversePrimary<1,0> ----------------------------- */
+/* Replaces the per-packet body of RenderTask::Work (src/render.cpp:58-62,67-68,112-115) plus the
+ * hit-array initialisation of Scene::RayTrace (src/scene_trace.cpp:106-120) for every 16x16 packet
+ * whose top-left corner lies in the rect [x0,x0+w) x [y0,y0+h) (x0,y0 multiples of 16).
+ * cam = pos[3], right[3], up[3], front[3], plane_dist (src/camera.h:7-14).
+ * Outputs are row-major resx*resy planes; only pixels inside both the rect and the image are written;
+ * rays of a packet that fall outside the image are still traced (they are part of the packet).
+ * miss = (t=+inf, u=0, v=0, triId=0) as src/scene_trace.cpp:112-115.  Any output plane may be NULL. */
+int snail_trace_primary(SnailScene *, const float cam[13], int resx, int resy, int x0, int y0, int w, int h,
+                        float *t, float *u, float *v, int32_t *triId, uint64_t stats[4]);
+int snail_trace_primary_dev(SnailScene *, const float cam[13], int resx, int resy, int x0, int y0, int w, int h,
+                            float *d_t, float *d_u, float *d_v, int32_t *d_triId, uint64_t *d_stats, void *stream);
+
+/* Same, for an explicit list of packets (tile sharding, src/render.cpp:244-267 / src/node.cpp:336-338):
+ * d_packet_xy = nPackets x (x,y) top-left pixel.  Outputs are PACKET-MAJOR in the reference's quad
+ * order (quad ty*4+k = pixels x+4k..x+4k+3 of row y+ty, src/ray_generator.cpp:29-45): element
+ * [p*256 + q*4 + lane], i.e. exactly the Context arrays host shading reads (bary as two planes). */
+int snail_trace_packets_dev(SnailScene *, const float cam[13], int resx, int resy, const int32_t *d_packet_xy, int nPackets,
+                            float *d_t, float *d_u, float *d_v, int32_t *d_triId, uint64_t *d_stats, void *stream);
+/* Scatter packet-major planes into row-major resx*resy frame planes (clipped to the image). */
+int snail_packets_to_frame_dev(const int32_t *d_packet_xy, int nPackets, int resx, int resy,
+                               const float *d_pt, const float *d_pu, const float *d_pv, const int32_t *d_pid,
+                               float *d_t, float *d_u, float *d_v, int32_t *d_triId, void *stream);
+
+/* ---- arbitrary packets: TraversePrimary<sharedOrigin,hasMask>(Context&) ------------------------- */
+/* src/bvh/traverse.cpp:14-80, callers src/scene_trace.cpp:119-120 (primary), :615-617 (reflection),
+ * :631-633 (transparency).  nPackets packets of `size` quads (1..64).  origin: one quad per packet if
+ * sharedOrigin else `size` quads per packet.  mask: NULL (hasMask=0) or 1 byte per quad.
+ * distance/object/bary are IN/OUT and must be initialised by the caller as Scene::RayTrace does
+ * (+inf / -inf for masked lanes, 0).  `element` of Context is not written by BVH and is not passed. */
+int snail_trace_rays(SnailScene *, int nPackets, int size, int sharedOrigin, const float *origin, const float *dir,
+                     const float *idir, const uint8_t *mask, float *distance, int32_t *object, float *bary, uint64_t stats[4]);
+int snail_trace_rays_dev(SnailScene *, int nPackets, int size, int sharedOrigin, const float *d_origin, const float *d_dir,
+                         const float *d_idir, const uint8_t *d_mask, float *d_distance, int32_t *d_object, float *d_bary,
+                         uint64_t *d_stats, void *stream);
+
+/* ---- shadow packets: TraverseShadow(ShadowContext&) --------------------------------------------- */
+/* src/bvh/traverse.cpp:82-149, caller src/scene_trace.cpp:560-563.  origin = 3 floats per packet (the
+ * light position).  distance is IN/OUT: in = max t per lane, negative = lane masked; out = -inf where
+ * occluded (src/triangle.cpp:94-98). */
+int snail_trace_shadow(SnailScene *, int nPackets, int size, const float *origin3, const float *dir, const float *idir,
+                       float *distance, uint64_t stats[4]);
+int snail_trace_shadow_dev(SnailScene *, int nPackets, int size, const float *d_origin3, const float *d_dir, const float *d_idir,
+                           float *d_distance, uint64_t *d_stats, void *stream);
+
+/* ---- measurement support ------------------------------------------------------------------------- */
+/* Single-ray, cache-less accounting walk of SURVEY.md section 8(d) over the same padded packet set as
+ * snail_trace_primary: d_out[0] += rays, [1] += sum V_n (node boxes tested), [2] += sum V_t
+ * (triangles tested), [3] += hits.  Used by bench.py to price algorithmic bytes:
+ * B_alg(ray) = 32*V_n + 64*V_t + 16. */
+int snail_account_primary(SnailScene *, const float cam[13], int resx, int resy, int x0, int y0, int w, int h, uint64_t out[4]);
+
+/* Launch geometry of the last primary launch on this scene (for profiles): waves, blocks, VGPR-independent. */
+int snail_last_launch(const SnailScene *, int *blocks, int *threadsPerBlock);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

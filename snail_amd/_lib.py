@@ -1,0 +1,75 @@
+"""ctypes binding of libsnailhip.so (the C-ABI of include/snail_hip.h).
+
+There is NO fallback: if the HIP library is missing or a call fails, SnailError is raised.  Nothing in
+this package imports or calls the CPU oracle under oracle/ (that is test infrastructure)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsnailhip.so")
+
+
+class SnailError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# name -> (restype, argtypes); kept in one table so tests can check every symbol of include/snail_hip.h
+_VP, _I, _F13 = C.c_void_p, C.c_int, C.c_void_p
+SIGNATURES = {
+    "snail_last_error": (C.c_char_p, []),
+    "snail_device_count": (_I, []),
+    "snail_tris_from_verts": (_I, [_VP, _I, _VP]),
+    "snail_bvh_build": (_I, [_VP, _I, _VP, _VP, _VP, _VP]),
+    "snail_scene_create": (_VP, [_VP, _I, _VP, _I, _I, _I]),
+    "snail_scene_destroy": (None, [_VP]),
+    "snail_scene_info": (_I, [_VP, _VP, _VP, _VP, _VP]),
+    "snail_trace_primary": (_I, [_VP, _F13, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),
+    "snail_trace_primary_dev": (_I, [_VP, _F13, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "snail_trace_packets_dev": (_I, [_VP, _F13, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "snail_packets_to_frame_dev": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "snail_trace_rays": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "snail_trace_rays_dev": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "snail_trace_shadow": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _VP]),
+    "snail_trace_shadow_dev": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "snail_account_primary": (_I, [_VP, _F13, _I, _I, _I, _I, _I, _I, _VP]),
+    "snail_last_launch": (_I, [_VP, _VP, _VP]),
+}
+
+
+def lib():
+    """Load libsnailhip.so or fail loudly."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SnailError(
+                "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C snail_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+        try:
+            L = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover - depends on the box
+            raise SnailError("cannot load %s: %s" % (LIB_PATH, e)) from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().snail_last_error()
+        raise SnailError("%s failed (status %d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def ptr(a):
+    """Device/host address of a numpy array, torch tensor, or None."""
+    if a is None:
+        return None
+    if hasattr(a, "data_ptr"):
+        return C.c_void_p(a.data_ptr())
+    return a.ctypes.data_as(C.c_void_p)

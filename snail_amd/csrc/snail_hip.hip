@@ -1,0 +1,1134 @@
+// snail_hip.hip -- gfx950 (MI355X / CDNA4) kernels and C-ABI of libsnailhip.so.
+//
+// Hot path of nadult/Snail re-designed for wave64:
+//
+//   ONE 16x16 RAY PACKET = ONE WAVEFRONT, ONE SSE QUAD (4 rays) = ONE LANE.
+//
+// The reference walks the BVH once per packet of 64 quads and keeps packet-wide state: a stack of
+// (node, firstActive, lastActive), a child order taken from lane 0 of quad 0, whole-packet interval
+// culls, and a [first,last] quad range that every box test shrinks (src/bvh/traverse.cpp:14-80,
+// src/bounding_box.cpp:61-142).  Those semantics decide which triangle wins an exact-t tie, so they are
+// kept exactly -- and they map onto a CDNA4 wavefront without any divergence:
+//   * control flow is wave-uniform: node index, stack pointer, first/last live in SGPRs;
+//   * a 32-B node record is ONE scalar load (s_load_dwordx8) through the scalar cache;
+//   * the traversal stack is a VGPR pair (lane i = stack slot i): pop = v_readlane, push = lane-predicated move;
+//   * "scan for the first/last quad with a surviving lane" is one __ballot + s_ff1/s_flbit;
+//   * per-leaf, lanes 0..count-1 each fetch one 64-B triangle (4 x dwordx4) and evaluate the
+//     packet-level Triangle::TestInterval cull and the shared-origin terms tvec0/tvec1/tmul for THEIR
+//     triangle in parallel; survivors are broadcast with v_readlane and intersected by all lanes.
+// No MFMA: this is branchy slab / Moeller-Trumbore work.  No FMA contraction either: every mul/add is
+// rounded separately, in the reference's operand order (build with -ffp-contract=off), IEEE divide and
+// sqrt (Inv(x)=1/x, RSqrt(x)=1/sqrt(x): veclib's scalar definitions, veclib/vecbase.h:53-55).
+//
+// Two instantiations of the walk live in each kernel and are selected per packet (wave-uniform):
+//   FAST  : all inputs finite -> no NaN can arise in a slab test, so veclib's Min/Max (second operand
+//           on NaN) equal v_min_f32/v_max_f32 up to the sign of zero (which no comparison sees), and
+//           BBox::TestInterval is implied by the per-lane test (monotonic rounding) and is skipped;
+//   EXACT : select-based Min/Max in the reference's operand order + the interval culls, for packets
+//           containing non-finite reciprocals (e.g. dir == -1e-8 exactly, src/rtbase.h:117-120).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/snail_hip.h"
+
+// ---------------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+void snail_set_error(const char *fmt, ...) {
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+}
+
+#define HIP_TRY(expr)                                                                                     \
+	do {                                                                                                  \
+		hipError_t e_ = (expr);                                                                           \
+		if(e_ != hipSuccess) {                                                                            \
+			snail_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);  \
+			return 100 + (int)e_;                                                                         \
+		}                                                                                                 \
+	} while(0)
+
+// ---------------------------------------------------------------------------------------------------
+// device code
+// ---------------------------------------------------------------------------------------------------
+namespace dev {
+
+typedef unsigned long long u64;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) u32x4 *scalar_ptr; // constant address space -> s_load
+
+struct Node {
+	float bmin[3], bmax[3];
+	unsigned sub;
+	int aux;
+};
+
+__device__ __forceinline__ float asf(unsigned u) { return __uint_as_float(u); }
+__device__ __forceinline__ float asf(int u) { return __int_as_float(u); }
+
+// one 32-B record, wave-uniform index -> two s_load_dwordx4 (merged to x8 by the backend)
+__device__ __forceinline__ Node loadNode(const uint4 *nodes, int idx) {
+	scalar_ptr p = (scalar_ptr)(unsigned long long)(nodes + (size_t)idx * 2);
+	u32x4 a = p[0], b = p[1];
+	Node n;
+	n.bmin[0] = asf(a.x); n.bmin[1] = asf(a.y); n.bmin[2] = asf(a.z);
+	n.bmax[0] = asf(a.w); n.bmax[1] = asf(b.x); n.bmax[2] = asf(b.y);
+	n.sub = b.z; n.aux = (int)b.w;
+	return n;
+}
+
+struct Tri {
+	float a[3], ba[3], ca[3], t0, it0, n[3];
+};
+template <class V4> __device__ __forceinline__ Tri unpackTri(V4 r0, V4 r1, V4 r2, V4 r3) {
+	Tri t;
+	t.a[0] = asf(r0.x); t.a[1] = asf(r0.y); t.a[2] = asf(r0.z);
+	t.ba[0] = asf(r0.w); t.ba[1] = asf(r1.x); t.ba[2] = asf(r1.y);
+	t.ca[0] = asf(r1.z); t.ca[1] = asf(r1.w); t.ca[2] = asf(r2.x);
+	t.t0 = asf(r2.y); t.it0 = asf(r2.z);
+	t.n[0] = asf(r3.x); t.n[1] = asf(r3.y); t.n[2] = asf(r3.z);
+	return t;
+}
+__device__ __forceinline__ Tri loadTriVector(const uint4 *tris, int idx) { // per-lane gather, 4 x dwordx4
+	const uint4 *p = tris + (size_t)idx * 4;
+	return unpackTri(p[0], p[1], p[2], p[3]);
+}
+__device__ __forceinline__ Tri loadTriScalar(const uint4 *tris, int idx) { // wave-uniform, s_load_dwordx16
+	scalar_ptr p = (scalar_ptr)(unsigned long long)(tris + (size_t)idx * 4);
+	u32x4 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
+	return unpackTri(r0, r1, r2, r3);
+}
+
+// veclib Min/Max: a<b?a:b / a>b?a:b (veclib/vecbase.h:75-76, minps/maxps in veclib/sse/f32.h:104-105).
+template <bool EXACT> __device__ __forceinline__ float Min(float a, float b) {
+	if(EXACT) return a < b ? a : b;
+	return __builtin_fminf(a, b);
+}
+template <bool EXACT> __device__ __forceinline__ float Max(float a, float b) {
+	if(EXACT) return a > b ? a : b;
+	return __builtin_fmaxf(a, b);
+}
+
+__device__ __forceinline__ float readlanef(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ float firstlanef(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+__device__ __forceinline__ float waveMin(float v) {
+#pragma unroll
+	for(int o = 32; o > 0; o >>= 1) v = __builtin_fminf(v, __shfl_xor(v, o));
+	return v;
+}
+__device__ __forceinline__ float waveMax(float v) {
+#pragma unroll
+	for(int o = 32; o > 0; o >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, o));
+	return v;
+}
+
+__device__ __forceinline__ u64 rangeMask(int first, int last) { return ((2ull << last) - 1ull) & ~((1ull << first) - 1ull); }
+
+// RayInterval (src/ray_group.h:293-338): packet bounds of dir, idir and origin
+struct Interval {
+	float minDir[3], maxDir[3], minIDir[3], maxIDir[3], minOrg[3], maxOrg[3];
+};
+
+struct Counters {
+	unsigned intersects, iters, skips;
+};
+
+// per-lane quad state: 4 rays
+struct Quad {
+	float d[3][4], id[3][4];
+	float dist[4];
+};
+
+// ---- ComputeMinMax (src/rtbase.cpp:61-121) ---------------------------------------------------------
+// FAST: all values finite -> plain wave reduction (min/max are order independent without NaN).
+// EXACT: the reference's sequential fold, per SSE slot, through LDS (NaN makes the fold order visible).
+template <bool EXACT, bool MASKED>
+__device__ void computeMinMax(const float (&v)[3][4], unsigned act4, bool seedFromFirst, int size, int lane, float *lds /*64*12+64 floats*/,
+							  float (&outMin)[3], float (&outMax)[3]) {
+	const float inf = __builtin_inff();
+	if(!EXACT) {
+		u64 anyAct = __ballot(act4 != 0);
+		for(int c = 0; c < 3; c++) {
+			float mn = inf, mx = -inf;
+#pragma unroll
+			for(int l = 0; l < 4; l++)
+				if(act4 & (1u << l)) { mn = __builtin_fminf(mn, v[c][l]); mx = __builtin_fmaxf(mx, v[c][l]); }
+			outMin[c] = anyAct ? waveMin(mn) : 0.0f;
+			outMax[c] = anyAct ? waveMax(mx) : 0.0f;
+		}
+		return;
+	}
+	// EXACT: stage the packet in LDS, lanes 0..11 fold (component c = lane>>2, slot l = lane&3)
+	unsigned *ldsMask = (unsigned *)(lds + 64 * 12);
+	if(lane < size) {
+#pragma unroll
+		for(int c = 0; c < 3; c++)
+#pragma unroll
+			for(int l = 0; l < 4; l++) lds[lane * 12 + c * 4 + l] = v[c][l];
+		ldsMask[lane] = act4;
+	}
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	float mn = 0.0f, mx = 0.0f;
+	bool none = false;
+	if(lane < 12) {
+		int c = lane >> 2, l = lane & 3;
+		int q = 0;
+		if(!MASKED) { mn = mx = lds[c * 4 + l]; q = 1; }
+		else {
+			while(q < size && ldsMask[q] == 0) q++;
+			if(q == size) none = true;
+			else {
+				int k = __builtin_ctz(ldsMask[q]);
+				mn = mx = lds[q * 12 + c * 4 + k];
+			}
+		}
+		if(!none)
+			for(; q < size; q++) {
+				if(MASKED && !(ldsMask[q] & (1u << l))) continue;
+				float x = lds[q * 12 + c * 4 + l];
+				mn = mn < x ? mn : x;
+				mx = mx > x ? mx : x;
+			}
+	}
+	__builtin_amdgcn_wave_barrier();
+	// Minimize / Maximize across the 4 slots: Min(Min(t0,t1),Min(t2,t3)) (src/rtbase_math.h:63-64)
+	bool noneU = __builtin_amdgcn_readfirstlane((int)none) != 0;
+	for(int c = 0; c < 3; c++) {
+		float a0 = readlanef(mn, c * 4 + 0), a1 = readlanef(mn, c * 4 + 1), a2 = readlanef(mn, c * 4 + 2), a3 = readlanef(mn, c * 4 + 3);
+		float b0 = readlanef(mx, c * 4 + 0), b1 = readlanef(mx, c * 4 + 1), b2 = readlanef(mx, c * 4 + 2), b3 = readlanef(mx, c * 4 + 3);
+		float m01 = a0 < a1 ? a0 : a1, m23 = a2 < a3 ? a2 : a3;
+		float x01 = b0 > b1 ? b0 : b1, x23 = b2 > b3 ? b2 : b3;
+		outMin[c] = noneU ? 0.0f : (m01 < m23 ? m01 : m23);
+		outMax[c] = noneU ? 0.0f : (x01 > x23 ? x01 : x23);
+	}
+	(void)seedFromFirst;
+}
+
+// BBox::TestInterval (src/bounding_box.cpp:208-236): wave-uniform, only needed on the EXACT path
+__device__ __forceinline__ bool boxTestInterval(const Node &n, const Interval &i) {
+	float lmin = 0.0f, lmax = 0.0f;
+#pragma unroll
+	for(int k = 0; k < 3; k++) {
+		float l1 = i.minIDir[k] * (n.bmin[k] - i.maxOrg[k]);
+		float l2 = i.maxIDir[k] * (n.bmin[k] - i.maxOrg[k]);
+		float l3 = i.minIDir[k] * (n.bmax[k] - i.minOrg[k]);
+		float l4 = i.maxIDir[k] * (n.bmax[k] - i.minOrg[k]);
+		float lo = Min<true>(Min<true>(l1, l2), Min<true>(l3, l4));
+		float hi = Max<true>(Max<true>(l1, l2), Max<true>(l3, l4));
+		if(k == 0) { lmin = lo; lmax = hi; }
+		else { lmin = Max<true>(lmin, lo); lmax = Min<true>(lmax, hi); }
+	}
+	return lmax >= 0.0f && lmin <= lmax;
+}
+
+// Triangle::TestInterval (src/triangle.cpp:110-167, shared-origin branch :122-129); each lane its own triangle
+__device__ __forceinline__ bool triTestInterval(const Tri &t, const Interval &i) {
+	float det = (t.n[0] < 0.0f ? i.minDir[0] : i.maxDir[0]) * t.n[0] + (t.n[1] < 0.0f ? i.minDir[1] : i.maxDir[1]) * t.n[1] +
+				(t.n[2] < 0.0f ? i.minDir[2] : i.maxDir[2]) * t.n[2];
+	if(det < 0.0f) return true;
+	float tv[3] = {i.minOrg[0] - t.a[0], i.minOrg[1] - t.a[1], i.minOrg[2] - t.a[2]};
+	float c1[3] = {t.ba[1] * tv[2] - t.ba[2] * tv[1], t.ba[2] * tv[0] - t.ba[0] * tv[2], t.ba[0] * tv[1] - t.ba[1] * tv[0]};
+	float c2[3] = {tv[1] * t.ca[2] - tv[2] * t.ca[1], tv[2] * t.ca[0] - tv[0] * t.ca[2], tv[0] * t.ca[1] - tv[1] * t.ca[0]};
+	float c1a[3], c1b[3], c2a[3], c2b[3];
+#pragma unroll
+	for(int k = 0; k < 3; k++) {
+		c1a[k] = i.minDir[k] * c1[k]; c1b[k] = i.maxDir[k] * c1[k];
+		c2a[k] = i.minDir[k] * c2[k]; c2b[k] = i.maxDir[k] * c2[k];
+	}
+	float u0 = Min<true>(c1a[0], c1b[0]) + Min<true>(c1a[1], c1b[1]) + Min<true>(c1a[2], c1b[2]);
+	float u1 = Max<true>(c1a[0], c1b[0]) + Max<true>(c1a[1], c1b[1]) + Max<true>(c1a[2], c1b[2]);
+	float v0 = Min<true>(c2a[0], c2b[0]) + Min<true>(c2a[1], c2b[1]) + Min<true>(c2a[2], c2b[2]);
+	float v1 = Max<true>(c2a[0], c2b[0]) + Max<true>(c2a[1], c2b[1]) + Max<true>(c2a[2], c2b[2]);
+	return Min<true>(u1, v1) >= 0.0f && u0 + v0 <= det * t.t0;
+}
+
+// ---- the packet walk -------------------------------------------------------------------------------
+// SHARED : one origin per packet (primary / shadow)   MASK : per-lane 4-bit masks (secondary rays)
+// SHADOW : any-hit TraverseShadow                      EXACT: see file header
+// Stack: lane i of (stkNode, stkFL) is slot i; slots >= 64 (only reachable for depth > 62) use a 2nd pair.
+template <bool SHARED, bool MASK, bool SHADOW, bool EXACT>
+__device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint4 *__restrict__ tris, int size, int lane,
+									 const float (&org)[3][4] /* SHARED: [c][0] uniform */, Quad &Q, unsigned mask4, int (&tid)[4],
+									 float (&bu)[4], float (&bv)[4], float *lds, Counters &st) {
+	const float inf = __builtin_inff();
+	Interval iv;
+	{ // RayInterval ctor (src/ray_group.h:296-333)
+		unsigned act4 = lane < size ? 15u : 0u;
+		if(SHADOW) {
+			act4 = 0;
+			if(lane < size)
+#pragma unroll
+				for(int l = 0; l < 4; l++) act4 |= (Q.dist[l] >= 0.0f ? 1u : 0u) << l;
+		} else if(MASK) act4 = lane < size ? (mask4 & 15u) : 0u;
+		computeMinMax<EXACT, (MASK || SHADOW)>(Q.d, act4, false, size, lane, lds, iv.minDir, iv.maxDir);
+		computeMinMax<EXACT, (MASK || SHADOW)>(Q.id, act4, false, size, lane, lds, iv.minIDir, iv.maxIDir);
+		if(SHARED) {
+#pragma unroll
+			for(int k = 0; k < 3; k++) iv.minOrg[k] = iv.maxOrg[k] = org[k][0];
+		} else computeMinMax<EXACT, MASK>(org, act4, false, size, lane, lds, iv.minOrg, iv.maxOrg);
+	}
+
+	// child order from lane 0 of quad 0 (src/bvh/traverse.cpp:21)
+	const int sign0 = firstlanef(Q.d[0][0]) < 0.0f, sign1 = firstlanef(Q.d[1][0]) < 0.0f, sign2 = firstlanef(Q.d[2][0]) < 0.0f;
+
+	int stkNode = 0, stkFL = 0, stkNode2 = 0, stkFL2 = 0;
+	int sp = 0;
+	int cur = 0, first = 0, last = size - 1;
+	bool haveCur = true;
+
+	for(;;) {
+		if(!haveCur) {
+			if(sp == 0) break;
+			sp--;
+			int fl;
+			if(sp < 64) { cur = __builtin_amdgcn_readlane(stkNode, sp); fl = __builtin_amdgcn_readlane(stkFL, sp); }
+			else { cur = __builtin_amdgcn_readlane(stkNode2, sp - 64); fl = __builtin_amdgcn_readlane(stkFL2, sp - 64); }
+			first = fl & 0xff; last = fl >> 8;
+		}
+		haveCur = false;
+		st.iters++;
+		const Node n = loadNode(nodes, cur);
+		const bool isLeaf = (n.sub & 0x80000000u) != 0;
+
+		if(EXACT && !boxTestInterval(n, iv)) continue;
+
+		// ---- BBox::Test (src/bounding_box.cpp:61-142 / :144-200) ----
+		bool anyPass = false;
+		{
+			float tmn[3], tmx[3];
+			if(SHARED) {
+#pragma unroll
+				for(int k = 0; k < 3; k++) { tmn[k] = n.bmin[k] - org[k][0]; tmx[k] = n.bmax[k] - org[k][0]; }
+			}
+#pragma unroll
+			for(int l = 0; l < 4; l++) {
+				float lmin = 0.0f, lmax = 0.0f;
+#pragma unroll
+				for(int k = 0; k < 3; k++) {
+					float l1 = Q.id[k][l] * (SHARED ? tmn[k] : n.bmin[k] - org[k][l]);
+					float l2 = Q.id[k][l] * (SHARED ? tmx[k] : n.bmax[k] - org[k][l]);
+					float lo = Min<EXACT>(l1, l2), hi = Max<EXACT>(l1, l2);
+					if(k == 0) { lmin = lo; lmax = hi; }
+					else if(SHADOW) { lmin = Max<EXACT>(lo, lmin); lmax = Min<EXACT>(hi, lmax); }
+					else { lmin = Max<EXACT>(lmin, lo); lmax = Min<EXACT>(lmax, hi); }
+				}
+				bool pass = SHADOW ? (lmax >= 0.0f && lmin <= Min<EXACT>(lmax, Q.dist[l])) : !(lmax < 0.0f || lmin > Min<EXACT>(lmax, Q.dist[l]));
+				anyPass |= pass;
+			}
+		}
+		const u64 range = rangeMask(first, last);
+		const u64 alive = __ballot(anyPass) & range;
+		if(alive == 0) continue;
+		first = __builtin_ctzll(alive);
+		last = 63 - __builtin_clzll(alive);
+
+		if(!isLeaf) {
+			const int child = (int)n.sub, axis = n.aux & 0xffff;
+			const int sgn = axis == 0 ? sign0 : axis == 1 ? sign1 : sign2;
+			const int firstNode = ((n.aux >> 16) & 0xffff) ^ sgn;
+			const int fl = first | (last << 8);
+			// push = predicated move into lane `sp` (clang has no v_writelane builtin; a select is hazard-free)
+			const int far = child + (firstNode ^ 1);
+			if(sp < 64) { const bool me = lane == sp; stkNode = me ? far : stkNode; stkFL = me ? fl : stkFL; }
+			else { const bool me = lane == sp - 64; stkNode2 = me ? far : stkNode2; stkFL2 = me ? fl : stkFL2; }
+			sp++;
+			cur = child + firstNode;
+			haveCur = true;
+			continue;
+		}
+
+		// ---- leaf (src/bvh/traverse.cpp:34-56 / :98-124) ----
+		const int count = n.aux, firstTri = (int)(n.sub & 0x7fffffffu);
+		const bool inRange = lane >= first && lane <= last;
+		const int width = last - first + 1;
+		const u64 curRange = rangeMask(first, last);
+
+		if(SHARED) {
+			for(int base = 0; base < count; base += 64) {
+				const int chunk = count - base < 64 ? count - base : 64;
+				const bool mine = lane < chunk;
+				const Tri t = loadTriVector(tris, firstTri + base + (mine ? lane : 0));
+				// shared-origin terms of Triangle::Collide (src/triangle.cpp:13-18 / :76-80), one triangle per lane
+				float tv[3] = {org[0][0] - t.a[0], org[1][0] - t.a[1], org[2][0] - t.a[2]};
+				float t0v[3] = {(t.ba[1] * tv[2] - t.ba[2] * tv[1]) * t.it0, (t.ba[2] * tv[0] - t.ba[0] * tv[2]) * t.it0,
+								(t.ba[0] * tv[1] - t.ba[1] * tv[0]) * t.it0};
+				float t1v[3] = {(tv[1] * t.ca[2] - tv[2] * t.ca[1]) * t.it0, (tv[2] * t.ca[0] - tv[0] * t.ca[2]) * t.it0,
+								(tv[0] * t.ca[1] - tv[1] * t.ca[0]) * t.it0};
+				float tmulV = -(tv[0] * t.n[0] + tv[1] * t.n[1] + tv[2] * t.n[2]);
+				u64 keep = __ballot(mine && triTestInterval(t, iv));
+
+				while(keep) {
+					const int k = __builtin_ctzll(keep);
+					keep &= keep - 1;
+					const float nx = readlanef(t.n[0], k), ny = readlanef(t.n[1], k), nz = readlanef(t.n[2], k);
+					const float ax = readlanef(t0v[0], k), ay = readlanef(t0v[1], k), az = readlanef(t0v[2], k);
+					const float bx = readlanef(t1v[0], k), by = readlanef(t1v[1], k), bz = readlanef(t1v[2], k);
+					const float tmul = readlanef(tmulV, k);
+					const int idx = firstTri + base + k;
+					bool all4 = true;
+#pragma unroll
+					for(int l = 0; l < 4; l++) {
+						const float det = Q.d[0][l] * nx + Q.d[1][l] * ny + Q.d[2][l] * nz;
+						const float v = Q.d[0][l] * ax + Q.d[1][l] * ay + Q.d[2][l] * az;
+						const float u = Q.d[0][l] * bx + Q.d[1][l] * by + Q.d[2][l] * bz;
+						if(SHADOW) { // src/triangle.cpp:91-98
+							bool test = Min<true>(u, v) >= 0.0f && u + v <= det;
+							test = test && tmul > 0.0f && tmul < Q.dist[l] * det;
+							all4 = all4 && test;
+							if(inRange && test) Q.dist[l] = -inf;
+						} else { // src/triangle.cpp:44-60
+							const float duv = det - u - v;
+							const float uvmin = Min<true>(u, Min<true>(v, duv)), uvmax = Max<true>(u, Max<true>(v, duv));
+							bool test = (uvmax <= 0.0f || uvmin >= 0.0f) && inRange;
+							if(MASK) test = test && ((mask4 >> l) & 1u);
+							if(test) {
+								const float idet = 1.0f / det;
+								const float dd = idet * tmul;
+								if(dd < Q.dist[l] && dd > 0.0f) { Q.dist[l] = dd; tid[l] = idx; bu[l] = u * idet; bv[l] = v * idet; }
+							}
+						}
+					}
+					if(SHADOW) {
+						const bool full = width == size && (__ballot(all4) & curRange) == curRange;
+						if(full) { st.skips++; return; }
+					}
+					st.intersects += width;
+				}
+			}
+		} else {
+			// per-ray origins (reflection / transparency packets, src/triangle.cpp:30-38): wave-uniform scalar triangle fetch
+			for(int k = 0; k < count; k++) {
+				const Tri t = loadTriScalar(tris, firstTri + k);
+#pragma unroll
+				for(int l = 0; l < 4; l++) {
+					const float det = Q.d[0][l] * t.n[0] + Q.d[1][l] * t.n[1] + Q.d[2][l] * t.n[2];
+					float tv[3] = {org[0][l] - t.a[0], org[1][l] - t.a[1], org[2][l] - t.a[2]};
+					float c0[3] = {t.ba[1] * tv[2] - t.ba[2] * tv[1], t.ba[2] * tv[0] - t.ba[0] * tv[2], t.ba[0] * tv[1] - t.ba[1] * tv[0]};
+					float c1[3] = {tv[1] * t.ca[2] - tv[2] * t.ca[1], tv[2] * t.ca[0] - tv[0] * t.ca[2], tv[0] * t.ca[1] - tv[1] * t.ca[0]};
+					const float tmul = -(tv[0] * t.n[0] + tv[1] * t.n[1] + tv[2] * t.n[2]);
+					const float v = (Q.d[0][l] * c0[0] + Q.d[1][l] * c0[1] + Q.d[2][l] * c0[2]) * t.it0;
+					const float u = (Q.d[0][l] * c1[0] + Q.d[1][l] * c1[1] + Q.d[2][l] * c1[2]) * t.it0;
+					const float duv = det - u - v;
+					const float uvmin = Min<true>(u, Min<true>(v, duv)), uvmax = Max<true>(u, Max<true>(v, duv));
+					bool test = (uvmax <= 0.0f || uvmin >= 0.0f) && inRange;
+					if(MASK) test = test && ((mask4 >> l) & 1u);
+					if(test) {
+						const float idet = 1.0f / det;
+						const float dd = idet * tmul;
+						if(dd < Q.dist[l] && dd > 0.0f) { Q.dist[l] = dd; tid[l] = firstTri + k; bu[l] = u * idet; bv[l] = v * idet; }
+					}
+				}
+				st.intersects += width;
+			}
+		}
+	}
+}
+
+__device__ __forceinline__ bool finite4(const float (&v)[3][4]) {
+	bool f = true;
+#pragma unroll
+	for(int c = 0; c < 3; c++)
+#pragma unroll
+		for(int l = 0; l < 4; l++) f = f && (__builtin_fabsf(v[c][l]) < __builtin_inff());
+	return f;
+}
+
+__device__ __forceinline__ void flushStats(u64 *stats, const Counters &st, unsigned rays, int lane) {
+	if(stats && lane == 0) {
+		atomicAdd(&stats[0], (u64)st.intersects);
+		atomicAdd(&stats[1], (u64)st.iters);
+		atomicAdd(&stats[2], (u64)rays);
+		atomicAdd(&stats[3], (u64)st.skips);
+	}
+}
+
+// ---- primary kernel: RayGenerator::Generate + SafeInv + TraversePrimary<1,0> ----------------------
+struct GenConst {
+	float tright[3], tup[3], txyz[3][4], org[3];
+};
+
+struct PrimaryArgs {
+	const uint4 *nodes, *tris;
+	GenConst g;
+	int resx, resy, x0, y0, w, h; // rect (frame layout) ...
+	const int2 *packetXY;		  // ... or explicit packet list (packet-major layout)
+	int nPackets, pw, ph;		  // packet grid of the rect
+	int nBlocks;
+	int fastOK;
+	float *t, *u, *v;
+	int *id;
+	u64 *stats;
+};
+
+#define WAVES_PER_BLOCK 4
+#define LDS_FLOATS_PER_WAVE (64 * 12 + 64)
+
+// XCD-aware block remap: blocks are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2), so
+// give every XCD a contiguous band of the packet grid; neighbouring packets walk the same BVH subtrees.
+__device__ __forceinline__ int xcdRemap(int b, int n) {
+	const int nx = 8;
+	int q = n / nx, r = n % nx, x = b % nx, i = b / nx;
+	// XCD x owns q (+1 if x < r) consecutive logical blocks
+	int start = x * q + (x < r ? x : r);
+	return start + i;
+}
+
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_primary(PrimaryArgs A) {
+	__shared__ float ldsAll[WAVES_PER_BLOCK][LDS_FLOATS_PER_WAVE];
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int blk = xcdRemap((int)blockIdx.x, A.nBlocks);
+
+	int px, py, pidx;
+	if(A.packetXY) {
+		pidx = blk * WAVES_PER_BLOCK + wave;
+		if(pidx >= A.nPackets) return;
+		int2 xy = A.packetXY[pidx];
+		px = __builtin_amdgcn_readfirstlane(xy.x);
+		py = __builtin_amdgcn_readfirstlane(xy.y);
+	} else {
+		// a block covers a 2x2 group of packets (32x32 px)
+		const int nbx = (A.pw + 1) >> 1;
+		const int bx = blk % nbx, by = blk / nbx;
+		const int cx = bx * 2 + (wave & 1), cy = by * 2 + (wave >> 1);
+		if(cx >= A.pw || cy >= A.ph) return;
+		px = A.x0 + cx * 16;
+		py = A.y0 + cy * 16;
+		pidx = cy * A.pw + cx;
+	}
+
+	// ---- RayGenerator::Generate, level 3 (src/ray_generator.cpp:23-47): quad ty*4+k, lane j -> pixel (x+4k+j, y+ty)
+	Quad Q;
+	const int ty = lane >> 2, k4 = lane & 3;
+#pragma unroll
+	for(int l = 0; l < 4; l++) {
+		const float xoff = (float)(px + (l >= 2 ? 2 : 0));
+		const float yoff = (float)(py - (l >= 2 ? 1 : 0));
+		const float tposx = (float)(4 * k4) + xoff;
+		const float tposy = (float)ty + yoff;
+		const float p0 = A.g.tright[0] * tposx + (A.g.tup[0] * tposy + A.g.txyz[0][l]);
+		const float p1 = A.g.tright[1] * tposx + (A.g.tup[1] * tposy + A.g.txyz[1][l]);
+		const float p2 = A.g.tright[2] * tposx + (A.g.tup[2] * tposy + A.g.txyz[2][l]);
+		const float rs = 1.0f / __builtin_sqrtf(p0 * p0 + p1 * p1 + p2 * p2);
+		Q.d[0][l] = p0 * rs; Q.d[1][l] = p1 * rs; Q.d[2][l] = p2 * rs;
+#pragma unroll
+		for(int c = 0; c < 3; c++) Q.id[c][l] = 1.0f / (Q.d[c][l] + 0.00000001f); // SafeInv (src/rtbase.h:117-120)
+		Q.dist[l] = __builtin_inff();											   // src/scene_trace.cpp:112-115
+	}
+	int tid[4] = {0, 0, 0, 0};
+	float bu[4] = {0, 0, 0, 0}, bv[4] = {0, 0, 0, 0};
+	float org[3][4];
+#pragma unroll
+	for(int c = 0; c < 3; c++)
+#pragma unroll
+		for(int l = 0; l < 4; l++) org[c][l] = A.g.org[c];
+
+	Counters st = {0, 0, 0};
+	const bool fast = A.fastOK && __all(finite4(Q.id) && finite4(Q.d));
+	if(fast) walk<true, false, false, false>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
+	else walk<true, false, false, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
+
+	flushStats(A.stats, st, 256u, lane);
+
+	if(A.packetXY) { // packet-major (Context layout)
+		const size_t o = (size_t)pidx * 256 + (size_t)lane * 4;
+		if(A.t) *(float4 *)(A.t + o) = make_float4(Q.dist[0], Q.dist[1], Q.dist[2], Q.dist[3]);
+		if(A.u) *(float4 *)(A.u + o) = make_float4(bu[0], bu[1], bu[2], bu[3]);
+		if(A.v) *(float4 *)(A.v + o) = make_float4(bv[0], bv[1], bv[2], bv[3]);
+		if(A.id) *(int4 *)(A.id + o) = make_int4(tid[0], tid[1], tid[2], tid[3]);
+	} else {
+		const int yy = py + ty, xx = px + k4 * 4;
+		const int xlim = min(A.resx, A.x0 + A.w), ylim = min(A.resy, A.y0 + A.h);
+		if(yy < ylim) {
+			const size_t o = (size_t)yy * A.resx + xx;
+			if(xx + 3 < xlim && (A.resx & 3) == 0) {
+				if(A.t) *(float4 *)(A.t + o) = make_float4(Q.dist[0], Q.dist[1], Q.dist[2], Q.dist[3]);
+				if(A.u) *(float4 *)(A.u + o) = make_float4(bu[0], bu[1], bu[2], bu[3]);
+				if(A.v) *(float4 *)(A.v + o) = make_float4(bv[0], bv[1], bv[2], bv[3]);
+				if(A.id) *(int4 *)(A.id + o) = make_int4(tid[0], tid[1], tid[2], tid[3]);
+			} else {
+#pragma unroll
+				for(int l = 0; l < 4; l++)
+					if(xx + l < xlim) {
+						if(A.t) A.t[o + l] = Q.dist[l];
+						if(A.u) A.u[o + l] = bu[l];
+						if(A.v) A.v[o + l] = bv[l];
+						if(A.id) A.id[o + l] = tid[l];
+					}
+			}
+		}
+	}
+}
+
+// ---- generic packets: TraversePrimary<SHARED,MASK>(Context&) --------------------------------------
+struct RaysArgs {
+	const uint4 *nodes, *tris;
+	int nPackets, size, fastOK;
+	const float *origin, *dir, *idir;
+	const unsigned char *mask;
+	float *distance;
+	int *object;
+	float *bary;
+	u64 *stats;
+};
+
+__device__ __forceinline__ void loadQuad3(const float *base, size_t quad, float (&v)[3][4]) {
+	const float4 *p = (const float4 *)(base + quad * 12);
+	float4 x = p[0], y = p[1], z = p[2];
+	v[0][0] = x.x; v[0][1] = x.y; v[0][2] = x.z; v[0][3] = x.w;
+	v[1][0] = y.x; v[1][1] = y.y; v[1][2] = y.z; v[1][3] = y.w;
+	v[2][0] = z.x; v[2][1] = z.y; v[2][2] = z.z; v[2][3] = z.w;
+}
+
+template <bool SHARED, bool MASK>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_rays(RaysArgs A) {
+	__shared__ float ldsAll[WAVES_PER_BLOCK][LDS_FLOATS_PER_WAVE];
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int p = (int)blockIdx.x * WAVES_PER_BLOCK + wave;
+	if(p >= A.nPackets) return;
+	const int size = A.size;
+	const size_t q0 = (size_t)p * size;
+	const bool live = lane < size;
+	const size_t q = q0 + (live ? lane : 0);
+
+	Quad Q;
+	float org[3][4];
+	loadQuad3(A.dir, q, Q.d);
+	loadQuad3(A.idir, q, Q.id);
+	if(SHARED) {
+		scalar_ptr op = (scalar_ptr)(unsigned long long)(A.origin + (size_t)p * 12);
+		u32x4 ox = op[0], oy = op[1], oz = op[2];
+#pragma unroll
+		for(int l = 0; l < 4; l++) { org[0][l] = asf(ox.x); org[1][l] = asf(oy.x); org[2][l] = asf(oz.x); } // ExtractN(Origin(0), 0)
+	} else loadQuad3(A.origin, q, org);
+	unsigned mask4 = 15u;
+	if(MASK) mask4 = A.mask[q] & 15u;
+	float4 dv = *(const float4 *)(A.distance + q * 4);
+	int4 ov = *(const int4 *)(A.object + q * 4);
+	float4 b0 = *(const float4 *)(A.bary + q * 8), b1 = *(const float4 *)(A.bary + q * 8 + 4);
+	Q.dist[0] = dv.x; Q.dist[1] = dv.y; Q.dist[2] = dv.z; Q.dist[3] = dv.w;
+	int tid[4] = {ov.x, ov.y, ov.z, ov.w};
+	float bu[4] = {b0.x, b0.y, b0.z, b0.w}, bv[4] = {b1.x, b1.y, b1.z, b1.w};
+
+	Counters st = {0, 0, 0};
+	bool fin = finite4(Q.id) && finite4(Q.d) && finite4(org);
+#pragma unroll
+	for(int l = 0; l < 4; l++) fin = fin && !(Q.dist[l] != Q.dist[l]);
+	const bool fast = A.fastOK && __all(fin || !live);
+	if(fast) walk<SHARED, MASK, false, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, ldsAll[wave], st);
+	else walk<SHARED, MASK, false, true>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, ldsAll[wave], st);
+	flushStats(A.stats, st, 0u, lane);
+
+	if(live) {
+		*(float4 *)(A.distance + q * 4) = make_float4(Q.dist[0], Q.dist[1], Q.dist[2], Q.dist[3]);
+		*(int4 *)(A.object + q * 4) = make_int4(tid[0], tid[1], tid[2], tid[3]);
+		*(float4 *)(A.bary + q * 8) = make_float4(bu[0], bu[1], bu[2], bu[3]);
+		*(float4 *)(A.bary + q * 8 + 4) = make_float4(bv[0], bv[1], bv[2], bv[3]);
+	}
+}
+
+// ---- shadow packets: TraverseShadow(ShadowContext&) -----------------------------------------------
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_shadow(RaysArgs A) {
+	__shared__ float ldsAll[WAVES_PER_BLOCK][LDS_FLOATS_PER_WAVE];
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int p = (int)blockIdx.x * WAVES_PER_BLOCK + wave;
+	if(p >= A.nPackets) return;
+	const int size = A.size;
+	const bool live = lane < size;
+	const size_t q = (size_t)p * size + (live ? lane : 0);
+
+	Quad Q;
+	float org[3][4];
+	loadQuad3(A.dir, q, Q.d);
+	loadQuad3(A.idir, q, Q.id);
+	{
+		const float *op = A.origin + (size_t)p * 3;
+		const float o0 = firstlanef(op[0]), o1 = firstlanef(op[1]), o2 = firstlanef(op[2]);
+#pragma unroll
+		for(int l = 0; l < 4; l++) { org[0][l] = o0; org[1][l] = o1; org[2][l] = o2; }
+	}
+	float4 dv = *(const float4 *)(A.distance + q * 4);
+	Q.dist[0] = dv.x; Q.dist[1] = dv.y; Q.dist[2] = dv.z; Q.dist[3] = dv.w;
+	int tid[4] = {0, 0, 0, 0};
+	float bu[4] = {0, 0, 0, 0}, bv[4] = {0, 0, 0, 0};
+
+	Counters st = {0, 0, 0};
+	bool fin = finite4(Q.id) && finite4(Q.d) && finite4(org);
+#pragma unroll
+	for(int l = 0; l < 4; l++) fin = fin && !(Q.dist[l] != Q.dist[l]);
+	const bool fast = A.fastOK && __all(fin || !live);
+	if(fast) walk<true, false, true, false>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
+	else walk<true, false, true, true>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
+	flushStats(A.stats, st, 0u, lane);
+	if(live) *(float4 *)(A.distance + q * 4) = make_float4(Q.dist[0], Q.dist[1], Q.dist[2], Q.dist[3]);
+}
+
+// ---- packet-major -> frame scatter ------------------------------------------------------------------
+struct ScatterArgs {
+	const int2 *packetXY;
+	int nPackets, resx, resy;
+	const float *pt, *pu, *pv;
+	const int *pid;
+	float *t, *u, *v;
+	int *id;
+};
+__global__ __launch_bounds__(256) void k_packets_to_frame(ScatterArgs A) {
+	const int lane = threadIdx.x & 63;
+	const int p = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+	if(p >= A.nPackets) return;
+	const int2 xy = A.packetXY[p];
+	const int yy = xy.y + (lane >> 2), xx = xy.x + (lane & 3) * 4;
+	if(yy >= A.resy) return;
+	const size_t src = (size_t)p * 256 + (size_t)lane * 4, dst = (size_t)yy * A.resx + xx;
+#pragma unroll
+	for(int l = 0; l < 4; l++)
+		if(xx + l < A.resx) {
+			if(A.t && A.pt) A.t[dst + l] = A.pt[src + l];
+			if(A.u && A.pu) A.u[dst + l] = A.pu[src + l];
+			if(A.v && A.pv) A.v[dst + l] = A.pv[src + l];
+			if(A.id && A.pid) A.id[dst + l] = A.pid[src + l];
+		}
+}
+
+// ---- single-ray accounting walk: V_n, V_t per ray ----------------------------
+struct AccountArgs {
+	const uint4 *nodes, *tris;
+	GenConst g;
+	int x0, y0, pw, ph;
+	u64 *out;
+};
+__global__ __launch_bounds__(256) void k_account(AccountArgs A) {
+	const int lane = threadIdx.x & 63;
+	const int p = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+	if(p >= A.pw * A.ph) return;
+	const int px = A.x0 + (p % A.pw) * 16, py = A.y0 + (p / A.pw) * 16;
+	const int ty = lane >> 2, k4 = lane & 3;
+	const float inf = __builtin_inff();
+	unsigned vn = 0, vt = 0, hits = 0;
+	for(int l = 0; l < 4; l++) {
+		const float xoff = (float)(px + (l >= 2 ? 2 : 0)), yoff = (float)(py - (l >= 2 ? 1 : 0));
+		const float tposx = (float)(4 * k4) + xoff, tposy = (float)ty + yoff;
+		float pp[3], d[3], id[3];
+		for(int c = 0; c < 3; c++) pp[c] = A.g.tright[c] * tposx + (A.g.tup[c] * tposy + A.g.txyz[c][l]);
+		const float rs = 1.0f / __builtin_sqrtf(pp[0] * pp[0] + pp[1] * pp[1] + pp[2] * pp[2]);
+		for(int c = 0; c < 3; c++) { d[c] = pp[c] * rs; id[c] = 1.0f / (d[c] + 0.00000001f); }
+		const int sg[3] = {d[0] < 0.0f, d[1] < 0.0f, d[2] < 0.0f};
+		int stack[SNAIL_MAX_DEPTH + 2], sp = 0;
+		stack[sp++] = 0;
+		float dist = inf;
+		while(sp) {
+			int cur = stack[--sp];
+			for(;;) {
+				const uint4 *np = A.nodes + (size_t)cur * 2;
+				const uint4 a = np[0], b = np[1];
+				const float bmin[3] = {asf(a.x), asf(a.y), asf(a.z)}, bmax[3] = {asf(a.w), asf(b.x), asf(b.y)};
+				vn++;
+				float lmin = 0.0f, lmax = 0.0f;
+				for(int k = 0; k < 3; k++) {
+					float l1 = id[k] * (bmin[k] - A.g.org[k]), l2 = id[k] * (bmax[k] - A.g.org[k]);
+					float lo = Min<true>(l1, l2), hi = Max<true>(l1, l2);
+					if(k == 0) { lmin = lo; lmax = hi; }
+					else { lmin = Max<true>(lmin, lo); lmax = Min<true>(lmax, hi); }
+				}
+				if(lmax < 0.0f || lmin > Min<true>(lmax, dist)) break;
+				if(b.z & 0x80000000u) {
+					const int count = (int)b.w, firstTri = (int)(b.z & 0x7fffffffu);
+					for(int k = 0; k < count; k++) {
+						const Tri t = loadTriVector(A.tris, firstTri + k);
+						vt++;
+						float tv[3] = {A.g.org[0] - t.a[0], A.g.org[1] - t.a[1], A.g.org[2] - t.a[2]};
+						float t0v[3] = {(t.ba[1] * tv[2] - t.ba[2] * tv[1]) * t.it0, (t.ba[2] * tv[0] - t.ba[0] * tv[2]) * t.it0,
+										(t.ba[0] * tv[1] - t.ba[1] * tv[0]) * t.it0};
+						float t1v[3] = {(tv[1] * t.ca[2] - tv[2] * t.ca[1]) * t.it0, (tv[2] * t.ca[0] - tv[0] * t.ca[2]) * t.it0,
+										(tv[0] * t.ca[1] - tv[1] * t.ca[0]) * t.it0};
+						const float tmul = -(tv[0] * t.n[0] + tv[1] * t.n[1] + tv[2] * t.n[2]);
+						const float det = d[0] * t.n[0] + d[1] * t.n[1] + d[2] * t.n[2];
+						const float v = d[0] * t0v[0] + d[1] * t0v[1] + d[2] * t0v[2];
+						const float u = d[0] * t1v[0] + d[1] * t1v[1] + d[2] * t1v[2];
+						const float duv = det - u - v;
+						const float uvmin = Min<true>(u, Min<true>(v, duv)), uvmax = Max<true>(u, Max<true>(v, duv));
+						if(!(uvmax <= 0.0f || uvmin >= 0.0f)) continue;
+						const float t2 = (1.0f / det) * tmul;
+						if(t2 < dist && t2 > 0.0f) dist = t2;
+					}
+					break;
+				}
+				const int child = (int)b.z, axis = (int)(b.w & 0xffff), fn = (int)((b.w >> 16) & 0xffff) ^ sg[axis];
+				stack[sp++] = child + (fn ^ 1);
+				cur = child + fn;
+			}
+		}
+		if(dist < inf) hits++;
+	}
+	// wave reduction then one atomic per wave
+	u64 r0 = 4, r1 = vn, r2 = vt, r3 = hits;
+	for(int o = 32; o > 0; o >>= 1) {
+		r0 += __shfl_xor(r0, o); r1 += __shfl_xor(r1, o); r2 += __shfl_xor(r2, o); r3 += __shfl_xor(r3, o);
+	}
+	if(lane == 0) { atomicAdd(&A.out[0], r0); atomicAdd(&A.out[1], r1); atomicAdd(&A.out[2], r2); atomicAdd(&A.out[3], r3); }
+}
+
+} // namespace dev
+
+// ---------------------------------------------------------------------------------------------------
+// host side of the C-ABI
+// ---------------------------------------------------------------------------------------------------
+struct SnailScene {
+	int device = 0;
+	int nNodes = 0, nTris = 0, depth = 0;
+	uint4 *dNodes = nullptr, *dTris = nullptr;
+	int fastOK = 0; // every triangle record finite and of sane magnitude (see file header)
+	int lastBlocks = 0, lastThreads = 0;
+	unsigned long long *dStats = nullptr; // 4 x u64 scratch for the host-pointer entry points
+};
+
+namespace {
+
+struct DeviceGuard {
+	int prev = -1;
+	bool ok = true;
+	explicit DeviceGuard(int dev) {
+		if(hipGetDevice(&prev) != hipSuccess) prev = -1;
+		if(prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+	}
+	~DeviceGuard() {
+		int cur = -1;
+		if(prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+	}
+};
+
+// RayGenerator ctor (src/ray_generator.cpp:4-15); plain fp32, this TU is built with -ffp-contract=off
+dev::GenConst makeGen(const float cam[13], int w, int h) {
+	dev::GenConst g;
+	const float *pos = cam, *right = cam + 3, *up = cam + 6, *front = cam + 9;
+	const float pd = cam[12];
+	float invW = 1.0f / float(w), invH = 1.0f / float(h);
+	invW *= float(w) / float(h);
+	const float ax[4] = {0.0f, 1.0f, 0.0f, 1.0f}, ay[4] = {0.0f, 0.0f, 1.0f, 1.0f};
+	for(int c = 0; c < 3; c++) { g.tright[c] = right[c] * invW; g.tup[c] = up[c] * invH; g.org[c] = pos[c]; }
+	for(int l = 0; l < 4; l++) {
+		const float taddx = ax[l] - w * 0.5f, taddy = ay[l] - h * 0.5f;
+		for(int c = 0; c < 3; c++) {
+			const float fp = front[c] * pd;
+			g.txyz[c][l] = g.tright[c] * taddx + g.tup[c] * taddy + fp;
+		}
+	}
+	return g;
+}
+
+bool originSane(const float *o) {
+	for(int c = 0; c < 3; c++)
+		if(!(std::fabs(o[c]) <= 1.0e9f)) return false;
+	return true;
+}
+
+int checkScene(const SnailScene *s, const char *fn) {
+	if(!s || !s->dNodes || !s->dTris) { snail_set_error("%s: invalid scene handle", fn); return 1; }
+	return 0;
+}
+
+int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0, int y0, int w, int h, const int32_t *dPacketXY,
+				  int nPackets, float *t, float *u, float *v, int32_t *id, uint64_t *dStats, hipStream_t stream) {
+	if(resx <= 0 || resy <= 0) { snail_set_error("snail_trace_primary: bad resolution %dx%d", resx, resy); return 1; }
+	dev::PrimaryArgs A;
+	memset(&A, 0, sizeof(A));
+	A.nodes = s->dNodes; A.tris = s->dTris;
+	A.g = makeGen(cam, resx, resy);
+	A.resx = resx; A.resy = resy;
+	A.fastOK = s->fastOK && originSane(cam);
+	A.t = t; A.u = u; A.v = v; A.id = id;
+	A.stats = (dev::u64 *)dStats;
+	int blocks;
+	if(dPacketXY) {
+		if(nPackets <= 0) return 0;
+		A.packetXY = (const int2 *)dPacketXY;
+		A.nPackets = nPackets;
+		blocks = (nPackets + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+	} else {
+		if((x0 & 15) || (y0 & 15) || w <= 0 || h <= 0 || x0 < 0 || y0 < 0) {
+			snail_set_error("snail_trace_primary: rect origin must be a non-negative multiple of 16 and the size positive (got %d,%d %dx%d)", x0, y0, w, h);
+			return 1;
+		}
+		A.x0 = x0; A.y0 = y0; A.w = w; A.h = h;
+		A.pw = (w + 15) / 16; A.ph = (h + 15) / 16;
+		A.nPackets = A.pw * A.ph;
+		blocks = ((A.pw + 1) / 2) * ((A.ph + 1) / 2);
+	}
+	A.nBlocks = blocks;
+	s->lastBlocks = blocks; s->lastThreads = WAVES_PER_BLOCK * 64;
+	hipLaunchKernelGGL(dev::k_primary, dim3(blocks), dim3(WAVES_PER_BLOCK * 64), 0, stream, A);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *snail_last_error(void) { return g_err; }
+
+int snail_device_count(void) {
+	int n = 0;
+	if(hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+SnailScene *snail_scene_create(const void *nodes32, int nNodes, const void *tris64, int nTris, int depth, int device) {
+	if(!nodes32 || !tris64 || nNodes <= 0 || nTris <= 0) { snail_set_error("snail_scene_create: empty scene"); return nullptr; }
+	if(depth > SNAIL_MAX_DEPTH) { snail_set_error("snail_scene_create: depth %d exceeds BVH::maxDepth %d", depth, SNAIL_MAX_DEPTH); return nullptr; }
+	// validate topology on the host so that no kernel can index out of bounds (a GPU fault resets the node)
+	const uint32_t *nw = (const uint32_t *)nodes32;
+	for(int i = 0; i < nNodes; i++) {
+		uint32_t sub = nw[i * 8 + 6], aux = nw[i * 8 + 7];
+		if(sub & 0x80000000u) {
+			uint32_t first = sub & 0x7fffffffu;
+			if((int32_t)aux < 0 || (uint64_t)first + aux > (uint64_t)nTris) { snail_set_error("snail_scene_create: leaf %d references triangles [%u,%u) of %d", i, first, first + aux, nTris); return nullptr; }
+		} else {
+			if((uint64_t)sub + 1 >= (uint64_t)nNodes || sub == 0) { snail_set_error("snail_scene_create: node %d has child %u of %d", i, sub, nNodes); return nullptr; }
+			if((aux & 0xffff) > 2 || (aux >> 16) > 1) { snail_set_error("snail_scene_create: node %d has axis/firstNode %u/%u", i, aux & 0xffff, aux >> 16); return nullptr; }
+		}
+	}
+	int fastOK = 1;
+	const float *tf = (const float *)tris64;
+	for(int i = 0; i < nTris && fastOK; i++) {
+		const float *r = tf + (size_t)i * 16;
+		for(int k = 0; k < 9; k++) if(!(std::fabs(r[k]) <= 1.0e9f)) fastOK = 0;         // a, ba, ca
+		if(!(r[9] > 0.0f) || !(r[10] <= 1.0e12f) || !(r[10] > 0.0f)) fastOK = 0;        // t0, it0
+		for(int k = 12; k < 16; k++) if(!(std::fabs(r[k]) <= 1.0e18f)) fastOK = 0;     // plane
+	}
+	const float *nf = (const float *)nodes32;
+	for(int i = 0; i < nNodes && fastOK; i++)
+		for(int k = 0; k < 6; k++) if(!(std::fabs(nf[(size_t)i * 8 + k]) <= 1.0e9f)) fastOK = 0;
+
+	DeviceGuard guard(device);
+	if(!guard.ok) { snail_set_error("snail_scene_create: hipSetDevice(%d) failed", device); return nullptr; }
+	SnailScene *s = new SnailScene();
+	s->device = device; s->nNodes = nNodes; s->nTris = nTris; s->depth = depth; s->fastOK = fastOK;
+	hipError_t e;
+	if((e = hipMalloc((void **)&s->dNodes, (size_t)nNodes * 32)) != hipSuccess || (e = hipMalloc((void **)&s->dTris, (size_t)nTris * 64)) != hipSuccess ||
+	   (e = hipMalloc((void **)&s->dStats, 4 * sizeof(unsigned long long))) != hipSuccess ||
+	   (e = hipMemcpy(s->dNodes, nodes32, (size_t)nNodes * 32, hipMemcpyHostToDevice)) != hipSuccess ||
+	   (e = hipMemcpy(s->dTris, tris64, (size_t)nTris * 64, hipMemcpyHostToDevice)) != hipSuccess) {
+		snail_set_error("snail_scene_create: %s", hipGetErrorString(e));
+		snail_scene_destroy(s);
+		return nullptr;
+	}
+	return s;
+}
+
+void snail_scene_destroy(SnailScene *s) {
+	if(!s) return;
+	DeviceGuard guard(s->device);
+	if(s->dNodes) (void)hipFree(s->dNodes);
+	if(s->dTris) (void)hipFree(s->dTris);
+	if(s->dStats) (void)hipFree(s->dStats);
+	delete s;
+}
+
+int snail_scene_info(const SnailScene *s, int *nNodes, int *nTris, int *depth, int *device) {
+	if(!s) { snail_set_error("snail_scene_info: null scene"); return 1; }
+	if(nNodes) *nNodes = s->nNodes;
+	if(nTris) *nTris = s->nTris;
+	if(depth) *depth = s->depth;
+	if(device) *device = s->device;
+	return 0;
+}
+
+int snail_last_launch(const SnailScene *s, int *blocks, int *threads) {
+	if(!s) { snail_set_error("snail_last_launch: null scene"); return 1; }
+	if(blocks) *blocks = s->lastBlocks;
+	if(threads) *threads = s->lastThreads;
+	return 0;
+}
+
+int snail_trace_primary_dev(SnailScene *s, const float cam[13], int resx, int resy, int x0, int y0, int w, int h, float *t, float *u,
+							float *v, int32_t *id, uint64_t *dStats, void *stream) {
+	if(int rc = checkScene(s, "snail_trace_primary_dev")) return rc;
+	DeviceGuard guard(s->device);
+	return launchPrimary(s, cam, resx, resy, x0, y0, w, h, nullptr, 0, t, u, v, id, dStats, (hipStream_t)stream);
+}
+
+int snail_trace_packets_dev(SnailScene *s, const float cam[13], int resx, int resy, const int32_t *dPacketXY, int nPackets, float *t,
+							float *u, float *v, int32_t *id, uint64_t *dStats, void *stream) {
+	if(int rc = checkScene(s, "snail_trace_packets_dev")) return rc;
+	if(!dPacketXY && nPackets > 0) { snail_set_error("snail_trace_packets_dev: null packet list"); return 1; }
+	DeviceGuard guard(s->device);
+	return launchPrimary(s, cam, resx, resy, 0, 0, 0, 0, dPacketXY, nPackets, t, u, v, id, dStats, (hipStream_t)stream);
+}
+
+int snail_packets_to_frame_dev(const int32_t *dPacketXY, int nPackets, int resx, int resy, const float *pt, const float *pu, const float *pv,
+							   const int32_t *pid, float *t, float *u, float *v, int32_t *id, void *stream) {
+	if(nPackets <= 0) return 0;
+	dev::ScatterArgs A{(const int2 *)dPacketXY, nPackets, resx, resy, pt, pu, pv, pid, t, u, v, id};
+	hipLaunchKernelGGL(dev::k_packets_to_frame, dim3((nPackets + 3) / 4), dim3(256), 0, (hipStream_t)stream, A);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+int snail_trace_primary(SnailScene *s, const float cam[13], int resx, int resy, int x0, int y0, int w, int h, float *t, float *u, float *v,
+						int32_t *id, uint64_t stats[4]) {
+	if(int rc = checkScene(s, "snail_trace_primary")) return rc;
+	DeviceGuard guard(s->device);
+	const size_t n = (size_t)resx * resy;
+	float *dt = nullptr, *du = nullptr, *dv = nullptr;
+	int32_t *did = nullptr;
+	int rc = 0;
+	auto freeAll = [&] { if(dt) (void)hipFree(dt); if(du) (void)hipFree(du); if(dv) (void)hipFree(dv); if(did) (void)hipFree(did); };
+#define TRY_OR_FREE(e) do { hipError_t e_ = (e); if(e_ != hipSuccess) { snail_set_error("%s: %s", #e, hipGetErrorString(e_)); freeAll(); return 100 + (int)e_; } } while(0)
+	// the host buffers are full frames of which only the rect is defined: stage through device frames
+	if(t) { TRY_OR_FREE(hipMalloc((void **)&dt, n * 4)); TRY_OR_FREE(hipMemcpy(dt, t, n * 4, hipMemcpyHostToDevice)); }
+	if(u) { TRY_OR_FREE(hipMalloc((void **)&du, n * 4)); TRY_OR_FREE(hipMemcpy(du, u, n * 4, hipMemcpyHostToDevice)); }
+	if(v) { TRY_OR_FREE(hipMalloc((void **)&dv, n * 4)); TRY_OR_FREE(hipMemcpy(dv, v, n * 4, hipMemcpyHostToDevice)); }
+	if(id) { TRY_OR_FREE(hipMalloc((void **)&did, n * 4)); TRY_OR_FREE(hipMemcpy(did, id, n * 4, hipMemcpyHostToDevice)); }
+	if(stats) TRY_OR_FREE(hipMemset(s->dStats, 0, 32));
+	rc = launchPrimary(s, cam, resx, resy, x0, y0, w, h, nullptr, 0, dt, du, dv, did, stats ? (uint64_t *)s->dStats : nullptr, 0);
+	if(rc) { freeAll(); return rc; }
+	TRY_OR_FREE(hipDeviceSynchronize());
+	if(t) TRY_OR_FREE(hipMemcpy(t, dt, n * 4, hipMemcpyDeviceToHost));
+	if(u) TRY_OR_FREE(hipMemcpy(u, du, n * 4, hipMemcpyDeviceToHost));
+	if(v) TRY_OR_FREE(hipMemcpy(v, dv, n * 4, hipMemcpyDeviceToHost));
+	if(id) TRY_OR_FREE(hipMemcpy(id, did, n * 4, hipMemcpyDeviceToHost));
+	if(stats) {
+		unsigned long long hs[4];
+		TRY_OR_FREE(hipMemcpy(hs, s->dStats, 32, hipMemcpyDeviceToHost));
+		for(int k = 0; k < 4; k++) stats[k] += hs[k];
+	}
+	freeAll();
+	return 0;
+}
+
+static int launchRays(SnailScene *s, bool shadow, int nPackets, int size, int sharedOrigin, const float *origin, const float *dir,
+					  const float *idir, const uint8_t *mask, float *distance, int32_t *object, float *bary, uint64_t *dStats, hipStream_t stream) {
+	if(nPackets <= 0) return 0;
+	if(size < 1 || size > SNAIL_PACKET_QUADS) { snail_set_error("packet size %d outside 1..%d quads", size, SNAIL_PACKET_QUADS); return 1; }
+	if(!origin || !dir || !idir || !distance || (!shadow && (!object || !bary))) { snail_set_error("null ray array"); return 1; }
+	dev::RaysArgs A;
+	memset(&A, 0, sizeof(A));
+	A.nodes = s->dNodes; A.tris = s->dTris;
+	A.nPackets = nPackets; A.size = size; A.fastOK = s->fastOK;
+	A.origin = origin; A.dir = dir; A.idir = idir; A.mask = mask;
+	A.distance = distance; A.object = object; A.bary = bary;
+	A.stats = (dev::u64 *)dStats;
+	const int blocks = (nPackets + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+	const dim3 g(blocks), b(WAVES_PER_BLOCK * 64);
+	if(shadow) hipLaunchKernelGGL(dev::k_shadow, g, b, 0, stream, A);
+	else if(sharedOrigin && mask) hipLaunchKernelGGL((dev::k_rays<true, true>), g, b, 0, stream, A);
+	else if(sharedOrigin) hipLaunchKernelGGL((dev::k_rays<true, false>), g, b, 0, stream, A);
+	else if(mask) hipLaunchKernelGGL((dev::k_rays<false, true>), g, b, 0, stream, A);
+	else hipLaunchKernelGGL((dev::k_rays<false, false>), g, b, 0, stream, A);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+int snail_trace_rays_dev(SnailScene *s, int nPackets, int size, int sharedOrigin, const float *origin, const float *dir, const float *idir,
+						 const uint8_t *mask, float *distance, int32_t *object, float *bary, uint64_t *dStats, void *stream) {
+	if(int rc = checkScene(s, "snail_trace_rays_dev")) return rc;
+	DeviceGuard guard(s->device);
+	return launchRays(s, false, nPackets, size, sharedOrigin, origin, dir, idir, mask, distance, object, bary, dStats, (hipStream_t)stream);
+}
+
+int snail_trace_shadow_dev(SnailScene *s, int nPackets, int size, const float *origin3, const float *dir, const float *idir, float *distance,
+						   uint64_t *dStats, void *stream) {
+	if(int rc = checkScene(s, "snail_trace_shadow_dev")) return rc;
+	DeviceGuard guard(s->device);
+	return launchRays(s, true, nPackets, size, 1, origin3, dir, idir, nullptr, distance, nullptr, nullptr, dStats, (hipStream_t)stream);
+}
+
+namespace {
+struct DevBuf {
+	void *p = nullptr;
+	~DevBuf() { if(p) (void)hipFree(p); }
+	int upload(const void *src, size_t bytes) {
+		if(hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) return 1;
+		if(src && bytes && hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return 1;
+		return 0;
+	}
+	int download(void *dst, size_t bytes) { return hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost) != hipSuccess; }
+};
+} // namespace
+
+int snail_trace_rays(SnailScene *s, int nPackets, int size, int sharedOrigin, const float *origin, const float *dir, const float *idir,
+					 const uint8_t *mask, float *distance, int32_t *object, float *bary, uint64_t stats[4]) {
+	if(int rc = checkScene(s, "snail_trace_rays")) return rc;
+	if(nPackets <= 0) return 0;
+	DeviceGuard guard(s->device);
+	const size_t nq = (size_t)nPackets * size;
+	DevBuf o, d, i, m, ds, ob, ba;
+	if(o.upload(origin, (sharedOrigin ? (size_t)nPackets : nq) * 48) || d.upload(dir, nq * 48) || i.upload(idir, nq * 48) ||
+	   (mask && m.upload(mask, nq)) || ds.upload(distance, nq * 16) || ob.upload(object, nq * 16) || ba.upload(bary, nq * 32)) {
+		snail_set_error("snail_trace_rays: device staging failed");
+		return 2;
+	}
+	if(stats) HIP_TRY(hipMemset(s->dStats, 0, 32));
+	int rc = launchRays(s, false, nPackets, size, sharedOrigin, (float *)o.p, (float *)d.p, (float *)i.p, mask ? (uint8_t *)m.p : nullptr, (float *)ds.p,
+						(int32_t *)ob.p, (float *)ba.p, stats ? (uint64_t *)s->dStats : nullptr, 0);
+	if(rc) return rc;
+	HIP_TRY(hipDeviceSynchronize());
+	if(ds.download(distance, nq * 16) || ob.download(object, nq * 16) || ba.download(bary, nq * 32)) { snail_set_error("snail_trace_rays: download failed"); return 2; }
+	if(stats) {
+		unsigned long long hs[4];
+		HIP_TRY(hipMemcpy(hs, s->dStats, 32, hipMemcpyDeviceToHost));
+		for(int k = 0; k < 4; k++) stats[k] += hs[k];
+	}
+	return 0;
+}
+
+int snail_trace_shadow(SnailScene *s, int nPackets, int size, const float *origin3, const float *dir, const float *idir, float *distance,
+					   uint64_t stats[4]) {
+	if(int rc = checkScene(s, "snail_trace_shadow")) return rc;
+	if(nPackets <= 0) return 0;
+	DeviceGuard guard(s->device);
+	const size_t nq = (size_t)nPackets * size;
+	DevBuf o, d, i, ds;
+	if(o.upload(origin3, (size_t)nPackets * 12) || d.upload(dir, nq * 48) || i.upload(idir, nq * 48) || ds.upload(distance, nq * 16)) {
+		snail_set_error("snail_trace_shadow: device staging failed");
+		return 2;
+	}
+	if(stats) HIP_TRY(hipMemset(s->dStats, 0, 32));
+	int rc = launchRays(s, true, nPackets, size, 1, (float *)o.p, (float *)d.p, (float *)i.p, nullptr, (float *)ds.p, nullptr, nullptr,
+						stats ? (uint64_t *)s->dStats : nullptr, 0);
+	if(rc) return rc;
+	HIP_TRY(hipDeviceSynchronize());
+	if(ds.download(distance, nq * 16)) { snail_set_error("snail_trace_shadow: download failed"); return 2; }
+	if(stats) {
+		unsigned long long hs[4];
+		HIP_TRY(hipMemcpy(hs, s->dStats, 32, hipMemcpyDeviceToHost));
+		for(int k = 0; k < 4; k++) stats[k] += hs[k];
+	}
+	return 0;
+}
+
+int snail_account_primary(SnailScene *s, const float cam[13], int resx, int resy, int x0, int y0, int w, int h, uint64_t out[4]) {
+	if(int rc = checkScene(s, "snail_account_primary")) return rc;
+	if((x0 & 15) || (y0 & 15) || w <= 0 || h <= 0 || !out) { snail_set_error("snail_account_primary: bad rect"); return 1; }
+	DeviceGuard guard(s->device);
+	dev::AccountArgs A;
+	A.nodes = s->dNodes; A.tris = s->dTris;
+	A.g = makeGen(cam, resx, resy);
+	A.x0 = x0; A.y0 = y0; A.pw = (w + 15) / 16; A.ph = (h + 15) / 16;
+	A.out = (dev::u64 *)s->dStats;
+	HIP_TRY(hipMemset(s->dStats, 0, 32));
+	const int np = A.pw * A.ph;
+	hipLaunchKernelGGL(dev::k_account, dim3((np + 3) / 4), dim3(256), 0, 0, A);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipDeviceSynchronize());
+	unsigned long long hs[4];
+	HIP_TRY(hipMemcpy(hs, s->dStats, 32, hipMemcpyDeviceToHost));
+	for(int k = 0; k < 4; k++) out[k] += hs[k];
+	return 0;
+}
+
+} // extern "C"

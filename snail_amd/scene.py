@@ -1,0 +1,223 @@
+"""Device scene + the traversal entry points: the host-side mirror of the `AccStruct` concept that
+`template <class AccStruct> class Scene` requires (src/scene.h:26-58, models src/bvh/tree.h:27-50).
+
+  Scene.traverse_primary(ctx)    <-> BVH::TraversePrimary<sharedOrigin,hasMask>(Context&)  src/bvh/traverse.cpp:14-80
+  Scene.traverse_shadow(ctx)     <-> BVH::TraverseShadow(ShadowContext&)                   src/bvh/traverse.cpp:82-149
+  Scene.trace_primary(cam, ...)  <-> RayGenerator::Generate + SafeInv + TraversePrimary over a rect of 16x16 packets
+                                     (the per-packet body of RenderTask::Work, src/render.cpp:58-62,112-115)
+
+torch is used for device memory, streams and (in render.py) torch.distributed -- plumbing only; all
+compute is in libsnailhip.so.  Tensors follow the reference's Context memory layouts (see
+include/snail_hip.h)."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from .bvh import HostBVH
+from .camera import Camera
+
+PACKET_QUADS = 64       # 16x16 px, src/render.cpp:50-53
+PACKET_DIM = 16
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _stream_ptr(stream=None):
+    torch = _torch()
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)
+
+
+@dataclass
+class HitFrame:
+    """Row-major [resy, resx] hit records: miss = (+inf, 0, 0, 0) (src/scene_trace.cpp:112-115)."""
+    t: "object"
+    u: "object"
+    v: "object"
+    tri_id: "object"
+
+
+@dataclass
+class Context:
+    """`struct Context<sharedOrigin,hasMask>` (src/ray_group.h:351-380) as device tensors.
+    origin: [npackets,12] if shared else [npackets*size,12]; dir/idir: [npackets*size,12];
+    mask: uint8 [npackets*size] or None; distance/object: [npackets*size,4]; barycentric: [npackets*size,8]."""
+    origin: "object"
+    dir: "object"
+    idir: "object"
+    distance: "object"
+    object: "object"
+    barycentric: "object"
+    size: int = PACKET_QUADS
+    shared_origin: bool = True
+    mask: "object" = None
+
+    @property
+    def n_packets(self) -> int:
+        return self.dir.shape[0] // self.size
+
+
+@dataclass
+class ShadowContext:
+    """`struct ShadowContext` (src/ray_group.h:383-403): origin [npackets,3] (light), distance in/out."""
+    origin: "object"
+    dir: "object"
+    idir: "object"
+    distance: "object"
+    size: int = PACKET_QUADS
+
+    @property
+    def n_packets(self) -> int:
+        return self.dir.shape[0] // self.size
+
+
+class Scene:
+    """A BVH resident in one GPU's HBM (the reference ships the same arrays to a render node in
+    SendBVH, src/server.cpp:144-164)."""
+
+    def __init__(self, bvh: HostBVH, device: int | None = None):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise _lib.SnailError("no HIP device available: the traversal path has no CPU fallback")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self.bvh = bvh
+        h = _lib.lib().snail_scene_create(_lib.ptr(bvh.nodes), bvh.n_nodes, _lib.ptr(bvh.tris), bvh.n_tris, bvh.depth, self.device)
+        if not h:
+            raise _lib.SnailError("snail_scene_create: %s" % _lib.lib().snail_last_error().decode())
+        self._h = C.c_void_p(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().snail_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- AccStruct-shaped accessors -----------------------------------------------------------
+    def get_bbox(self):
+        return self.bvh.bbox()
+
+    def get_normal(self, elem: int, sub: int = 0):
+        return self.bvh.normal(elem)
+
+    def has_shading_data(self) -> bool:
+        return False    # BVH::noShadingData: ShTriangle records stay with the host shader
+
+    # ---- helpers ------------------------------------------------------------------------------
+    def _dev(self):
+        return _torch().device("cuda", self.device)
+
+    def new_stats(self):
+        """uint64[4] device accumulator {intersects, iters, rays, skips} (TreeStats, src/tree_stats.h:86-113)."""
+        torch = _torch()
+        return torch.zeros(4, dtype=torch.int64, device=self._dev())
+
+    def alloc_frame(self, resx: int, resy: int) -> HitFrame:
+        torch = _torch()
+        d = self._dev()
+        return HitFrame(torch.full((resy, resx), float("inf"), dtype=torch.float32, device=d),
+                        torch.zeros((resy, resx), dtype=torch.float32, device=d),
+                        torch.zeros((resy, resx), dtype=torch.float32, device=d),
+                        torch.zeros((resy, resx), dtype=torch.int32, device=d))
+
+    # ---- primary packets ----------------------------------------------------------------------
+    def trace_primary(self, cam: Camera, resx: int, resy: int, rect=None, out: HitFrame | None = None, stats=None, stream=None) -> HitFrame:
+        """Trace every 16x16 packet of `rect` (x0,y0,w,h; default the whole image)."""
+        x0, y0, w, h = rect if rect is not None else (0, 0, resx, resy)
+        out = out if out is not None else self.alloc_frame(resx, resy)
+        cam13 = np.ascontiguousarray(cam.as_array13(), dtype=np.float32)
+        rc = _lib.lib().snail_trace_primary_dev(self._h, _lib.ptr(cam13), resx, resy, x0, y0, w, h, _lib.ptr(out.t), _lib.ptr(out.u),
+                                                _lib.ptr(out.v), _lib.ptr(out.tri_id), _lib.ptr(stats), _stream_ptr(stream))
+        _lib.check(rc, "snail_trace_primary_dev")
+        return out
+
+    def trace_packets(self, cam: Camera, resx: int, resy: int, packet_xy, out=None, stats=None, stream=None):
+        """Trace an explicit packet list (int32 device tensor [n,2] of top-left pixels); results are
+        packet-major [n,256] in the reference's quad order (t, u, v, tri_id)."""
+        torch = _torch()
+        n = int(packet_xy.shape[0])
+        if out is None:
+            d = self._dev()
+            out = (torch.empty((n, 256), dtype=torch.float32, device=d), torch.empty((n, 256), dtype=torch.float32, device=d),
+                   torch.empty((n, 256), dtype=torch.float32, device=d), torch.empty((n, 256), dtype=torch.int32, device=d))
+        cam13 = np.ascontiguousarray(cam.as_array13(), dtype=np.float32)
+        rc = _lib.lib().snail_trace_packets_dev(self._h, _lib.ptr(cam13), resx, resy, _lib.ptr(packet_xy), n, _lib.ptr(out[0]), _lib.ptr(out[1]),
+                                                _lib.ptr(out[2]), _lib.ptr(out[3]), _lib.ptr(stats), _stream_ptr(stream))
+        _lib.check(rc, "snail_trace_packets_dev")
+        return out
+
+    @staticmethod
+    def packets_to_frame(packet_xy, planes, frame: HitFrame, stream=None):
+        resy, resx = frame.t.shape
+        rc = _lib.lib().snail_packets_to_frame_dev(_lib.ptr(packet_xy), int(packet_xy.shape[0]), resx, resy, _lib.ptr(planes[0]), _lib.ptr(planes[1]),
+                                                   _lib.ptr(planes[2]), _lib.ptr(planes[3]), _lib.ptr(frame.t), _lib.ptr(frame.u), _lib.ptr(frame.v),
+                                                   _lib.ptr(frame.tri_id), _stream_ptr(stream))
+        _lib.check(rc, "snail_packets_to_frame_dev")
+        return frame
+
+    def trace_primary_host(self, cam: Camera, resx: int, resy: int, rect=None):
+        """Host-buffer entry point (what a C++ host would call): numpy planes in, numpy planes out."""
+        x0, y0, w, h = rect if rect is not None else (0, 0, resx, resy)
+        t = np.full((resy, resx), np.inf, dtype=np.float32)
+        u = np.zeros((resy, resx), dtype=np.float32)
+        v = np.zeros((resy, resx), dtype=np.float32)
+        tid = np.zeros((resy, resx), dtype=np.int32)
+        stats = np.zeros(4, dtype=np.uint64)
+        cam13 = np.ascontiguousarray(cam.as_array13(), dtype=np.float32)
+        rc = _lib.lib().snail_trace_primary(self._h, _lib.ptr(cam13), resx, resy, x0, y0, w, h, _lib.ptr(t), _lib.ptr(u), _lib.ptr(v), _lib.ptr(tid),
+                                            _lib.ptr(stats))
+        _lib.check(rc, "snail_trace_primary")
+        return t, u, v, tid, stats
+
+    # ---- generic / shadow packets -------------------------------------------------------------
+    def traverse_primary(self, ctx: Context, stats=None, stream=None) -> Context:
+        rc = _lib.lib().snail_trace_rays_dev(self._h, ctx.n_packets, ctx.size, int(ctx.shared_origin), _lib.ptr(ctx.origin), _lib.ptr(ctx.dir),
+                                             _lib.ptr(ctx.idir), _lib.ptr(ctx.mask), _lib.ptr(ctx.distance), _lib.ptr(ctx.object),
+                                             _lib.ptr(ctx.barycentric), _lib.ptr(stats), _stream_ptr(stream))
+        _lib.check(rc, "snail_trace_rays_dev")
+        return ctx
+
+    def traverse_shadow(self, ctx: ShadowContext, stats=None, stream=None) -> ShadowContext:
+        rc = _lib.lib().snail_trace_shadow_dev(self._h, ctx.n_packets, ctx.size, _lib.ptr(ctx.origin), _lib.ptr(ctx.dir), _lib.ptr(ctx.idir),
+                                               _lib.ptr(ctx.distance), _lib.ptr(stats), _stream_ptr(stream))
+        _lib.check(rc, "snail_trace_shadow_dev")
+        return ctx
+
+    def trace_rays_host(self, origin, dir, idir, mask, distance, obj, bary, n_packets, size, shared):
+        stats = np.zeros(4, dtype=np.uint64)
+        rc = _lib.lib().snail_trace_rays(self._h, n_packets, size, int(shared), _lib.ptr(origin), _lib.ptr(dir), _lib.ptr(idir), _lib.ptr(mask),
+                                         _lib.ptr(distance), _lib.ptr(obj), _lib.ptr(bary), _lib.ptr(stats))
+        _lib.check(rc, "snail_trace_rays")
+        return stats
+
+    def trace_shadow_host(self, origin3, dir, idir, distance, n_packets, size):
+        stats = np.zeros(4, dtype=np.uint64)
+        rc = _lib.lib().snail_trace_shadow(self._h, n_packets, size, _lib.ptr(origin3), _lib.ptr(dir), _lib.ptr(idir), _lib.ptr(distance),
+                                           _lib.ptr(stats))
+        _lib.check(rc, "snail_trace_shadow")
+        return stats
+
+    # ---- measurement --------------------------------------------------------------------------
+    def account_primary(self, cam: Camera, resx: int, resy: int, rect=None) -> np.ndarray:
+        """{rays, sum V_n, sum V_t, hits} of the single-ray accounting walk."""
+        x0, y0, w, h = rect if rect is not None else (0, 0, resx, resy)
+        out = np.zeros(4, dtype=np.uint64)
+        cam13 = np.ascontiguousarray(cam.as_array13(), dtype=np.float32)
+        _lib.check(_lib.lib().snail_account_primary(self._h, _lib.ptr(cam13), resx, resy, x0, y0, w, h, _lib.ptr(out)), "snail_account_primary")
+        return out
+
+    def last_launch(self):
+        b, t = C.c_int(0), C.c_int(0)
+        _lib.check(_lib.lib().snail_last_launch(self._h, C.addressof(b), C.addressof(t)), "snail_last_launch")
+        return b.value, t.value

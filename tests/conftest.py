@@ -1,0 +1,21 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def reference_scenes():
+    """Directory of the reference's OBJ assets; only present in the build container (never on the GPU box)."""
+    p = "/root/reference/scenes"
+    if not os.path.isdir(p):
+        pytest.skip("reference checkout not present")
+    return p

@@ -1,0 +1,114 @@
+"""Shared helpers for the parity tests: scene construction (product builder AND oracle builder),
+cameras, seeded secondary-ray packets in the reference's Context layout."""
+from __future__ import annotations
+
+import functools
+import math
+
+import numpy as np
+
+from snail_amd import FPSCamera, HostBVH, scenes, survey_camera
+from tests import oracle_lib as O
+
+
+@functools.lru_cache(maxsize=8)
+def scene_pair(name: str):
+    """(tri_verts, HostBVH built by the product, OracleScene built by the oracle)."""
+    tv = scenes.scene_by_name(name)
+    return tv, HostBVH.build(tv), O.OracleScene(tv)
+
+
+def camera_for(name: str, tv):
+    if name.startswith("atrium"):
+        pos, ang, pitch = scenes.atrium_camera()
+        return FPSCamera(pos, ang, pitch).camera()
+    if name.startswith("stress"):
+        pos, ang, pitch = scenes.stress_camera()
+        return FPSCamera(pos, ang, pitch).camera()
+    return survey_camera(tv)
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32 if a.dtype.itemsize == 4 else np.uint8)
+
+
+def assert_bit_equal(a, b, what=""):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    ne = bits(a) != bits(b)
+    assert not ne.any(), "%s: %d of %d elements differ (first at %s: %r vs %r)" % (
+        what, int(ne.sum()), ne.size, np.argwhere(ne)[0], a[tuple(np.argwhere(ne)[0])], b[tuple(np.argwhere(ne)[0])])
+
+
+def secondary_packets(oscene, cam, resx, resy, n_packets, seed, shared, masked, size=64, poison=False):
+    """Build seeded packets the way the reference's secondary rays look (src/scene_trace.cpp:603-634):
+    origins on first-hit points of primary packets, directions = mirrored primaries + jitter; idir = 1/(d+1e-8);
+    masks with random dead lanes; distance = +inf / -inf(masked), object = 0 (src/scene_trace.cpp:112-115).
+    Returns numpy arrays in Context layout."""
+    rng = np.random.RandomState(seed)
+    nq = n_packets * size
+    origin = np.zeros((n_packets if shared else nq, 12), dtype=np.float32)
+    dirs = np.zeros((nq, 12), dtype=np.float32)
+    bmin, bmax = oscene.nodes[0]["bmin"], oscene.nodes[0]["bmax"]
+    centre, ext = (bmin + bmax) * 0.5, (bmax - bmin)
+    for p in range(n_packets):
+        base = centre + (rng.rand(3) - 0.5) * ext * 0.6
+        main = rng.randn(3)
+        main /= np.linalg.norm(main)
+        for q in range(size):
+            d = main[None, :] + 0.08 * rng.randn(4, 3) + 0.004 * np.array([[q % 4, q // 4, 0]])
+            d /= np.linalg.norm(d, axis=1, keepdims=True)
+            dirs[p * size + q] = d.T.reshape(-1).astype(np.float32)
+            if not shared:
+                o = base[None, :] + 0.02 * ext * rng.randn(4, 3)
+                origin[p * size + q] = o.T.reshape(-1).astype(np.float32)
+        if shared:
+            origin[p] = np.repeat(base.astype(np.float32), 4)
+    if poison:
+        # axis-parallel and the SafeInv singularity dir == -1e-8 (src/rtbase.h:117-120): idir = 1/0 = inf
+        dirs[0, 0:4] = 0.0
+        dirs[1, 4:8] = np.float32(-0.00000001)
+        dirs[2 * size // 3, 8:12] = np.float32(-0.00000001)
+    idir = (np.float32(1.0) / (dirs + np.float32(0.00000001))).astype(np.float32)
+    mask = None
+    dist = np.full((nq, 4), np.inf, dtype=np.float32)
+    if masked:
+        mask = rng.randint(0, 16, size=nq).astype(np.uint8)
+        mask[rng.rand(nq) < 0.2] = 0
+        mask[rng.rand(nq) < 0.3] = 15
+        if n_packets > 1:
+            mask[size:2 * size] = 0          # one fully dead packet
+        lanes = (mask[:, None] >> np.arange(4)[None, :]) & 1
+        dist[lanes == 0] = -np.inf
+    obj = np.zeros((nq, 4), dtype=np.int32)
+    bary = np.zeros((nq, 8), dtype=np.float32)
+    return origin, dirs, idir, mask, dist, obj, bary
+
+
+def shadow_packets(oscene, n_packets, seed, size=64):
+    """Shadow packets as Scene::TraceLight builds them (src/scene_trace.cpp:538-558): dir = (P - L)/|P - L|,
+    idir = SafeInv(dir), distance = |P - L| * 0.9999 for lit candidates, -inf for masked lanes."""
+    rng = np.random.RandomState(seed)
+    nq = n_packets * size
+    bmin, bmax = oscene.nodes[0]["bmin"], oscene.nodes[0]["bmax"]
+    centre, ext = (bmin + bmax) * 0.5, (bmax - bmin)
+    origin = np.zeros((n_packets, 3), dtype=np.float32)
+    dirs = np.zeros((nq, 12), dtype=np.float32)
+    dist = np.zeros((nq, 4), dtype=np.float32)
+    for p in range(n_packets):
+        L = (centre + (rng.rand(3) - 0.5) * ext * np.array([0.5, 0.2, 0.5]) + np.array([0, 0.3 * ext[1], 0])).astype(np.float32)
+        origin[p] = L
+        tgt = centre + (rng.rand(3) - 0.5) * ext
+        for q in range(size):
+            P = (tgt[None, :] + 0.03 * ext[None, :] * rng.randn(4, 3) + 0.01 * ext * np.array([[q % 4, 0, q // 4]])).astype(np.float32)
+            lv = (P - L[None, :]).astype(np.float32)
+            ln = np.sqrt((lv * lv).sum(axis=1)).astype(np.float32)
+            d = (lv / ln[:, None]).astype(np.float32)
+            dirs[p * size + q] = d.T.reshape(-1)
+            dist[p * size + q] = (ln * np.float32(0.9999)).astype(np.float32)
+    dead = rng.rand(nq, 4) < 0.25
+    dist[dead] = -np.inf
+    if n_packets > 2:
+        dist[2 * size:3 * size] = -np.inf      # fully masked packet
+    idir = (np.float32(1.0) / (dirs + np.float32(0.00000001))).astype(np.float32)
+    return origin, dirs, idir, dist
