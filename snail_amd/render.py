@@ -1,0 +1,147 @@
+"""Tile-level rendering: the mirror of src/render.h:16-28 restricted to the traversal path, plus the
+image-space data parallelism of the reference's MPI server/node pair re-done for one process per GPU.
+
+Reference scheme (src/server.cpp:233-265, src/node.cpp:245-258,336-349): the frame is cut into
+blockWidth x blockHeight = 16 x 64 pixel tiles (src/rtbase_math.h:31-34), tiles are dealt to the render
+nodes by shuffled round-robin at connect time, every node renders its tiles, and each frame the
+per-tile buffers travel back to rank 0.  Here: the tile map is computed identically on every rank
+(seeded shuffle, no message), each rank traces the 16x16 packets of its tiles with ONE kernel launch
+into packet-major buffers, and ONE collective per frame (torch.distributed gather -> RCCL send/recv over
+xGMI, all 7 peer links of GPU0 in parallel; gloo on CPU for tests) brings them to rank 0, which scatters
+them into the frame.  There is no exchange step inside traversal, hence no other collective."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+BLOCK_WIDTH = 16     # src/rtbase_math.h:31-34
+BLOCK_HEIGHT = 64
+PACKET = 16
+
+
+def divide_image(resx: int, resy: int, bw: int = BLOCK_WIDTH, bh: int = BLOCK_HEIGHT) -> np.ndarray:
+    """DivideImage as used at src/server.cpp:235: row-major list of tiles (x, y, w, h).  The reference
+    demands resx % 16 == 0 and resy % 64 == 0 (src/server.cpp:227-231); partial edge tiles are allowed
+    here because packets are traced whole anyway (src/render.cpp:67-68)."""
+    tiles = []
+    for y in range(0, resy, bh):
+        for x in range(0, resx, bw):
+            tiles.append((x, y, min(bw, resx - x), min(bh, resy - y)))
+    return np.asarray(tiles, dtype=np.int32).reshape(-1, 4)
+
+
+def assign_tiles(n_tiles: int, n_ranks: int, seed: int = 20090501) -> np.ndarray:
+    """Shuffled round-robin of src/server.cpp:239-248: every group of n_ranks consecutive tiles gets a
+    fresh permutation of the ranks.  (The reference uses std::random_shuffle with the C library's unseeded
+    rand(); any permutation sequence balances equally well, so a seeded numpy generator is used and
+    the map is reproducible on every rank without communication.)"""
+    rng = np.random.RandomState(seed)
+    owner = np.empty(n_tiles, dtype=np.int32)
+    order = np.arange(n_ranks)
+    for n in range(n_tiles):
+        if n % n_ranks == 0:
+            order = rng.permutation(n_ranks)
+        owner[n] = order[n % n_ranks]
+    return owner
+
+
+def tile_packets(tiles: np.ndarray) -> np.ndarray:
+    """Top-left corners of the 16x16 packets of each tile, tile after tile (RenderTask::Work loop order,
+    src/render.cpp:67-68: y outer, x inner)."""
+    out = []
+    for x, y, w, h in tiles.tolist():
+        for py in range(y, y + h, PACKET):
+            for px in range(x, x + w, PACKET):
+                out.append((px, py))
+    return np.asarray(out, dtype=np.int32).reshape(-1, 2)
+
+
+@dataclass
+class ShardPlan:
+    """Everything a rank needs, computed identically everywhere."""
+    resx: int
+    resy: int
+    n_ranks: int
+    tiles: np.ndarray            # [nTiles,4]
+    owner: np.ndarray            # [nTiles]
+    packets: list                # per rank: int32 [n_r,2]
+    padded: int                  # packets per rank after padding to equal size
+
+    @staticmethod
+    def make(resx: int, resy: int, n_ranks: int, seed: int = 20090501) -> "ShardPlan":
+        tiles = divide_image(resx, resy)
+        owner = assign_tiles(len(tiles), n_ranks, seed)
+        packets = [tile_packets(tiles[owner == r]) for r in range(n_ranks)]
+        padded = max(len(p) for p in packets)
+        return ShardPlan(resx, resy, n_ranks, tiles, owner, packets, padded)
+
+    def padded_packets(self, rank: int) -> np.ndarray:
+        """Equal-sized shards for the collective: short ranks repeat their last packet (idempotent)."""
+        p = self.packets[rank]
+        if len(p) == self.padded:
+            return p
+        if len(p) == 0:
+            return np.zeros((self.padded, 2), dtype=np.int32)
+        pad = np.repeat(p[-1:], self.padded - len(p), axis=0)
+        return np.concatenate([p, pad], axis=0)
+
+    def total_rays(self) -> int:
+        return sum(len(p) for p in self.packets) * 256
+
+
+def gather_planes(local, rank: int, world: int, group=None, gathered=None):
+    """The per-frame collective: every rank's equal-sized [4, n, 256] packet-major buffer to rank 0
+    (src/node.cpp:346-349 MPI_Send / src/server.cpp:389-401 MPI_Recv in the reference).  Returns the list of
+    per-rank buffers on rank 0, None elsewhere.  Backend-agnostic (nccl = RCCL on GPU, gloo on CPU)."""
+    import torch
+    import torch.distributed as dist
+    if rank == 0 and gathered is None:
+        gathered = [torch.empty_like(local) for _ in range(world)]
+    dist.gather(local, gathered if rank == 0 else None, dst=0, group=group)
+    return gathered if rank == 0 else None
+
+
+class DistributedRenderer:
+    """One process per GPU.  render() = trace this rank's packets, gather to rank 0, scatter into the
+    frame there.  With world_size 1 the frame is traced directly in frame layout (no collective)."""
+
+    def __init__(self, scene, resx: int, resy: int, rank: int = 0, world_size: int = 1, group=None, seed: int = 20090501):
+        import torch
+        self.torch = torch
+        self.scene = scene
+        self.rank, self.world = rank, world_size
+        self.group = group
+        self.plan = ShardPlan.make(resx, resy, world_size, seed)
+        dev = scene._dev()
+        self.frame = scene.alloc_frame(resx, resy) if rank == 0 else None
+        if world_size > 1:
+            n = self.plan.padded
+            self.packet_xy = torch.from_numpy(self.plan.padded_packets(rank)).to(dev)
+            # one buffer [4, n, 256] so that the frame's planes travel in ONE collective
+            self.local = torch.empty((4, n, 256), dtype=torch.float32, device=dev)
+            self.planes = (self.local[0], self.local[1], self.local[2], self.local[3].view(torch.int32))
+            if rank == 0:
+                self.gathered = [torch.empty_like(self.local) for _ in range(world_size)]
+                self.all_xy = [torch.from_numpy(self.plan.padded_packets(r)).to(dev) for r in range(world_size)]
+            else:
+                self.gathered = None
+
+    def rays_per_frame(self) -> int:
+        return self.plan.total_rays()
+
+    def local_rays(self) -> int:
+        return len(self.plan.packets[self.rank]) * 256
+
+    def render(self, cam, stats=None):
+        torch = self.torch
+        sc, p = self.scene, self.plan
+        if self.world == 1:
+            return sc.trace_primary(cam, p.resx, p.resy, out=self.frame, stats=stats)
+        sc.trace_packets(cam, p.resx, p.resy, self.packet_xy, out=self.planes, stats=stats)
+        gather_planes(self.local, self.rank, self.world, self.group, self.gathered)
+        if self.rank == 0:
+            for r in range(self.world):
+                g = self.gathered[r]
+                sc.packets_to_frame(self.all_xy[r], (g[0], g[1], g[2], g[3].view(torch.int32)), self.frame)
+        return self.frame

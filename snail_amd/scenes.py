@@ -81,11 +81,12 @@ def load_obj(path: str, flip: bool = True) -> np.ndarray:
 
 
 def save_obj(path: str, tri_verts: np.ndarray) -> None:
-    """Write triangles as an OBJ with '%f' coordinates (exact for dyadic-grid coordinates)."""
+    """Write triangles as an OBJ with 10 decimals: exact for the generators' 1/1024 coordinate grid, so
+    the text round-trips bit-exactly through sscanf("%f") (src/formats/wavefront_obj.cpp:98-101)."""
     tv = np.asarray(tri_verts, dtype=F32).reshape(-1, 3)
     with open(path, "w") as fh:
         for p in tv:
-            fh.write("v %f %f %f\n" % (p[0], p[1], p[2]))
+            fh.write("v %.10f %.10f %.10f\n" % (p[0], p[1], p[2]))
         for i in range(len(tv) // 3):
             fh.write("f %d %d %d\n" % (3 * i + 1, 3 * i + 2, 3 * i + 3))
 
@@ -112,7 +113,7 @@ def box_scene(flip: bool = True) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------------------------------
-# procedural stand-ins.  All coordinates are snapped to a 1/1024 grid so "%f" text round-trips.
+# procedural stand-ins.  All coordinates are snapped to a 1/1024 grid so 10-decimal text round-trips.
 # --------------------------------------------------------------------------------------------------
 def _snap(a: np.ndarray) -> np.ndarray:
     return (np.round(np.asarray(a, dtype=np.float64) * 1024.0) / 1024.0).astype(F32)

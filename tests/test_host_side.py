@@ -1,0 +1,148 @@
+"""CPU tests of the product's host side (no GPU, no compute through the HIP kernels): the C-ABI library
+loads and exports every symbol include/snail_hip.h declares; the host SAH builder inside libsnailhip.so
+is bit-identical to the oracle's; scene ingest mirrors the loader's order/winding rules; tile plan."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import snail_amd
+from snail_amd import HostBVH, scenes
+from snail_amd import render as R
+from tests import oracle_lib as O
+from tests import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_capi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "snail_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(snail_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(declared) >= 15
+    lib = snail_amd.lib()
+    for name in declared:
+        assert hasattr(lib, name), "libsnailhip.so does not export " + name
+    from snail_amd._lib import SIGNATURES
+    assert sorted(SIGNATURES) == declared          # the Python binding covers the whole header
+
+
+def test_missing_extension_fails_loudly(monkeypatch, tmp_path):
+    from snail_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(snail_amd.SnailError):
+        _lib.lib()
+
+
+def test_scene_needs_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from snail_amd.scene import Scene
+    tv, hb, osc = util.scene_pair("box")
+    with pytest.raises(snail_amd.SnailError):
+        Scene(hb, 0)
+
+
+@pytest.mark.parametrize("name", ["box", "atrium:0.05", "stress:0.01"])
+def test_builder_bit_identical_to_oracle(name):
+    tv, hb, osc = util.scene_pair(name)
+    assert hb.tris.tobytes() == osc.tris.tobytes()
+    assert hb.nodes.tobytes() == osc.nodes.tobytes()
+    assert hb.depth == osc.depth and np.array_equal(hb.perm, osc.perm)
+
+
+@pytest.mark.parametrize("name", ["box", "atrium:0.05"])
+def test_tree_invariants(name):
+    tv, hb, osc = util.scene_pair(name)
+    n = len(tv)
+    assert sorted(hb.perm.tolist()) == list(range(n))                       # a permutation of the input
+    # triangles were only permuted, never altered
+    fresh = HostBVH.triangles(tv)
+    assert hb.tris.tobytes() == fresh[hb.perm].tobytes()
+    nodes = hb.nodes
+    leaf = (nodes["sub"] & 0x80000000) != 0
+    first = (nodes["sub"] & 0x7fffffff)[leaf]
+    count = nodes["aux"][leaf]
+    order = np.argsort(first)
+    assert first[order][0] == 0 and (first[order][1:] == (first[order] + count[order])[:-1]).all()   # leaves tile [0,n)
+    assert int(count.sum()) == n and count.max() <= max(4, count.max())
+    inner = ~leaf
+    child = nodes["sub"][inner]
+    assert (child >= 1).all() and (child + 1 < len(nodes)).all()
+    assert ((nodes["aux"][inner] & 0xffff) <= 2).all() and ((nodes["aux"][inner] >> 16) <= 1).all()
+    # every child box lies inside... not required by the builder (leaf boxes are recomputed), but leaves must bound their triangles
+    for i in np.nonzero(leaf)[0][:200]:
+        f, c = int(nodes["sub"][i] & 0x7fffffff), int(nodes["aux"][i])
+        t = hb.tris[f:f + c]
+        p = np.stack([t["a"], t["a"] + t["ba"], t["a"] + t["ca"]], axis=1).reshape(-1, 3)
+        assert (p.min(0) >= nodes["bmin"][i] - 1e-6).all() and (p.max(0) <= nodes["bmax"][i] + 1e-6).all()
+    assert hb.depth <= 64
+
+
+def test_triangle_record_matches_reference_formulae():
+    tv = scenes.box_scene()
+    t = HostBVH.triangles(tv)
+    for k in range(len(tv)):
+        v0, v1, v2 = tv[k].astype(np.float32)
+        assert np.array_equal(t["a"][k], v0) and np.array_equal(t["ba"][k], v1 - v0) and np.array_equal(t["ca"][k], v2 - v0)
+        n = np.cross((v1 - v0).astype(np.float64), (v2 - v0).astype(np.float64))
+        assert abs(t["t0"][k] - np.linalg.norm(n)) < 1e-5 and abs(t["it0"][k] * t["t0"][k] - 1) < 1e-6
+        assert np.allclose(t["plane"][k][:3], n / np.linalg.norm(n), atol=1e-6)
+        assert abs(t["plane"][k][3] - (n / np.linalg.norm(n)) @ v0) < 1e-5
+
+
+def test_obj_ingest_rules(tmp_path):
+    p = tmp_path / "m.obj"
+    p.write_text("""# quad, degenerate face, negative indices, v/vt/vn forms
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+v 0 0 1
+vt 0 0
+vn 0 0 1
+f 1 2 3 4
+f 1/1/1 2/1/1 2/1/1
+f 1//1 3//1 5//1
+f -5 -4 -1
+""")
+    tv = scenes.load_obj(str(p), flip=False)
+    V = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1]], dtype=np.float32)
+    # quad -> (v0,v1,v2),(v2,v3,v0); the degenerate face (index 2) is replaced by the LAST face (swap-with-last)
+    want = np.array([V[[0, 1, 2]], V[[2, 3, 0]], V[[0, 1, 4]], V[[0, 2, 4]]])
+    assert np.array_equal(tv, want)
+    flipped = scenes.load_obj(str(p), flip=True)
+    assert np.array_equal(flipped, want[:, [1, 0, 2]])                      # FlipNormals swaps v0 <-> v1
+    # '%f' round trip of a dyadic-grid scene is exact
+    a = scenes.drop_degenerate(scenes.atrium(detail=0.01))
+    q = tmp_path / "a.obj"
+    scenes.save_obj(str(q), a)
+    assert np.array_equal(scenes.load_obj(str(q), flip=False), a)
+
+
+def test_box_restatement_matches_reference_asset(reference_scenes):
+    assert np.array_equal(scenes.load_obj(os.path.join(reference_scenes, "box.obj")), scenes.box_scene())
+
+
+def test_tile_plan_partitions_the_frame():
+    for resx, resy, n in ((1920, 1080, 1), (2720, 1528, 2), (3840, 2160, 8), (250, 130, 3)):
+        plan = R.ShardPlan.make(resx, resy, n)
+        assert len(plan.tiles) == ((resx + 15) // 16) * ((resy + 63) // 64)
+        allp = np.concatenate(plan.packets, axis=0)
+        want = {(x, y) for y in range(0, resy, 16) for x in range(0, resx, 16)}
+        got = [tuple(p) for p in allp.tolist()]
+        assert len(got) == len(set(got)) == len(want) and set(got) == want          # every packet exactly once
+        sizes = [len(p) for p in plan.packets]
+        assert max(sizes) - min(sizes) <= 4 * 2                                     # balanced to within two tiles
+        for r in range(n):
+            pp = plan.padded_packets(r)
+            assert len(pp) == plan.padded and np.array_equal(pp[:len(plan.packets[r])], plan.packets[r])
+        assert plan.total_rays() == len(want) * 256
+    # identical on every rank without communication
+    a, b = R.ShardPlan.make(640, 384, 4), R.ShardPlan.make(640, 384, 4)
+    assert np.array_equal(a.owner, b.owner)
+    # shuffled round-robin: each group of n consecutive tiles is a permutation of the ranks (src/server.cpp:239-248)
+    own = R.assign_tiles(64, 8)
+    assert all(sorted(own[i:i + 8].tolist()) == list(range(8)) for i in range(0, 64, 8))
