@@ -108,14 +108,40 @@ __device__ __forceinline__ Tri loadTriScalar(const uint4 *tris, int idx) { // wa
 	return unpackTri(r0, r1, r2, r3);
 }
 
-// veclib Min/Max: a<b?a:b / a>b?a:b (veclib/vecbase.h:75-76, minps/maxps in veclib/sse/f32.h:104-105).
-template <bool EXACT> __device__ __forceinline__ float Min(float a, float b) {
-	if(EXACT) return a < b ? a : b;
-	return __builtin_fminf(a, b);
+// Arithmetic modes of the walk (selected per packet, wave-uniform):
+//   M_EXACT: veclib Min/Max as selects, a<b?a:b / a>b?a:b (veclib/vecbase.h:75-76; minps/maxps of
+//            veclib/sse/f32.h:104-105 have the same "second operand on NaN" behaviour), reference operand
+//            order, interval culls included.  Always correct; used when a packet holds non-finite values.
+//   M_FAST : every input finite => no NaN can arise, Min/Max == v_min_f32/v_max_f32 up to the sign of zero
+//            (never observed by a comparison); BBox::TestInterval is implied by the per-lane test
+//            (monotonic rounding) and skipped.
+//   M_COH  : M_FAST + every ray of the packet has the same idir sign per axis, so min(l1,l2)/max(l1,l2)
+//            of a slab are known without comparing: near/far planes are picked once per node (scalar).
+enum { M_EXACT = 0, M_FAST = 1, M_COH = 2 };
+
+// raw VALU min/max: clang would wrap llvm.minnum in sNaN-quieting canonicalisations (v_max_f32 x,x,x)
+// whenever an operand crosses a basic block; the FAST paths only ever see finite values.
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+template <int M> __device__ __forceinline__ float Min(float a, float b) {
+	if(M == M_EXACT) return a < b ? a : b;
+	return vmin(a, b);
 }
-template <bool EXACT> __device__ __forceinline__ float Max(float a, float b) {
-	if(EXACT) return a > b ? a : b;
-	return __builtin_fmaxf(a, b);
+template <int M> __device__ __forceinline__ float Max(float a, float b) {
+	if(M == M_EXACT) return a > b ? a : b;
+	return vmax(a, b);
+}
+// Min(a, Min(b, c)) / Max(a, Max(b, c))
+template <int M> __device__ __forceinline__ float Min3(float a, float b, float c) {
+	if(M == M_EXACT) { float m = b < c ? b : c; return a < m ? a : m; }
+	return vmin3(a, b, c);
+}
+template <int M> __device__ __forceinline__ float Max3(float a, float b, float c) {
+	if(M == M_EXACT) { float m = b > c ? b : c; return a > m ? a : m; }
+	return vmax3(a, b, c);
 }
 
 __device__ __forceinline__ float readlanef(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
@@ -123,12 +149,12 @@ __device__ __forceinline__ float firstlanef(float v) { return __int_as_float(__b
 
 __device__ __forceinline__ float waveMin(float v) {
 #pragma unroll
-	for(int o = 32; o > 0; o >>= 1) v = __builtin_fminf(v, __shfl_xor(v, o));
+	for(int o = 32; o > 0; o >>= 1) v = vmin(v, __shfl_xor(v, o));
 	return v;
 }
 __device__ __forceinline__ float waveMax(float v) {
 #pragma unroll
-	for(int o = 32; o > 0; o >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, o));
+	for(int o = 32; o > 0; o >>= 1) v = vmax(v, __shfl_xor(v, o));
 	return v;
 }
 
@@ -153,7 +179,7 @@ struct Quad {
 // FAST: all values finite -> plain wave reduction (min/max are order independent without NaN).
 // EXACT: the reference's sequential fold, per SSE slot, through LDS (NaN makes the fold order visible).
 template <bool EXACT, bool MASKED>
-__device__ void computeMinMax(const float (&v)[3][4], unsigned act4, bool seedFromFirst, int size, int lane, float *lds /*64*12+64 floats*/,
+__device__ void computeMinMax(const float (&v)[3][4], unsigned act4, int size, int lane, float *lds /*64*12+64 floats*/,
 							  float (&outMin)[3], float (&outMax)[3]) {
 	const float inf = __builtin_inff();
 	if(!EXACT) {
@@ -162,7 +188,7 @@ __device__ void computeMinMax(const float (&v)[3][4], unsigned act4, bool seedFr
 			float mn = inf, mx = -inf;
 #pragma unroll
 			for(int l = 0; l < 4; l++)
-				if(act4 & (1u << l)) { mn = __builtin_fminf(mn, v[c][l]); mx = __builtin_fmaxf(mx, v[c][l]); }
+				if(act4 & (1u << l)) { mn = vmin(mn, v[c][l]); mx = vmax(mx, v[c][l]); }
 			outMin[c] = anyAct ? waveMin(mn) : 0.0f;
 			outMax[c] = anyAct ? waveMax(mx) : 0.0f;
 		}
@@ -170,6 +196,8 @@ __device__ void computeMinMax(const float (&v)[3][4], unsigned act4, bool seedFr
 	}
 	// EXACT: stage the packet in LDS, lanes 0..11 fold (component c = lane>>2, slot l = lane&3)
 	unsigned *ldsMask = (unsigned *)(lds + 64 * 12);
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
 	if(lane < size) {
 #pragma unroll
 		for(int c = 0; c < 3; c++)
@@ -177,8 +205,8 @@ __device__ void computeMinMax(const float (&v)[3][4], unsigned act4, bool seedFr
 			for(int l = 0; l < 4; l++) lds[lane * 12 + c * 4 + l] = v[c][l];
 		ldsMask[lane] = act4;
 	}
-	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
 	float mn = 0.0f, mx = 0.0f;
 	bool none = false;
 	if(lane < 12) {
@@ -201,6 +229,7 @@ __device__ void computeMinMax(const float (&v)[3][4], unsigned act4, bool seedFr
 				mx = mx > x ? mx : x;
 			}
 	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	// Minimize / Maximize across the 4 slots: Min(Min(t0,t1),Min(t2,t3)) (src/rtbase_math.h:63-64)
 	bool noneU = __builtin_amdgcn_readfirstlane((int)none) != 0;
@@ -212,7 +241,6 @@ __device__ void computeMinMax(const float (&v)[3][4], unsigned act4, bool seedFr
 		outMin[c] = noneU ? 0.0f : (m01 < m23 ? m01 : m23);
 		outMax[c] = noneU ? 0.0f : (x01 > x23 ? x01 : x23);
 	}
-	(void)seedFromFirst;
 }
 
 // BBox::TestInterval (src/bounding_box.cpp:208-236): wave-uniform, only needed on the EXACT path
@@ -224,19 +252,20 @@ __device__ __forceinline__ bool boxTestInterval(const Node &n, const Interval &i
 		float l2 = i.maxIDir[k] * (n.bmin[k] - i.maxOrg[k]);
 		float l3 = i.minIDir[k] * (n.bmax[k] - i.minOrg[k]);
 		float l4 = i.maxIDir[k] * (n.bmax[k] - i.minOrg[k]);
-		float lo = Min<true>(Min<true>(l1, l2), Min<true>(l3, l4));
-		float hi = Max<true>(Max<true>(l1, l2), Max<true>(l3, l4));
+		float lo = Min<M_EXACT>(Min<M_EXACT>(l1, l2), Min<M_EXACT>(l3, l4));
+		float hi = Max<M_EXACT>(Max<M_EXACT>(l1, l2), Max<M_EXACT>(l3, l4));
 		if(k == 0) { lmin = lo; lmax = hi; }
-		else { lmin = Max<true>(lmin, lo); lmax = Min<true>(lmax, hi); }
+		else { lmin = Max<M_EXACT>(lmin, lo); lmax = Min<M_EXACT>(lmax, hi); }
 	}
 	return lmax >= 0.0f && lmin <= lmax;
 }
 
-// Triangle::TestInterval (src/triangle.cpp:110-167, shared-origin branch :122-129); each lane its own triangle
+// Triangle::TestInterval (src/triangle.cpp:110-167, shared-origin branch :122-129); each lane its own triangle.
+// Branch-free: (det < 0) | (...) has the same truth value as the reference's early return.
+template <int M>
 __device__ __forceinline__ bool triTestInterval(const Tri &t, const Interval &i) {
 	float det = (t.n[0] < 0.0f ? i.minDir[0] : i.maxDir[0]) * t.n[0] + (t.n[1] < 0.0f ? i.minDir[1] : i.maxDir[1]) * t.n[1] +
 				(t.n[2] < 0.0f ? i.minDir[2] : i.maxDir[2]) * t.n[2];
-	if(det < 0.0f) return true;
 	float tv[3] = {i.minOrg[0] - t.a[0], i.minOrg[1] - t.a[1], i.minOrg[2] - t.a[2]};
 	float c1[3] = {t.ba[1] * tv[2] - t.ba[2] * tv[1], t.ba[2] * tv[0] - t.ba[0] * tv[2], t.ba[0] * tv[1] - t.ba[1] * tv[0]};
 	float c2[3] = {tv[1] * t.ca[2] - tv[2] * t.ca[1], tv[2] * t.ca[0] - tv[0] * t.ca[2], tv[0] * t.ca[1] - tv[1] * t.ca[0]};
@@ -246,22 +275,42 @@ __device__ __forceinline__ bool triTestInterval(const Tri &t, const Interval &i)
 		c1a[k] = i.minDir[k] * c1[k]; c1b[k] = i.maxDir[k] * c1[k];
 		c2a[k] = i.minDir[k] * c2[k]; c2b[k] = i.maxDir[k] * c2[k];
 	}
-	float u0 = Min<true>(c1a[0], c1b[0]) + Min<true>(c1a[1], c1b[1]) + Min<true>(c1a[2], c1b[2]);
-	float u1 = Max<true>(c1a[0], c1b[0]) + Max<true>(c1a[1], c1b[1]) + Max<true>(c1a[2], c1b[2]);
-	float v0 = Min<true>(c2a[0], c2b[0]) + Min<true>(c2a[1], c2b[1]) + Min<true>(c2a[2], c2b[2]);
-	float v1 = Max<true>(c2a[0], c2b[0]) + Max<true>(c2a[1], c2b[1]) + Max<true>(c2a[2], c2b[2]);
-	return Min<true>(u1, v1) >= 0.0f && u0 + v0 <= det * t.t0;
+	float u0 = Min<M>(c1a[0], c1b[0]) + Min<M>(c1a[1], c1b[1]) + Min<M>(c1a[2], c1b[2]);
+	float u1 = Max<M>(c1a[0], c1b[0]) + Max<M>(c1a[1], c1b[1]) + Max<M>(c1a[2], c1b[2]);
+	float v0 = Min<M>(c2a[0], c2b[0]) + Min<M>(c2a[1], c2b[1]) + Min<M>(c2a[2], c2b[2]);
+	float v1 = Max<M>(c2a[0], c2b[0]) + Max<M>(c2a[1], c2b[1]) + Max<M>(c2a[2], c2b[2]);
+	return (det < 0.0f) | ((Min<M>(u1, v1) >= 0.0f) & (u0 + v0 <= det * t.t0));
+}
+
+// shared-origin terms of Triangle::Collide (src/triangle.cpp:13-18 / :76-80)
+struct TriTerms {
+	float t0v[3], t1v[3], tmul;
+};
+__device__ __forceinline__ TriTerms triTerms(const Tri &t, float ox, float oy, float oz) {
+	TriTerms r;
+	float tv[3] = {ox - t.a[0], oy - t.a[1], oz - t.a[2]};
+	r.t0v[0] = (t.ba[1] * tv[2] - t.ba[2] * tv[1]) * t.it0;
+	r.t0v[1] = (t.ba[2] * tv[0] - t.ba[0] * tv[2]) * t.it0;
+	r.t0v[2] = (t.ba[0] * tv[1] - t.ba[1] * tv[0]) * t.it0;
+	r.t1v[0] = (tv[1] * t.ca[2] - tv[2] * t.ca[1]) * t.it0;
+	r.t1v[1] = (tv[2] * t.ca[0] - tv[0] * t.ca[2]) * t.it0;
+	r.t1v[2] = (tv[0] * t.ca[1] - tv[1] * t.ca[0]) * t.it0;
+	r.tmul = -(tv[0] * t.n[0] + tv[1] * t.n[1] + tv[2] * t.n[2]);
+	return r;
 }
 
 // ---- the packet walk -------------------------------------------------------------------------------
 // SHARED : one origin per packet (primary / shadow)   MASK : per-lane 4-bit masks (secondary rays)
-// SHADOW : any-hit TraverseShadow                      EXACT: see file header
-// Stack: lane i of (stkNode, stkFL) is slot i; slots >= 64 (only reachable for depth > 62) use a 2nd pair.
-template <bool SHARED, bool MASK, bool SHADOW, bool EXACT>
+// SHADOW : any-hit TraverseShadow                      M    : arithmetic mode (above)
+// BARY   : keep barycentrics up to date in registers (else the caller derives them from the final triId)
+// DEEP   : scene depth > 62, stack slots >= 64 live in a second VGPR pair
+// Stack: lane i of (stkNode, stkFL) is slot i.
+template <bool SHARED, bool MASK, bool SHADOW, int M, bool BARY, bool DEEP>
 __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint4 *__restrict__ tris, int size, int lane,
 									 const float (&org)[3][4] /* SHARED: [c][0] uniform */, Quad &Q, unsigned mask4, int (&tid)[4],
 									 float (&bu)[4], float (&bv)[4], float *lds, Counters &st) {
 	const float inf = __builtin_inff();
+	constexpr bool EXACT = M == M_EXACT;
 	Interval iv;
 	{ // RayInterval ctor (src/ray_group.h:296-333)
 		unsigned act4 = lane < size ? 15u : 0u;
@@ -271,16 +320,18 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 #pragma unroll
 				for(int l = 0; l < 4; l++) act4 |= (Q.dist[l] >= 0.0f ? 1u : 0u) << l;
 		} else if(MASK) act4 = lane < size ? (mask4 & 15u) : 0u;
-		computeMinMax<EXACT, (MASK || SHADOW)>(Q.d, act4, false, size, lane, lds, iv.minDir, iv.maxDir);
-		computeMinMax<EXACT, (MASK || SHADOW)>(Q.id, act4, false, size, lane, lds, iv.minIDir, iv.maxIDir);
+		computeMinMax<EXACT, (MASK || SHADOW)>(Q.d, act4, size, lane, lds, iv.minDir, iv.maxDir);
+		computeMinMax<EXACT, (MASK || SHADOW)>(Q.id, act4, size, lane, lds, iv.minIDir, iv.maxIDir);
 		if(SHARED) {
 #pragma unroll
 			for(int k = 0; k < 3; k++) iv.minOrg[k] = iv.maxOrg[k] = org[k][0];
-		} else computeMinMax<EXACT, MASK>(org, act4, false, size, lane, lds, iv.minOrg, iv.maxOrg);
+		} else computeMinMax<EXACT, MASK>(org, act4, size, lane, lds, iv.minOrg, iv.maxOrg);
 	}
 
 	// child order from lane 0 of quad 0 (src/bvh/traverse.cpp:21)
 	const int sign0 = firstlanef(Q.d[0][0]) < 0.0f, sign1 = firstlanef(Q.d[1][0]) < 0.0f, sign2 = firstlanef(Q.d[2][0]) < 0.0f;
+	// M_COH: the (packet-uniform) sign of idir per axis picks the near/far slab plane
+	const bool neg0 = firstlanef(Q.id[0][0]) < 0.0f, neg1 = firstlanef(Q.id[1][0]) < 0.0f, neg2 = firstlanef(Q.id[2][0]) < 0.0f;
 
 	int stkNode = 0, stkFL = 0, stkNode2 = 0, stkFL2 = 0;
 	int sp = 0;
@@ -292,7 +343,7 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 			if(sp == 0) break;
 			sp--;
 			int fl;
-			if(sp < 64) { cur = __builtin_amdgcn_readlane(stkNode, sp); fl = __builtin_amdgcn_readlane(stkFL, sp); }
+			if(!DEEP || sp < 64) { cur = __builtin_amdgcn_readlane(stkNode, sp); fl = __builtin_amdgcn_readlane(stkFL, sp); }
 			else { cur = __builtin_amdgcn_readlane(stkNode2, sp - 64); fl = __builtin_amdgcn_readlane(stkFL2, sp - 64); }
 			first = fl & 0xff; last = fl >> 8;
 		}
@@ -305,7 +356,7 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 
 		// ---- BBox::Test (src/bounding_box.cpp:61-142 / :144-200) ----
 		bool anyPass = false;
-		{
+		if(EXACT) {
 			float tmn[3], tmx[3];
 			if(SHARED) {
 #pragma unroll
@@ -318,13 +369,36 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				for(int k = 0; k < 3; k++) {
 					float l1 = Q.id[k][l] * (SHARED ? tmn[k] : n.bmin[k] - org[k][l]);
 					float l2 = Q.id[k][l] * (SHARED ? tmx[k] : n.bmax[k] - org[k][l]);
-					float lo = Min<EXACT>(l1, l2), hi = Max<EXACT>(l1, l2);
+					float lo = Min<M_EXACT>(l1, l2), hi = Max<M_EXACT>(l1, l2);
 					if(k == 0) { lmin = lo; lmax = hi; }
-					else if(SHADOW) { lmin = Max<EXACT>(lo, lmin); lmax = Min<EXACT>(hi, lmax); }
-					else { lmin = Max<EXACT>(lmin, lo); lmax = Min<EXACT>(lmax, hi); }
+					else if(SHADOW) { lmin = Max<M_EXACT>(lo, lmin); lmax = Min<M_EXACT>(hi, lmax); }
+					else { lmin = Max<M_EXACT>(lmin, lo); lmax = Min<M_EXACT>(lmax, hi); }
 				}
-				bool pass = SHADOW ? (lmax >= 0.0f && lmin <= Min<EXACT>(lmax, Q.dist[l])) : !(lmax < 0.0f || lmin > Min<EXACT>(lmax, Q.dist[l]));
+				bool pass = SHADOW ? (lmax >= 0.0f && lmin <= Min<M_EXACT>(lmax, Q.dist[l])) : !(lmax < 0.0f || lmin > Min<M_EXACT>(lmax, Q.dist[l]));
 				anyPass |= pass;
+			}
+		} else {
+			// finite inputs: lane passes  <=>  lmax >= 0  &&  lmin <= lmax  &&  lmin <= dist   (both flavours)
+			float pn[3], pf[3]; // M_COH: near/far plane per axis (uniform); M_FAST: min/max plane
+			pn[0] = (M == M_COH && neg0) ? n.bmax[0] : n.bmin[0]; pf[0] = (M == M_COH && neg0) ? n.bmin[0] : n.bmax[0];
+			pn[1] = (M == M_COH && neg1) ? n.bmax[1] : n.bmin[1]; pf[1] = (M == M_COH && neg1) ? n.bmin[1] : n.bmax[1];
+			pn[2] = (M == M_COH && neg2) ? n.bmax[2] : n.bmin[2]; pf[2] = (M == M_COH && neg2) ? n.bmin[2] : n.bmax[2];
+			if(SHARED) {
+#pragma unroll
+				for(int k = 0; k < 3; k++) { pn[k] = pn[k] - org[k][0]; pf[k] = pf[k] - org[k][0]; }
+			}
+#pragma unroll
+			for(int l = 0; l < 4; l++) {
+				float lo[3], hi[3];
+#pragma unroll
+				for(int k = 0; k < 3; k++) {
+					const float a = Q.id[k][l] * (SHARED ? pn[k] : pn[k] - org[k][l]);
+					const float b = Q.id[k][l] * (SHARED ? pf[k] : pf[k] - org[k][l]);
+					if(M == M_COH) { lo[k] = a; hi[k] = b; }
+					else { lo[k] = vmin(a, b); hi[k] = vmax(a, b); }
+				}
+				const float lmin = vmax3(lo[0], lo[1], lo[2]), lmax = vmin3(hi[0], hi[1], hi[2]);
+				anyPass |= (lmax >= 0.0f) & (lmin <= lmax) & (lmin <= Q.dist[l]);
 			}
 		}
 		const u64 range = rangeMask(first, last);
@@ -340,7 +414,7 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 			const int fl = first | (last << 8);
 			// push = predicated move into lane `sp` (clang has no v_writelane builtin; a select is hazard-free)
 			const int far = child + (firstNode ^ 1);
-			if(sp < 64) { const bool me = lane == sp; stkNode = me ? far : stkNode; stkFL = me ? fl : stkFL; }
+			if(!DEEP || sp < 64) { const bool me = lane == sp; stkNode = me ? far : stkNode; stkFL = me ? fl : stkFL; }
 			else { const bool me = lane == sp - 64; stkNode2 = me ? far : stkNode2; stkFL2 = me ? fl : stkFL2; }
 			sp++;
 			cur = child + firstNode;
@@ -358,23 +432,18 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 			for(int base = 0; base < count; base += 64) {
 				const int chunk = count - base < 64 ? count - base : 64;
 				const bool mine = lane < chunk;
+				// lanes 0..chunk-1 each take one triangle: packet-level cull + shared-origin terms in parallel
 				const Tri t = loadTriVector(tris, firstTri + base + (mine ? lane : 0));
-				// shared-origin terms of Triangle::Collide (src/triangle.cpp:13-18 / :76-80), one triangle per lane
-				float tv[3] = {org[0][0] - t.a[0], org[1][0] - t.a[1], org[2][0] - t.a[2]};
-				float t0v[3] = {(t.ba[1] * tv[2] - t.ba[2] * tv[1]) * t.it0, (t.ba[2] * tv[0] - t.ba[0] * tv[2]) * t.it0,
-								(t.ba[0] * tv[1] - t.ba[1] * tv[0]) * t.it0};
-				float t1v[3] = {(tv[1] * t.ca[2] - tv[2] * t.ca[1]) * t.it0, (tv[2] * t.ca[0] - tv[0] * t.ca[2]) * t.it0,
-								(tv[0] * t.ca[1] - tv[1] * t.ca[0]) * t.it0};
-				float tmulV = -(tv[0] * t.n[0] + tv[1] * t.n[1] + tv[2] * t.n[2]);
-				u64 keep = __ballot(mine && triTestInterval(t, iv));
+				const TriTerms tt = triTerms(t, org[0][0], org[1][0], org[2][0]);
+				u64 keep = __ballot(mine & triTestInterval<M>(t, iv));
 
 				while(keep) {
 					const int k = __builtin_ctzll(keep);
 					keep &= keep - 1;
 					const float nx = readlanef(t.n[0], k), ny = readlanef(t.n[1], k), nz = readlanef(t.n[2], k);
-					const float ax = readlanef(t0v[0], k), ay = readlanef(t0v[1], k), az = readlanef(t0v[2], k);
-					const float bx = readlanef(t1v[0], k), by = readlanef(t1v[1], k), bz = readlanef(t1v[2], k);
-					const float tmul = readlanef(tmulV, k);
+					const float ax = readlanef(tt.t0v[0], k), ay = readlanef(tt.t0v[1], k), az = readlanef(tt.t0v[2], k);
+					const float bx = readlanef(tt.t1v[0], k), by = readlanef(tt.t1v[1], k), bz = readlanef(tt.t1v[2], k);
+					const float tmul = readlanef(tt.tmul, k);
 					const int idx = firstTri + base + k;
 					bool all4 = true;
 #pragma unroll
@@ -383,19 +452,22 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 						const float v = Q.d[0][l] * ax + Q.d[1][l] * ay + Q.d[2][l] * az;
 						const float u = Q.d[0][l] * bx + Q.d[1][l] * by + Q.d[2][l] * bz;
 						if(SHADOW) { // src/triangle.cpp:91-98
-							bool test = Min<true>(u, v) >= 0.0f && u + v <= det;
-							test = test && tmul > 0.0f && tmul < Q.dist[l] * det;
-							all4 = all4 && test;
+							bool test = (Min<M>(u, v) >= 0.0f) & (u + v <= det);
+							test = test & (tmul > 0.0f) & (tmul < Q.dist[l] * det);
+							all4 = all4 & test;
 							if(inRange && test) Q.dist[l] = -inf;
 						} else { // src/triangle.cpp:44-60
 							const float duv = det - u - v;
-							const float uvmin = Min<true>(u, Min<true>(v, duv)), uvmax = Max<true>(u, Max<true>(v, duv));
-							bool test = (uvmax <= 0.0f || uvmin >= 0.0f) && inRange;
-							if(MASK) test = test && ((mask4 >> l) & 1u);
+							const float uvmin = Min3<M>(u, v, duv), uvmax = Max3<M>(u, v, duv);
+							bool test = ((uvmax <= 0.0f) | (uvmin >= 0.0f)) & inRange;
+							if(MASK) test = test & (((mask4 >> l) & 1u) != 0);
 							if(test) {
 								const float idet = 1.0f / det;
 								const float dd = idet * tmul;
-								if(dd < Q.dist[l] && dd > 0.0f) { Q.dist[l] = dd; tid[l] = idx; bu[l] = u * idet; bv[l] = v * idet; }
+								if(dd < Q.dist[l] && dd > 0.0f) {
+									Q.dist[l] = dd; tid[l] = idx;
+									if(BARY) { bu[l] = u * idet; bv[l] = v * idet; }
+								}
 							}
 						}
 					}
@@ -420,19 +492,57 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 					const float v = (Q.d[0][l] * c0[0] + Q.d[1][l] * c0[1] + Q.d[2][l] * c0[2]) * t.it0;
 					const float u = (Q.d[0][l] * c1[0] + Q.d[1][l] * c1[1] + Q.d[2][l] * c1[2]) * t.it0;
 					const float duv = det - u - v;
-					const float uvmin = Min<true>(u, Min<true>(v, duv)), uvmax = Max<true>(u, Max<true>(v, duv));
-					bool test = (uvmax <= 0.0f || uvmin >= 0.0f) && inRange;
-					if(MASK) test = test && ((mask4 >> l) & 1u);
+					const float uvmin = Min3<M>(u, v, duv), uvmax = Max3<M>(u, v, duv);
+					bool test = ((uvmax <= 0.0f) | (uvmin >= 0.0f)) & inRange;
+					if(MASK) test = test & (((mask4 >> l) & 1u) != 0);
 					if(test) {
 						const float idet = 1.0f / det;
 						const float dd = idet * tmul;
-						if(dd < Q.dist[l] && dd > 0.0f) { Q.dist[l] = dd; tid[l] = firstTri + k; bu[l] = u * idet; bv[l] = v * idet; }
+						if(dd < Q.dist[l] && dd > 0.0f) {
+							Q.dist[l] = dd; tid[l] = firstTri + k;
+							if(BARY) { bu[l] = u * idet; bv[l] = v * idet; }
+						}
 					}
 				}
 				st.intersects += width;
 			}
 		}
 	}
+}
+
+// barycentrics of the final hits, derived after the walk (primary kernel): the same operations on the same
+// operands as src/triangle.cpp:13-18,26-28,55,60 -> the same bits as updating them on every accepted hit
+__device__ __forceinline__ void finalBarycentrics(const uint4 *__restrict__ tris, const float (&org)[3][4], const Quad &Q, const int (&tid)[4],
+												  float (&bu)[4], float (&bv)[4]) {
+#pragma unroll
+	for(int l = 0; l < 4; l++) {
+		bu[l] = 0.0f; bv[l] = 0.0f;
+		if(Q.dist[l] < __builtin_inff()) {
+			const Tri t = loadTriVector(tris, tid[l]);
+			const TriTerms tt = triTerms(t, org[0][0], org[1][0], org[2][0]);
+			const float det = Q.d[0][l] * t.n[0] + Q.d[1][l] * t.n[1] + Q.d[2][l] * t.n[2];
+			const float v = Q.d[0][l] * tt.t0v[0] + Q.d[1][l] * tt.t0v[1] + Q.d[2][l] * tt.t0v[2];
+			const float u = Q.d[0][l] * tt.t1v[0] + Q.d[1][l] * tt.t1v[1] + Q.d[2][l] * tt.t1v[2];
+			const float idet = 1.0f / det;
+			bu[l] = u * idet; bv[l] = v * idet;
+		}
+	}
+}
+
+// packet classification (wave-uniform): M_EXACT unless everything is finite; M_COH if additionally every
+// ray of the packet (lanes < size) has the same idir sign on each axis
+__device__ __forceinline__ int classify(bool fastOK, bool laneFinite, bool live, const float (&id)[3][4]) {
+	if(!(fastOK && __all(laneFinite || !live))) return M_EXACT;
+	bool coh = true;
+#pragma unroll
+	for(int k = 0; k < 3; k++) {
+		bool anyNeg = false, anyPos = false;
+#pragma unroll
+		for(int l = 0; l < 4; l++) { anyNeg |= id[k][l] < 0.0f; anyPos |= !(id[k][l] < 0.0f); }
+		const bool n = __any(anyNeg && live), p = __any(anyPos && live);
+		coh = coh && !(n && p);
+	}
+	return coh ? M_COH : M_FAST;
 }
 
 __device__ __forceinline__ bool finite4(const float (&v)[3][4]) {
@@ -484,6 +594,7 @@ __device__ __forceinline__ int xcdRemap(int b, int n) {
 	return start + i;
 }
 
+template <bool DEEP>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_primary(PrimaryArgs A) {
 	__shared__ float ldsAll[WAVES_PER_BLOCK][LDS_FLOATS_PER_WAVE];
 	const int lane = threadIdx.x & 63;
@@ -535,9 +646,11 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_primary(PrimaryArgs A)
 		for(int l = 0; l < 4; l++) org[c][l] = A.g.org[c];
 
 	Counters st = {0, 0, 0};
-	const bool fast = A.fastOK && __all(finite4(Q.id) && finite4(Q.d));
-	if(fast) walk<true, false, false, false>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
-	else walk<true, false, false, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
+	const int mode = classify(A.fastOK != 0, finite4(Q.id) && finite4(Q.d), true, Q.id);
+	if(mode == M_COH) walk<true, false, false, M_COH, false, DEEP>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
+	else if(mode == M_FAST) walk<true, false, false, M_FAST, false, DEEP>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
+	else walk<true, false, false, M_EXACT, false, DEEP>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
+	finalBarycentrics(A.tris, org, Q, tid, bu, bv);
 
 	flushStats(A.stats, st, 256u, lane);
 
@@ -626,9 +739,10 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_rays(RaysArgs A) {
 	bool fin = finite4(Q.id) && finite4(Q.d) && finite4(org);
 #pragma unroll
 	for(int l = 0; l < 4; l++) fin = fin && !(Q.dist[l] != Q.dist[l]);
-	const bool fast = A.fastOK && __all(fin || !live);
-	if(fast) walk<SHARED, MASK, false, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, ldsAll[wave], st);
-	else walk<SHARED, MASK, false, true>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, ldsAll[wave], st);
+	const int mode = classify(A.fastOK != 0, fin, live, Q.id);
+	if(mode == M_COH) walk<SHARED, MASK, false, M_COH, true, true>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, ldsAll[wave], st);
+	else if(mode == M_FAST) walk<SHARED, MASK, false, M_FAST, true, true>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, ldsAll[wave], st);
+	else walk<SHARED, MASK, false, M_EXACT, true, true>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, ldsAll[wave], st);
 	flushStats(A.stats, st, 0u, lane);
 
 	if(live) {
@@ -669,9 +783,10 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_shadow(RaysArgs A) {
 	bool fin = finite4(Q.id) && finite4(Q.d) && finite4(org);
 #pragma unroll
 	for(int l = 0; l < 4; l++) fin = fin && !(Q.dist[l] != Q.dist[l]);
-	const bool fast = A.fastOK && __all(fin || !live);
-	if(fast) walk<true, false, true, false>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
-	else walk<true, false, true, true>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
+	const int mode = classify(A.fastOK != 0, fin, live, Q.id);
+	if(mode == M_COH) walk<true, false, true, M_COH, false, true>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
+	else if(mode == M_FAST) walk<true, false, true, M_FAST, false, true>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
+	else walk<true, false, true, M_EXACT, false, true>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
 	flushStats(A.stats, st, 0u, lane);
 	if(live) *(float4 *)(A.distance + q * 4) = make_float4(Q.dist[0], Q.dist[1], Q.dist[2], Q.dist[3]);
 }
@@ -739,11 +854,11 @@ __global__ __launch_bounds__(256) void k_account(AccountArgs A) {
 				float lmin = 0.0f, lmax = 0.0f;
 				for(int k = 0; k < 3; k++) {
 					float l1 = id[k] * (bmin[k] - A.g.org[k]), l2 = id[k] * (bmax[k] - A.g.org[k]);
-					float lo = Min<true>(l1, l2), hi = Max<true>(l1, l2);
+					float lo = Min<M_EXACT>(l1, l2), hi = Max<M_EXACT>(l1, l2);
 					if(k == 0) { lmin = lo; lmax = hi; }
-					else { lmin = Max<true>(lmin, lo); lmax = Min<true>(lmax, hi); }
+					else { lmin = Max<M_EXACT>(lmin, lo); lmax = Min<M_EXACT>(lmax, hi); }
 				}
-				if(lmax < 0.0f || lmin > Min<true>(lmax, dist)) break;
+				if(lmax < 0.0f || lmin > Min<M_EXACT>(lmax, dist)) break;
 				if(b.z & 0x80000000u) {
 					const int count = (int)b.w, firstTri = (int)(b.z & 0x7fffffffu);
 					for(int k = 0; k < count; k++) {
@@ -759,7 +874,7 @@ __global__ __launch_bounds__(256) void k_account(AccountArgs A) {
 						const float v = d[0] * t0v[0] + d[1] * t0v[1] + d[2] * t0v[2];
 						const float u = d[0] * t1v[0] + d[1] * t1v[1] + d[2] * t1v[2];
 						const float duv = det - u - v;
-						const float uvmin = Min<true>(u, Min<true>(v, duv)), uvmax = Max<true>(u, Max<true>(v, duv));
+						const float uvmin = Min<M_EXACT>(u, Min<M_EXACT>(v, duv)), uvmax = Max<M_EXACT>(u, Max<M_EXACT>(v, duv));
 						if(!(uvmax <= 0.0f || uvmin >= 0.0f)) continue;
 						const float t2 = (1.0f / det) * tmul;
 						if(t2 < dist && t2 > 0.0f) dist = t2;
@@ -869,7 +984,8 @@ int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0
 	}
 	A.nBlocks = blocks;
 	s->lastBlocks = blocks; s->lastThreads = WAVES_PER_BLOCK * 64;
-	hipLaunchKernelGGL(dev::k_primary, dim3(blocks), dim3(WAVES_PER_BLOCK * 64), 0, stream, A);
+	if(s->depth > 62) hipLaunchKernelGGL(dev::k_primary<true>, dim3(blocks), dim3(WAVES_PER_BLOCK * 64), 0, stream, A);
+	else hipLaunchKernelGGL(dev::k_primary<false>, dim3(blocks), dim3(WAVES_PER_BLOCK * 64), 0, stream, A);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
@@ -910,8 +1026,10 @@ SnailScene *snail_scene_create(const void *nodes32, int nNodes, const void *tris
 		for(int k = 12; k < 16; k++) if(!(std::fabs(r[k]) <= 1.0e18f)) fastOK = 0;     // plane
 	}
 	const float *nf = (const float *)nodes32;
-	for(int i = 0; i < nNodes && fastOK; i++)
+	for(int i = 0; i < nNodes && fastOK; i++) {
 		for(int k = 0; k < 6; k++) if(!(std::fabs(nf[(size_t)i * 8 + k]) <= 1.0e9f)) fastOK = 0;
+		for(int k = 0; k < 3; k++) if(!(nf[(size_t)i * 8 + k] <= nf[(size_t)i * 8 + 3 + k])) fastOK = 0;   // M_COH needs min <= max
+	}
 
 	DeviceGuard guard(device);
 	if(!guard.ok) { snail_set_error("snail_scene_create: hipSetDevice(%d) failed", device); return nullptr; }
