@@ -110,6 +110,11 @@ int snail_trace_shadow_dev(SnailScene *, int nPackets, int size, const float *d_
  * B_alg(ray) = 32*V_n + 64*V_t + 16. */
 int snail_account_primary(SnailScene *, const float cam[13], int resx, int resy, int x0, int y0, int w, int h, uint64_t out[4]);
 
+/* Diagnostic: per-packet cost of one full-frame primary launch, row-major over the packet grid:
+ * out4[p*4 + {0,1,2,3}] = {loop iterations, quad x triangle tests, shader-clock cycles of that wavefront,
+ * start time >> 6}.  For load-balance studies (tools/packet_costs.py); not on any product path. */
+int snail_debug_packet_costs(SnailScene *, const float cam[13], int resx, int resy, uint32_t *out4);
+
 /* Launch geometry of the last primary launch on this scene (for profiles): waves, blocks, VGPR-independent. */
 int snail_last_launch(const SnailScene *, int *blocks, int *threadsPerBlock);
 

@@ -36,6 +36,7 @@ SIGNATURES = {
     "snail_trace_shadow": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "snail_trace_shadow_dev": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "snail_account_primary": (_I, [_VP, _F13, _I, _I, _I, _I, _I, _I, _VP]),
+    "snail_debug_packet_costs": (_I, [_VP, _F13, _I, _I, _VP]),
     "snail_last_launch": (_I, [_VP, _VP, _VP]),
 }
 

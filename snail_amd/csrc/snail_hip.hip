@@ -115,7 +115,7 @@ __device__ __forceinline__ Tri loadTriScalar(const uint4 *tris, int idx) { // wa
 //   M_FAST : every input finite => no NaN can arise, Min/Max == v_min_f32/v_max_f32 up to the sign of zero
 //            (never observed by a comparison); BBox::TestInterval is implied by the per-lane test
 //            (monotonic rounding) and skipped.
-//   M_COH  : M_FAST + every ray of the packet has the same idir sign per axis, so min(l1,l2)/max(l1,l2)
+//   M_COH  : M_FAST + every ray of the packet has the same idir sign bit per axis, so min(l1,l2)/max(l1,l2)
 //            of a slab are known without comparing: near/far planes are picked once per node (scalar).
 enum { M_EXACT = 0, M_FAST = 1, M_COH = 2 };
 
@@ -144,19 +144,33 @@ template <int M> __device__ __forceinline__ float Max3(float a, float b, float c
 	return vmax3(a, b, c);
 }
 
+// two stack words into lane `laneSel`: the lane select goes through M0 (gfx9 allows one SGPR on the constant
+// bus, so value and select cannot both be ordinary SGPRs)
+__device__ __forceinline__ void writeLane2(int &vregA, int valueA, int &vregB, int valueB, int laneSel) {
+	asm volatile("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+				 : "+v"(vregA), "+v"(vregB) : "s"(valueA), "s"(valueB), "s"(laneSel) : "m0");
+}
 __device__ __forceinline__ float readlanef(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 __device__ __forceinline__ float firstlanef(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
-__device__ __forceinline__ float waveMin(float v) {
-#pragma unroll
-	for(int o = 32; o > 0; o >>= 1) v = vmin(v, __shfl_xor(v, o));
-	return v;
+// wave64 min/max reductions on the VALU with DPP (no LDS round trips): row_shr 1,2,4,8 inside each row of 16,
+// then row_bcast:15 / row_bcast:31 across rows; the full result lands in lane 63.  Inputs are finite (FAST paths).
+template <bool MAX, int CTRL, int ROWMASK> __device__ __forceinline__ float dppStep(float v, float ident) {
+	const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ident), __float_as_int(v), CTRL, ROWMASK, 0xf, false));
+	return MAX ? vmax(v, o) : vmin(v, o);
 }
-__device__ __forceinline__ float waveMax(float v) {
-#pragma unroll
-	for(int o = 32; o > 0; o >>= 1) v = vmax(v, __shfl_xor(v, o));
-	return v;
+template <bool MAX> __device__ __forceinline__ float waveReduce(float v) {
+	const float ident = MAX ? -__builtin_inff() : __builtin_inff();
+	v = dppStep<MAX, 0x111, 0xf>(v, ident); // row_shr:1
+	v = dppStep<MAX, 0x112, 0xf>(v, ident); // row_shr:2
+	v = dppStep<MAX, 0x114, 0xf>(v, ident); // row_shr:4
+	v = dppStep<MAX, 0x118, 0xf>(v, ident); // row_shr:8
+	v = dppStep<MAX, 0x142, 0xa>(v, ident); // row_bcast:15 -> rows 1,3
+	v = dppStep<MAX, 0x143, 0xc>(v, ident); // row_bcast:31 -> rows 2,3
+	return readlanef(v, 63);
 }
+__device__ __forceinline__ float waveMin(float v) { return waveReduce<false>(v); }
+__device__ __forceinline__ float waveMax(float v) { return waveReduce<true>(v); }
 
 __device__ __forceinline__ u64 rangeMask(int first, int last) { return ((2ull << last) - 1ull) & ~((1ull << first) - 1ull); }
 
@@ -299,13 +313,38 @@ __device__ __forceinline__ TriTerms triTerms(const Tri &t, float ox, float oy, f
 	return r;
 }
 
+// M_COH slab test for one sign octant OCT (bit k set = idir negative on axis k): the near plane of axis k is
+// bmax when the rays travel in -k, else bmin -- resolved at compile time, so no select is executed.
+template <bool SHARED, int OCT>
+__device__ __forceinline__ void slabsCoherent(const Node &n, const float (&org)[3][4], const Quad &Q, float (&tn)[4], float (&tf)[4]) {
+	float pn[3], pf[3];
+#pragma unroll
+	for(int k = 0; k < 3; k++) {
+		const float nr = ((OCT >> k) & 1) ? n.bmax[k] : n.bmin[k], fr = ((OCT >> k) & 1) ? n.bmin[k] : n.bmax[k];
+		pn[k] = SHARED ? nr - org[k][0] : nr;
+		pf[k] = SHARED ? fr - org[k][0] : fr;
+	}
+#pragma unroll
+	for(int l = 0; l < 4; l++) {
+		float lo[3], hi[3];
+#pragma unroll
+		for(int k = 0; k < 3; k++) {
+			lo[k] = Q.id[k][l] * (SHARED ? pn[k] : pn[k] - org[k][l]);
+			hi[k] = Q.id[k][l] * (SHARED ? pf[k] : pf[k] - org[k][l]);
+		}
+		tn[l] = vmax3(lo[0], lo[1], lo[2]);
+		tf[l] = vmin3(hi[0], hi[1], hi[2]);
+	}
+}
+
 // ---- the packet walk -------------------------------------------------------------------------------
 // SHARED : one origin per packet (primary / shadow)   MASK : per-lane 4-bit masks (secondary rays)
 // SHADOW : any-hit TraverseShadow                      M    : arithmetic mode (above)
 // BARY   : keep barycentrics up to date in registers (else the caller derives them from the final triId)
 // DEEP   : scene depth > 62, stack slots >= 64 live in a second VGPR pair
+// DISTPOS: every lane's distance is >= 0 on entry (primary packets) -> single-compare slab test
 // Stack: lane i of (stkNode, stkFL) is slot i.
-template <bool SHARED, bool MASK, bool SHADOW, int M, bool BARY, bool DEEP>
+template <bool SHARED, bool MASK, bool SHADOW, int M, bool BARY, bool DEEP, bool DISTPOS>
 __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint4 *__restrict__ tris, int size, int lane,
 									 const float (&org)[3][4] /* SHARED: [c][0] uniform */, Quad &Q, unsigned mask4, int (&tid)[4],
 									 float (&bu)[4], float (&bv)[4], float *lds, Counters &st) {
@@ -329,99 +368,111 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 	}
 
 	// child order from lane 0 of quad 0 (src/bvh/traverse.cpp:21)
-	const int sign0 = firstlanef(Q.d[0][0]) < 0.0f, sign1 = firstlanef(Q.d[1][0]) < 0.0f, sign2 = firstlanef(Q.d[2][0]) < 0.0f;
+	const int signBits = __builtin_amdgcn_readfirstlane((Q.d[0][0] < 0.0f ? 1 : 0) | (Q.d[1][0] < 0.0f ? 2 : 0) | (Q.d[2][0] < 0.0f ? 4 : 0));
 	// M_COH: the (packet-uniform) sign of idir per axis picks the near/far slab plane
-	const bool neg0 = firstlanef(Q.id[0][0]) < 0.0f, neg1 = firstlanef(Q.id[1][0]) < 0.0f, neg2 = firstlanef(Q.id[2][0]) < 0.0f;
+	// (sign BIT, so that the selects stay on the scalar unit; -0 behaves like any negative: both slab products are 0)
+	const int octant = __builtin_amdgcn_readfirstlane(((__float_as_int(Q.id[0][0]) >> 31) & 1) | ((__float_as_int(Q.id[1][0]) >> 31) & 2) |
+													  ((__float_as_int(Q.id[2][0]) >> 31) & 4));
 
 	int stkNode = 0, stkFL = 0, stkNode2 = 0, stkFL2 = 0;
 	int sp = 0;
-	int cur = 0, first = 0, last = size - 1;
-	bool haveCur = true;
+	int first = 0, last = size - 1;
+	Node n = loadNode(nodes, 0);
 
 	for(;;) {
-		if(!haveCur) {
-			if(sp == 0) break;
-			sp--;
-			int fl;
-			if(!DEEP || sp < 64) { cur = __builtin_amdgcn_readlane(stkNode, sp); fl = __builtin_amdgcn_readlane(stkFL, sp); }
-			else { cur = __builtin_amdgcn_readlane(stkNode2, sp - 64); fl = __builtin_amdgcn_readlane(stkFL2, sp - 64); }
-			first = fl & 0xff; last = fl >> 8;
-		}
-		haveCur = false;
 		st.iters++;
-		const Node n = loadNode(nodes, cur);
 		const bool isLeaf = (n.sub & 0x80000000u) != 0;
+		// children are adjacent (src/bvh/tree.cpp:153-157); near = firstNode ^ sign[axis] (src/bvh/traverse.cpp:71-74).
+		// The near child's record is fetched NOW (one scalar load, in flight during the box test) and simply
+		// dropped if this node is culled or is a leaf (then index 0, the root: always valid, always cached).
+		const int axis = n.aux & 0xffff;
+		const int firstNode = ((n.aux >> 16) ^ (signBits >> axis)) & 1;
+		const int nearIdx = isLeaf ? 0 : (int)n.sub + firstNode;
+		const int farIdx = (int)n.sub + (firstNode ^ 1);
+		const Node nn = loadNode(nodes, nearIdx);
+		__builtin_amdgcn_sched_barrier(0); // keep the fetch ahead of the slab arithmetic it overlaps with
 
-		if(EXACT && !boxTestInterval(n, iv)) continue;
-
-		// ---- BBox::Test (src/bounding_box.cpp:61-142 / :144-200) ----
+		// ---- BBox::TestInterval + BBox::Test (src/bounding_box.cpp:208-236, :61-142 / :144-200) ----
 		bool anyPass = false;
 		if(EXACT) {
-			float tmn[3], tmx[3];
-			if(SHARED) {
+			if(boxTestInterval(n, iv)) {
+				float tmn[3], tmx[3];
+				if(SHARED) {
 #pragma unroll
-				for(int k = 0; k < 3; k++) { tmn[k] = n.bmin[k] - org[k][0]; tmx[k] = n.bmax[k] - org[k][0]; }
-			}
-#pragma unroll
-			for(int l = 0; l < 4; l++) {
-				float lmin = 0.0f, lmax = 0.0f;
-#pragma unroll
-				for(int k = 0; k < 3; k++) {
-					float l1 = Q.id[k][l] * (SHARED ? tmn[k] : n.bmin[k] - org[k][l]);
-					float l2 = Q.id[k][l] * (SHARED ? tmx[k] : n.bmax[k] - org[k][l]);
-					float lo = Min<M_EXACT>(l1, l2), hi = Max<M_EXACT>(l1, l2);
-					if(k == 0) { lmin = lo; lmax = hi; }
-					else if(SHADOW) { lmin = Max<M_EXACT>(lo, lmin); lmax = Min<M_EXACT>(hi, lmax); }
-					else { lmin = Max<M_EXACT>(lmin, lo); lmax = Min<M_EXACT>(lmax, hi); }
+					for(int k = 0; k < 3; k++) { tmn[k] = n.bmin[k] - org[k][0]; tmx[k] = n.bmax[k] - org[k][0]; }
 				}
-				bool pass = SHADOW ? (lmax >= 0.0f && lmin <= Min<M_EXACT>(lmax, Q.dist[l])) : !(lmax < 0.0f || lmin > Min<M_EXACT>(lmax, Q.dist[l]));
-				anyPass |= pass;
+#pragma unroll
+				for(int l = 0; l < 4; l++) {
+					float lmin = 0.0f, lmax = 0.0f;
+#pragma unroll
+					for(int k = 0; k < 3; k++) {
+						float l1 = Q.id[k][l] * (SHARED ? tmn[k] : n.bmin[k] - org[k][l]);
+						float l2 = Q.id[k][l] * (SHARED ? tmx[k] : n.bmax[k] - org[k][l]);
+						float lo = Min<M_EXACT>(l1, l2), hi = Max<M_EXACT>(l1, l2);
+						if(k == 0) { lmin = lo; lmax = hi; }
+						else if(SHADOW) { lmin = Max<M_EXACT>(lo, lmin); lmax = Min<M_EXACT>(hi, lmax); }
+						else { lmin = Max<M_EXACT>(lmin, lo); lmax = Min<M_EXACT>(lmax, hi); }
+					}
+					bool pass = SHADOW ? (lmax >= 0.0f && lmin <= Min<M_EXACT>(lmax, Q.dist[l])) : !(lmax < 0.0f || lmin > Min<M_EXACT>(lmax, Q.dist[l]));
+					anyPass |= pass;
+				}
 			}
 		} else {
 			// finite inputs: lane passes  <=>  lmax >= 0  &&  lmin <= lmax  &&  lmin <= dist   (both flavours)
-			float pn[3], pf[3]; // M_COH: near/far plane per axis (uniform); M_FAST: min/max plane
-			pn[0] = (M == M_COH && neg0) ? n.bmax[0] : n.bmin[0]; pf[0] = (M == M_COH && neg0) ? n.bmin[0] : n.bmax[0];
-			pn[1] = (M == M_COH && neg1) ? n.bmax[1] : n.bmin[1]; pf[1] = (M == M_COH && neg1) ? n.bmin[1] : n.bmax[1];
-			pn[2] = (M == M_COH && neg2) ? n.bmax[2] : n.bmin[2]; pf[2] = (M == M_COH && neg2) ? n.bmin[2] : n.bmax[2];
-			if(SHARED) {
-#pragma unroll
-				for(int k = 0; k < 3; k++) { pn[k] = pn[k] - org[k][0]; pf[k] = pf[k] - org[k][0]; }
-			}
-#pragma unroll
-			for(int l = 0; l < 4; l++) {
-				float lo[3], hi[3];
-#pragma unroll
-				for(int k = 0; k < 3; k++) {
-					const float a = Q.id[k][l] * (SHARED ? pn[k] : pn[k] - org[k][l]);
-					const float b = Q.id[k][l] * (SHARED ? pf[k] : pf[k] - org[k][l]);
-					if(M == M_COH) { lo[k] = a; hi[k] = b; }
-					else { lo[k] = vmin(a, b); hi[k] = vmax(a, b); }
+			float tn[4], tf[4];
+			if(M == M_COH) {
+				// eight specialisations (one per sign octant of the packet): near/far planes are compile-time picks
+				switch(octant) {
+				case 0: slabsCoherent<SHARED, 0>(n, org, Q, tn, tf); break;
+				case 1: slabsCoherent<SHARED, 1>(n, org, Q, tn, tf); break;
+				case 2: slabsCoherent<SHARED, 2>(n, org, Q, tn, tf); break;
+				case 3: slabsCoherent<SHARED, 3>(n, org, Q, tn, tf); break;
+				case 4: slabsCoherent<SHARED, 4>(n, org, Q, tn, tf); break;
+				case 5: slabsCoherent<SHARED, 5>(n, org, Q, tn, tf); break;
+				case 6: slabsCoherent<SHARED, 6>(n, org, Q, tn, tf); break;
+				default: slabsCoherent<SHARED, 7>(n, org, Q, tn, tf); break;
 				}
-				const float lmin = vmax3(lo[0], lo[1], lo[2]), lmax = vmin3(hi[0], hi[1], hi[2]);
-				anyPass |= (lmax >= 0.0f) & (lmin <= lmax) & (lmin <= Q.dist[l]);
+			} else {
+				float pn[3], pf[3];
+#pragma unroll
+				for(int k = 0; k < 3; k++) { pn[k] = SHARED ? n.bmin[k] - org[k][0] : n.bmin[k]; pf[k] = SHARED ? n.bmax[k] - org[k][0] : n.bmax[k]; }
+#pragma unroll
+				for(int l = 0; l < 4; l++) {
+					float lo[3], hi[3];
+#pragma unroll
+					for(int k = 0; k < 3; k++) {
+						const float a = Q.id[k][l] * (SHARED ? pn[k] : pn[k] - org[k][l]);
+						const float b = Q.id[k][l] * (SHARED ? pf[k] : pf[k] - org[k][l]);
+						lo[k] = vmin(a, b); hi[k] = vmax(a, b);
+					}
+					tn[l] = vmax3(lo[0], lo[1], lo[2]);
+					tf[l] = vmin3(hi[0], hi[1], hi[2]);
+				}
+			}
+			// all compares last: one VALU->SALU hand-over per node instead of twelve
+			if(DISTPOS) { // dist >= 0 on every lane (primary packets): lmax>=0 && lmin<=lmax && lmin<=dist  <=>  max(lmin,0) <= min(lmax,dist)
+#pragma unroll
+				for(int l = 0; l < 4; l++) { tn[l] = vmax(tn[l], 0.0f); tf[l] = vmin(tf[l], Q.dist[l]); }
+				anyPass = (tn[0] <= tf[0]) | (tn[1] <= tf[1]) | (tn[2] <= tf[2]) | (tn[3] <= tf[3]);
+			} else {
+#pragma unroll
+				for(int l = 0; l < 4; l++) anyPass |= (tf[l] >= 0.0f) & (tn[l] <= tf[l]) & (tn[l] <= Q.dist[l]);
 			}
 		}
-		const u64 range = rangeMask(first, last);
-		const u64 alive = __ballot(anyPass) & range;
-		if(alive == 0) continue;
-		first = __builtin_ctzll(alive);
-		last = 63 - __builtin_clzll(alive);
-
-		if(!isLeaf) {
-			const int child = (int)n.sub, axis = n.aux & 0xffff;
-			const int sgn = axis == 0 ? sign0 : axis == 1 ? sign1 : sign2;
-			const int firstNode = ((n.aux >> 16) & 0xffff) ^ sgn;
-			const int fl = first | (last << 8);
-			// push = predicated move into lane `sp` (clang has no v_writelane builtin; a select is hazard-free)
-			const int far = child + (firstNode ^ 1);
-			if(!DEEP || sp < 64) { const bool me = lane == sp; stkNode = me ? far : stkNode; stkFL = me ? fl : stkFL; }
-			else { const bool me = lane == sp - 64; stkNode2 = me ? far : stkNode2; stkFL2 = me ? fl : stkFL2; }
-			sp++;
-			cur = child + firstNode;
-			haveCur = true;
-			continue;
-		}
-
+		const u64 alive = __builtin_amdgcn_ballot_w64(anyPass) & rangeMask(first, last);
+		if(alive != 0) {
+			first = __builtin_ctzll(alive);
+			last = 63 - __builtin_clzll(alive);
+			if(!isLeaf) {
+				const int fl = first | (last << 8);
+				// push: v_writelane_b32 (no clang builtin).  Both the value and the lane select are SALU-produced SGPRs,
+				// so none of the VALU->v_writelane hazards of the ISA applies.
+				if(!DEEP || sp < 64) writeLane2(stkNode, farIdx, stkFL, fl, sp);
+				else writeLane2(stkNode2, farIdx, stkFL2, fl, sp - 64);
+				sp++;
+				n = nn;
+				continue;
+			}
 		// ---- leaf (src/bvh/traverse.cpp:34-56 / :98-124) ----
 		const int count = n.aux, firstTri = (int)(n.sub & 0x7fffffffu);
 		const bool inRange = lane >= first && lane <= last;
@@ -507,6 +558,15 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				st.intersects += width;
 			}
 		}
+		} // alive != 0
+		// ---- pop (src/bvh/traverse.cpp:26-30) ----
+		if(sp == 0) break;
+		sp--;
+		int cur, fl;
+		if(!DEEP || sp < 64) { cur = __builtin_amdgcn_readlane(stkNode, sp); fl = __builtin_amdgcn_readlane(stkFL, sp); }
+		else { cur = __builtin_amdgcn_readlane(stkNode2, sp - 64); fl = __builtin_amdgcn_readlane(stkFL2, sp - 64); }
+		first = fl & 0xff; last = fl >> 8;
+		n = loadNode(nodes, cur);
 	}
 }
 
@@ -538,7 +598,7 @@ __device__ __forceinline__ int classify(bool fastOK, bool laneFinite, bool live,
 	for(int k = 0; k < 3; k++) {
 		bool anyNeg = false, anyPos = false;
 #pragma unroll
-		for(int l = 0; l < 4; l++) { anyNeg |= id[k][l] < 0.0f; anyPos |= !(id[k][l] < 0.0f); }
+		for(int l = 0; l < 4; l++) { anyNeg |= __float_as_int(id[k][l]) < 0; anyPos |= __float_as_int(id[k][l]) >= 0; }
 		const bool n = __any(anyNeg && live), p = __any(anyPos && live);
 		coh = coh && !(n && p);
 	}
@@ -579,46 +639,49 @@ struct PrimaryArgs {
 	float *t, *u, *v;
 	int *id;
 	u64 *stats;
+	unsigned *cost; // diagnostic: per packet {iters, intersects, shader cycles, start time low bits}
 };
 
 #define WAVES_PER_BLOCK 4
 #define LDS_FLOATS_PER_WAVE (64 * 12 + 64)
 
-// XCD-aware block remap: blocks are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2), so
-// give every XCD a contiguous band of the packet grid; neighbouring packets walk the same BVH subtrees.
-__device__ __forceinline__ int xcdRemap(int b, int n) {
-	const int nx = 8;
-	int q = n / nx, r = n % nx, x = b % nx, i = b / nx;
-	// XCD x owns q (+1 if x < r) consecutive logical blocks
-	int start = x * q + (x < r ? x : r);
-	return start + i;
+// Block -> packet mapping of the primary kernel.  ONE WAVE PER BLOCK: packet costs vary ~10x (p5 66 K .. max
+// 570 K cycles on the atrium frame), and a multi-wave block holds all its slots until its slowest wave ends.
+// Blocks are dealt round-robin over the 8 XCDs (each with a private L2): XCD x receives blocks x, x+8, ...
+// Give each XCD whole 4x4-packet REGIONS (64x64 px; its 16 consecutive blocks), regions interleaved over the
+// image: neighbouring packets (same BVH subtrees) share an L2, and every XCD samples the whole frame, so a
+// heavy image band does not land on one XCD.
+__device__ __forceinline__ int interleave16(int b) { // -> logical index; 16 consecutive logical indices per XCD turn
+	const int xcd = b & 7, j = b >> 3;
+	return (((j >> 4) << 3) + xcd) * 16 + (j & 15);
 }
 
 template <bool DEEP>
-__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_primary(PrimaryArgs A) {
-	__shared__ float ldsAll[WAVES_PER_BLOCK][LDS_FLOATS_PER_WAVE];
+__global__ __launch_bounds__(64) void k_primary(PrimaryArgs A) {
+	__shared__ float ldsAll[1][LDS_FLOATS_PER_WAVE];
 	const int lane = threadIdx.x & 63;
-	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	const int blk = xcdRemap((int)blockIdx.x, A.nBlocks);
+	const int wave = 0;
+	const int li = interleave16((int)blockIdx.x);
 
 	int px, py, pidx;
 	if(A.packetXY) {
-		pidx = blk * WAVES_PER_BLOCK + wave;
+		pidx = li;
 		if(pidx >= A.nPackets) return;
 		int2 xy = A.packetXY[pidx];
 		px = __builtin_amdgcn_readfirstlane(xy.x);
 		py = __builtin_amdgcn_readfirstlane(xy.y);
 	} else {
-		// a block covers a 2x2 group of packets (32x32 px)
-		const int nbx = (A.pw + 1) >> 1;
-		const int bx = blk % nbx, by = blk / nbx;
-		const int cx = bx * 2 + (wave & 1), cy = by * 2 + (wave >> 1);
+		const int nrx = (A.pw + 3) >> 2;
+		const int region = li >> 4, k = li & 15;
+		const int rx = region % nrx, ry = region / nrx;
+		const int cx = rx * 4 + (k & 3), cy = ry * 4 + (k >> 2);
 		if(cx >= A.pw || cy >= A.ph) return;
 		px = A.x0 + cx * 16;
 		py = A.y0 + cy * 16;
 		pidx = cy * A.pw + cx;
 	}
 
+	const u64 tStart = A.cost ? __builtin_amdgcn_s_memtime() : 0;
 	// ---- RayGenerator::Generate, level 3 (src/ray_generator.cpp:23-47): quad ty*4+k, lane j -> pixel (x+4k+j, y+ty)
 	Quad Q;
 	const int ty = lane >> 2, k4 = lane & 3;
@@ -647,12 +710,17 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_primary(PrimaryArgs A)
 
 	Counters st = {0, 0, 0};
 	const int mode = classify(A.fastOK != 0, finite4(Q.id) && finite4(Q.d), true, Q.id);
-	if(mode == M_COH) walk<true, false, false, M_COH, false, DEEP>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
-	else if(mode == M_FAST) walk<true, false, false, M_FAST, false, DEEP>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
-	else walk<true, false, false, M_EXACT, false, DEEP>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
+	if(mode == M_COH) walk<true, false, false, M_COH, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
+	else if(mode == M_FAST) walk<true, false, false, M_FAST, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
+	else walk<true, false, false, M_EXACT, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
 	finalBarycentrics(A.tris, org, Q, tid, bu, bv);
 
 	flushStats(A.stats, st, 256u, lane);
+	if(A.cost && lane == 0) {
+		const u64 tEnd = __builtin_amdgcn_s_memtime();
+		A.cost[(size_t)pidx * 4 + 0] = st.iters; A.cost[(size_t)pidx * 4 + 1] = st.intersects;
+		A.cost[(size_t)pidx * 4 + 2] = (unsigned)(tEnd - tStart); A.cost[(size_t)pidx * 4 + 3] = (unsigned)(tStart >> 6);
+	}
 
 	if(A.packetXY) { // packet-major (Context layout)
 		const size_t o = (size_t)pidx * 256 + (size_t)lane * 4;
@@ -740,9 +808,9 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_rays(RaysArgs A) {
 #pragma unroll
 	for(int l = 0; l < 4; l++) fin = fin && !(Q.dist[l] != Q.dist[l]);
 	const int mode = classify(A.fastOK != 0, fin, live, Q.id);
-	if(mode == M_COH) walk<SHARED, MASK, false, M_COH, true, true>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, ldsAll[wave], st);
-	else if(mode == M_FAST) walk<SHARED, MASK, false, M_FAST, true, true>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, ldsAll[wave], st);
-	else walk<SHARED, MASK, false, M_EXACT, true, true>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, ldsAll[wave], st);
+	if(mode == M_COH) walk<SHARED, MASK, false, M_COH, true, true, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, ldsAll[wave], st);
+	else if(mode == M_FAST) walk<SHARED, MASK, false, M_FAST, true, true, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, ldsAll[wave], st);
+	else walk<SHARED, MASK, false, M_EXACT, true, true, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, ldsAll[wave], st);
 	flushStats(A.stats, st, 0u, lane);
 
 	if(live) {
@@ -784,9 +852,9 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_shadow(RaysArgs A) {
 #pragma unroll
 	for(int l = 0; l < 4; l++) fin = fin && !(Q.dist[l] != Q.dist[l]);
 	const int mode = classify(A.fastOK != 0, fin, live, Q.id);
-	if(mode == M_COH) walk<true, false, true, M_COH, false, true>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
-	else if(mode == M_FAST) walk<true, false, true, M_FAST, false, true>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
-	else walk<true, false, true, M_EXACT, false, true>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
+	if(mode == M_COH) walk<true, false, true, M_COH, false, true, false>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
+	else if(mode == M_FAST) walk<true, false, true, M_FAST, false, true, false>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
+	else walk<true, false, true, M_EXACT, false, true, false>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
 	flushStats(A.stats, st, 0u, lane);
 	if(live) *(float4 *)(A.distance + q * 4) = make_float4(Q.dist[0], Q.dist[1], Q.dist[2], Q.dist[3]);
 }
@@ -956,7 +1024,7 @@ int checkScene(const SnailScene *s, const char *fn) {
 }
 
 int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0, int y0, int w, int h, const int32_t *dPacketXY,
-				  int nPackets, float *t, float *u, float *v, int32_t *id, uint64_t *dStats, hipStream_t stream) {
+				  int nPackets, float *t, float *u, float *v, int32_t *id, uint64_t *dStats, hipStream_t stream, unsigned *dCost = nullptr) {
 	if(resx <= 0 || resy <= 0) { snail_set_error("snail_trace_primary: bad resolution %dx%d", resx, resy); return 1; }
 	dev::PrimaryArgs A;
 	memset(&A, 0, sizeof(A));
@@ -966,12 +1034,13 @@ int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0
 	A.fastOK = s->fastOK && originSane(cam);
 	A.t = t; A.u = u; A.v = v; A.id = id;
 	A.stats = (dev::u64 *)dStats;
+	A.cost = dCost;
 	int blocks;
 	if(dPacketXY) {
 		if(nPackets <= 0) return 0;
 		A.packetXY = (const int2 *)dPacketXY;
 		A.nPackets = nPackets;
-		blocks = (nPackets + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+		blocks = ((nPackets + 127) / 128) * 128;
 	} else {
 		if((x0 & 15) || (y0 & 15) || w <= 0 || h <= 0 || x0 < 0 || y0 < 0) {
 			snail_set_error("snail_trace_primary: rect origin must be a non-negative multiple of 16 and the size positive (got %d,%d %dx%d)", x0, y0, w, h);
@@ -980,12 +1049,15 @@ int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0
 		A.x0 = x0; A.y0 = y0; A.w = w; A.h = h;
 		A.pw = (w + 15) / 16; A.ph = (h + 15) / 16;
 		A.nPackets = A.pw * A.ph;
-		blocks = ((A.pw + 1) / 2) * ((A.ph + 1) / 2);
+		const int nRegions = ((A.pw + 3) / 4) * ((A.ph + 3) / 4);
+		blocks = ((nRegions + 7) / 8) * 8 * 16;
 	}
 	A.nBlocks = blocks;
-	s->lastBlocks = blocks; s->lastThreads = WAVES_PER_BLOCK * 64;
-	if(s->depth > 62) hipLaunchKernelGGL(dev::k_primary<true>, dim3(blocks), dim3(WAVES_PER_BLOCK * 64), 0, stream, A);
-	else hipLaunchKernelGGL(dev::k_primary<false>, dim3(blocks), dim3(WAVES_PER_BLOCK * 64), 0, stream, A);
+	s->lastBlocks = blocks; s->lastThreads = 64;
+	// SNAIL_DEBUG_DYNLDS=<bytes>: occupancy experiments only (unused dynamic LDS limits waves per CU)
+	static const int dynLds = getenv("SNAIL_DEBUG_DYNLDS") ? atoi(getenv("SNAIL_DEBUG_DYNLDS")) : 0;
+	if(s->depth > 62) hipLaunchKernelGGL(dev::k_primary<true>, dim3(blocks), dim3(64), dynLds, stream, A);
+	else hipLaunchKernelGGL(dev::k_primary<false>, dim3(blocks), dim3(64), dynLds, stream, A);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
@@ -1226,6 +1298,21 @@ int snail_trace_shadow(SnailScene *s, int nPackets, int size, const float *origi
 		HIP_TRY(hipMemcpy(hs, s->dStats, 32, hipMemcpyDeviceToHost));
 		for(int k = 0; k < 4; k++) stats[k] += hs[k];
 	}
+	return 0;
+}
+
+int snail_debug_packet_costs(SnailScene *s, const float cam[13], int resx, int resy, uint32_t *out4) {
+	if(int rc = checkScene(s, "snail_debug_packet_costs")) return rc;
+	if(!out4) { snail_set_error("snail_debug_packet_costs: null output"); return 1; }
+	DeviceGuard guard(s->device);
+	const int np = ((resx + 15) / 16) * ((resy + 15) / 16);
+	DevBuf c;
+	if(c.upload(nullptr, (size_t)np * 16)) { snail_set_error("snail_debug_packet_costs: allocation failed"); return 2; }
+	HIP_TRY(hipMemset(c.p, 0, (size_t)np * 16));
+	int rc = launchPrimary(s, cam, resx, resy, 0, 0, resx, resy, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, (unsigned *)c.p);
+	if(rc) return rc;
+	HIP_TRY(hipDeviceSynchronize());
+	if(c.download(out4, (size_t)np * 16)) { snail_set_error("snail_debug_packet_costs: download failed"); return 2; }
 	return 0;
 }
 

@@ -313,3 +313,25 @@ def test_gpu_against_committed_fixtures(torch_mod):
     util.assert_bit_equal(d, g["shadow_dist_out"], "shadow")
     assert st[0] == g["shadow_stats"][0] and st[1] == g["shadow_stats"][1] and st[3] == g["shadow_stats"][3]
     sc.close()
+
+
+def test_cpp_adapter_end_to_end(torch_mod, tmp_path):
+    """A C++ host in the reference's shape (AccStruct-conforming class from include/snail_adapter.hpp, packets
+    announced in RenderTask::Work order, Context arrays filled per packet) gets the oracle's frame."""
+    import subprocess
+    from tests.test_host_side import build_adapter_mock
+    name = "atrium:0.05"
+    tv, hb, osc = util.scene_pair(name)
+    cam = util.camera_for(name, tv)
+    resx, resy = 328, 200
+    hb.nodes.tofile(str(tmp_path / "nodes.bin")); hb.tris.tofile(str(tmp_path / "tris.bin"))
+    cam.as_array13().astype(np.float32).tofile(str(tmp_path / "cam.bin"))
+    exe = build_adapter_mock(tmp_path)
+    r = subprocess.run([exe, str(tmp_path / "nodes.bin"), str(tmp_path / "tris.bin"), str(hb.depth), str(resx), str(resy), str(tmp_path / "cam.bin"),
+                        str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = np.fromfile(str(tmp_path / "out.bin"), dtype=np.uint8)
+    t = raw[:resx * resy * 4].view(np.float32).reshape(resy, resx)
+    tid = raw[resx * resy * 4:].view(np.int32).reshape(resy, resx)
+    ref = osc.render_primary(cam.as_array13(), resx, resy, mode=O.MODE_IEEE)
+    util.assert_bit_equal(t, ref[0], "adapter t"); util.assert_bit_equal(tid, ref[3], "adapter triId")

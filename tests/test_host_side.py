@@ -146,3 +146,21 @@ def test_tile_plan_partitions_the_frame():
     # shuffled round-robin: each group of n consecutive tiles is a permutation of the ranks (src/server.cpp:239-248)
     own = R.assign_tiles(64, 8)
     assert all(sorted(own[i:i + 8].tolist()) == list(range(8)) for i in range(0, 64, 8))
+
+
+def build_adapter_mock(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "adapter_mock")
+    libdir = os.path.join(ROOT, "snail_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", os.path.join(ROOT, "tests", "cpp", "adapter_mock.cpp"), "-o", exe,
+                           "-L" + libdir, "-lsnailhip", "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_cpp_adapter_compiles_and_links(tmp_path):
+    """include/snail_adapter.hpp (AccStruct-shaped HipBVH + TraceFrame) against mock types with the reference's
+    member names; links against libsnailhip.so; runs without touching the GPU when given no arguments."""
+    import subprocess
+    exe = build_adapter_mock(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
+    assert "compiled and linked" in out
