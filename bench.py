@@ -10,7 +10,10 @@ region.  Workload at N=1 = BASELINE.json configs[1]: the sponza stand-in `atrium
 reference checkout lacks sponza.obj) at 1920x1080, primary rays.  At N>1 the frame has
 N times the pixels (same camera, both axes scaled by sqrt(N) and rounded to the 16x64 tile grid), cut
 into the reference's 16x64 tiles, dealt to the ranks by shuffled round-robin, traced with one launch per
-rank and gathered to rank 0 with one RCCL collective per frame, which is inside the timed step
+rank; the hit records stay in each rank's HBM, are shaded to RGB8 with the reference's depth shading
+(gVals[1], src/scene_trace.cpp:128-137 + ConvColor) and the RGB8 tiles are gathered to rank 0 with one RCCL
+collective per frame -- what a render node returns in the reference (src/node.cpp:336-349) -- asynchronously,
+overlapping the next frame's traversal; shading, gather and the rank-0 scatter are inside the timed region
 ("scaling": "weak": per-GPU work is fixed as N grows).
 
 Mrays = rays launched (every lane of every traced packet, hit or miss), as TreeStats::TracingRays counts
@@ -41,6 +44,20 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+CPU_THREADS_CAP = 16
+
+
+def pmc_traffic(workload_key: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/traffic.json: FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, KB -> bytes)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        d = json.load(open(path))
+        return d.get(workload_key)
+    except Exception:
+        return None
 
 
 def frame_size_for(n_gpus: int):
@@ -54,7 +71,8 @@ def frame_size_for(n_gpus: int):
 def cpu_baseline(tv, cam, resx, resy):
     """Rank 0, N=1 only.  The ONLY place bench.py touches oracle/ -- as the reported CPU baseline."""
     from tests import oracle_lib as O
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(avail, CPU_THREADS_CAP))      # the GPU box grants a 16-CPU share per GPU
     osc = O.OracleScene(tv)
     cam13 = cam.as_array13()
     osc.render_primary(cam13, resx, resy, rect=(0, 0, resx, 64), mode=O.MODE_SSE, threads=cores)   # warm-up strip
@@ -137,6 +155,8 @@ def main():
 
     # ---- timed region: EXACTLY K steps ----
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    rnd.flush()
+    barrier()
     t0 = time.perf_counter()
     if world == 1:
         for e0, e1 in ev:
@@ -144,16 +164,19 @@ def main():
             scene.trace_primary(cam, resx, resy, out=rnd.frame)
             e1.record()
     else:
-        from snail_amd.render import gather_planes
+        # same sequence as DistributedRenderer.render(), with HIP events around the traversal launch
         for e0, e1 in ev:
             e0.record()
             scene.trace_packets(cam, resx, resy, rnd.packet_xy, out=rnd.planes)
             e1.record()
-            gather_planes(rnd.local, rank, world, None, rnd.gathered)
-            if rank == 0:
-                for r in range(world):
-                    g = rnd.gathered[r]
-                    scene.packets_to_frame(rnd.all_xy[r], (g[0], g[1], g[2], g[3].view(torch.int32)), rnd.frame)
+            slot = rnd.step & 1
+            rnd.step += 1
+            scene.shade_depth(rnd.planes[0], out=rnd.bgr[slot])
+            work = dist.gather(rnd.bgr[slot], rnd.gathered[slot] if rank == 0 else None, dst=0, async_op=True)
+            prev, rnd.pending = rnd.pending, (work, slot)
+            if prev is not None:
+                rnd._finish(prev)
+        rnd.flush()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -166,7 +189,9 @@ def main():
         ms_per_step = elapsed * 1e3 / args.steps
         value = total_rays * args.steps / elapsed / 1e6
         achieved = launch_rays * b_alg / (kern_ms * 1e-3) / 1e9
-        hit_frac = float(torch.isfinite(rnd.frame.t).float().mean().item())
+        tr = pmc_traffic("%s_%dx%d_n%d" % (args.scene, resx, resy, world))
+        traffic = round(tr["bytes_per_launch"] / (kern_ms * 1e-3) / 1e9, 1) if tr else None
+        hit_frac = float(torch.isfinite(rnd.frame.t).float().mean().item()) if rnd.frame is not None else float((rnd.frame_rgb8.amax(dim=2) > 0).float().mean().item())
         out = {
             "metric": "Mrays/sec (primary)", "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
@@ -174,9 +199,10 @@ def main():
             "config": {"workload": "%s (%d tris, sponza.obj stand-in) %dx%d primary rays, hit records (t,u,v,triId)" % (args.scene, hbvh.n_tris, resx, resy),
                        "rays_per_step": total_rays, "packets": "16x16 px = 1 wavefront", "bvh_nodes": hbvh.n_nodes, "bvh_depth": hbvh.depth,
                        "bvh_build_s": round(build_s, 3), "hit_fraction": round(hit_frac, 5),
-                       "parallelism": "tiles16x64-roundrobin-x%d+gather" % world if world > 1 else "single-gpu"},
+                       "parallelism": "tiles16x64-roundrobin-x%d + depth-shade + async RCCL gather of rgb8 tiles to rank 0" % world if world > 1 else "single-gpu"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None, "kernel": "dev::k_primary", "kernel_ms": round(kern_ms, 5),
+                         "traffic": traffic, "traffic_bytes_per_launch": tr["bytes_per_launch"] if tr else None,
+                         "traffic_source": tr["source"] if tr else None, "kernel": "dev::k_primary", "kernel_ms": round(kern_ms, 5),
                          "alg_bytes_per_ray": round(b_alg, 1), "rays_per_launch": launch_rays,
                          "note": "achieved = single-ray algorithmic bytes (32*V_n+64*V_t+16 per ray) / kernel time; the packet kernel fetches a node once per 256 rays, so this can exceed the HBM peak"},
         }

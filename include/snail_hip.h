@@ -103,6 +103,17 @@ int snail_trace_shadow(SnailScene *, int nPackets, int size, const float *origin
 int snail_trace_shadow_dev(SnailScene *, int nPackets, int size, const float *d_origin3, const float *d_dir, const float *d_idir,
                            float *d_distance, uint64_t *d_stats, void *stream);
 
+/* ---- framebuffer (the reference's simplest shading mode + RGB8 store) ----------------------------- */
+/* gVals[1] "very simple shading" (src/scene_trace.cpp:128-137): c = Inv(t) * (20, 250, 2) per pixel, then
+ * ConvColor (src/render.cpp:11-17): trunc(clamp(c*255, 0, 255)) packed b | g<<8 | r<<16 and stored as 3 bytes
+ * (B,G,R) per pixel (src/render.cpp:171-198).  d_t: packet-major distances [nPackets][256];
+ * d_bgr: packet-major bytes [nPackets][256][3].  This is what a render node returns per tile in the reference
+ * (RGB8, src/node.cpp:336-349) and what the multi-GPU path gathers over xGMI. */
+int snail_shade_depth_dev(const float *d_t, int nPackets, uint8_t *d_bgr, void *stream);
+/* Scatter packet-major BGR bytes into an interleaved rgb8 frame (pitch bytes per row), clipped to the image. */
+int snail_packets_bgr_to_frame_dev(const int32_t *d_packet_xy, int nPackets, int resx, int resy, const uint8_t *d_bgr,
+                                   uint8_t *d_frame, int pitch, void *stream);
+
 /* ---- measurement support ------------------------------------------------------------------------- */
 /* Single-ray, cache-less accounting walk of SURVEY.md section 8(d) over the same padded packet set as
  * snail_trace_primary: d_out[0] += rays, [1] += sum V_n (node boxes tested), [2] += sum V_t

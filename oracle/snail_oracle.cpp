@@ -678,6 +678,17 @@ void orc_account_primary(const OrcNode *nodes, const OrcTri *tris, const OrcCame
 	else accountPrimary<ORC_MODE_IEEE>(nodes, tris, cam, resx, resy, x0, y0, w, h, out, threads);
 }
 
+void orc_shade_depth(const float *t, int n, uint8_t *bgr, int mode) {
+	for(int i = 0; i < n; i++) {
+		// Condition(tDistance > maxDist(+inf), 0, Inv(tDistance)): the comparison is never true (src/scene_trace.cpp:130)
+		float dist = mode == ORC_MODE_SSE ? Inv<ORC_MODE_SSE>(t[i]) : Inv<ORC_MODE_IEEE>(t[i]);
+		float c[3] = {dist * 20.0f, dist * 250.0f, dist * 2.0f}; // r, g, b
+		int q[3];
+		for(int k = 0; k < 3; k++) q[k] = (int)Min(Max(c[k] * 255.0f, 0.0f), 255.0f); // Trunc(Clamp(..)), src/render.cpp:11-17
+		bgr[i * 3 + 0] = (uint8_t)q[2]; bgr[i * 3 + 1] = (uint8_t)q[1]; bgr[i * 3 + 2] = (uint8_t)q[0];
+	}
+}
+
 float orc_inv(float x, int mode) { return mode == ORC_MODE_SSE ? Inv<ORC_MODE_SSE>(x) : Inv<ORC_MODE_IEEE>(x); }
 float orc_rsqrt(float x, int mode) { return mode == ORC_MODE_SSE ? RSqrt<ORC_MODE_SSE>(x) : RSqrt<ORC_MODE_IEEE>(x); }
 float orc_min(float a, float b) { return Min(a, b); }

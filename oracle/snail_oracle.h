@@ -12,7 +12,7 @@
  * What IS pinned: (1) the arithmetic primitives (Inv/RSqrt/Min/Max/Condition, Vec3 dot/cross) against
  * the reference's own header-only veclib compiled from /root/reference/veclib (oracle/_ref/veclib_probe);
  * (2) the digests SURVEY.md section 8(c) recorded from the reference during the survey session
- * (box / lancia / feline / barracks tree hashes and hit sums), checked by tests/test_survey_digests.py.
+ * (box / lancia / feline / barracks tree hashes and hit sums), checked by tests/test_oracle_pins.py.
  *
  * Two arithmetic modes for the two approximate operations of the path (Inv, RSqrt):
  *   ORC_MODE_IEEE (0): veclib's scalar definitions  Inv(x)=1.0f/x, RSqrt(x)=1.0f/sqrtf(x)
@@ -91,6 +91,9 @@ void orc_render_primary(const OrcNode *nodes, const OrcTri *tris, const OrcCamer
 void orc_account_primary(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam,
                          int resx, int resy, int x0, int y0, int w, int h, uint64_t *out,
                          int mode, int threads);
+
+/* gVals[1] depth shading + ConvColor -> 3 bytes (B,G,R) per ray (src/scene_trace.cpp:128-137, src/render.cpp:11-17,171-198) */
+void orc_shade_depth(const float *t, int n, uint8_t *bgr, int mode);
 
 /* arithmetic primitives exposed for the veclib pin test */
 float orc_inv(float x, int mode);

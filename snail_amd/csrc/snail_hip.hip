@@ -886,6 +886,34 @@ __global__ __launch_bounds__(256) void k_packets_to_frame(ScatterArgs A) {
 		}
 }
 
+// ---- gVals[1] depth shading + ConvColor (src/scene_trace.cpp:128-137, src/render.cpp:11-17) ---------
+__device__ __forceinline__ int convChannel(float c) { // Trunc(Clamp(c * 255, 0, 255)); Clamp = Min(Max(v, lo), hi), veclib/vecbase.h:75-77
+	float v = c * 255.0f;
+	v = v > 0.0f ? v : 0.0f;
+	v = v < 255.0f ? v : 255.0f;
+	return (int)v;
+}
+__global__ __launch_bounds__(256) void k_shade_depth(const float *t, int nRays, unsigned char *bgr) {
+	const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+	if(i >= nRays) return;
+	const float dist = 1.0f / t[i];              // Condition(t > inf, 0, Inv(t)): the condition is never true
+	const int r = convChannel(dist * 20.0f), g = convChannel(dist * 250.0f), b = convChannel(dist * 2.0f);
+	bgr[(size_t)i * 3 + 0] = (unsigned char)b; bgr[(size_t)i * 3 + 1] = (unsigned char)g; bgr[(size_t)i * 3 + 2] = (unsigned char)r;
+}
+__global__ __launch_bounds__(256) void k_bgr_to_frame(const int2 *packetXY, int nPackets, int resx, int resy, const unsigned char *src,
+														unsigned char *frame, int pitch) {
+	const int lane = threadIdx.x & 63;
+	const int p = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+	if(p >= nPackets) return;
+	const int2 xy = packetXY[p];
+	const int yy = xy.y + (lane >> 2), xx = xy.x + (lane & 3) * 4;
+	if(yy >= resy) return;
+	const unsigned char *s = src + ((size_t)p * 256 + (size_t)lane * 4) * 3;
+	unsigned char *d = frame + (size_t)yy * pitch + (size_t)xx * 3;
+	for(int l = 0; l < 4; l++)
+		if(xx + l < resx) { d[l * 3 + 0] = s[l * 3 + 0]; d[l * 3 + 1] = s[l * 3 + 1]; d[l * 3 + 2] = s[l * 3 + 2]; }
+}
+
 // ---- single-ray accounting walk: V_n, V_t per ray ----------------------------
 struct AccountArgs {
 	const uint4 *nodes, *tris;
@@ -1298,6 +1326,25 @@ int snail_trace_shadow(SnailScene *s, int nPackets, int size, const float *origi
 		HIP_TRY(hipMemcpy(hs, s->dStats, 32, hipMemcpyDeviceToHost));
 		for(int k = 0; k < 4; k++) stats[k] += hs[k];
 	}
+	return 0;
+}
+
+int snail_shade_depth_dev(const float *t, int nPackets, uint8_t *bgr, void *stream) {
+	if(nPackets <= 0) return 0;
+	if(!t || !bgr) { snail_set_error("snail_shade_depth_dev: null buffer"); return 1; }
+	const int n = nPackets * 256;
+	hipLaunchKernelGGL(dev::k_shade_depth, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, n, bgr);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+int snail_packets_bgr_to_frame_dev(const int32_t *dPacketXY, int nPackets, int resx, int resy, const uint8_t *bgr, uint8_t *frame, int pitch,
+								   void *stream) {
+	if(nPackets <= 0) return 0;
+	if(!dPacketXY || !bgr || !frame || pitch < resx * 3) { snail_set_error("snail_packets_bgr_to_frame_dev: bad arguments"); return 1; }
+	hipLaunchKernelGGL(dev::k_bgr_to_frame, dim3((nPackets + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const int2 *)dPacketXY, nPackets, resx,
+					   resy, bgr, frame, pitch);
+	HIP_TRY(hipGetLastError());
 	return 0;
 }
 

@@ -103,29 +103,44 @@ def gather_planes(local, rank: int, world: int, group=None, gathered=None):
 
 
 class DistributedRenderer:
-    """One process per GPU.  render() = trace this rank's packets, gather to rank 0, scatter into the
-    frame there.  With world_size 1 the frame is traced directly in frame layout (no collective)."""
+    """One process per GPU.  With world_size 1 the frame's hit records are traced directly in frame layout (no
+    collective).  With world_size > 1 every rank traces its tiles' packets (hit records stay in its HBM, where a
+    device-side shader consumes them), shades them to RGB8 with the reference's depth shading
+    (Scene.shade_depth) and rank 0 gathers the RGB8 tiles -- what a render node returns in the reference
+    (src/node.cpp:336-349: rgb8 per tile) -- and scatters them into the frame.  `payload="hits"` gathers the
+    16-B/px hit records instead (5.3x the bytes).  The gather of frame i is asynchronous and overlaps the
+    traversal of frame i+1 (RCCL runs on its own stream); flush() completes the last frame."""
 
-    def __init__(self, scene, resx: int, resy: int, rank: int = 0, world_size: int = 1, group=None, seed: int = 20090501):
+    def __init__(self, scene, resx: int, resy: int, rank: int = 0, world_size: int = 1, group=None, seed: int = 20090501,
+                 payload: str = "rgb8"):
         import torch
         self.torch = torch
         self.scene = scene
         self.rank, self.world = rank, world_size
         self.group = group
+        self.payload = payload
         self.plan = ShardPlan.make(resx, resy, world_size, seed)
         dev = scene._dev()
-        self.frame = scene.alloc_frame(resx, resy) if rank == 0 else None
+        self.frame = scene.alloc_frame(resx, resy) if (rank == 0 and (world_size == 1 or payload == "hits")) else None
+        self.frame_rgb8 = torch.zeros((resy, resx, 3), dtype=torch.uint8, device=dev) if (rank == 0 and world_size > 1 and payload == "rgb8") else None
+        self.pending = None
+        self.step = 0
         if world_size > 1:
             n = self.plan.padded
             self.packet_xy = torch.from_numpy(self.plan.padded_packets(rank)).to(dev)
-            # one buffer [4, n, 256] so that the frame's planes travel in ONE collective
+            # one buffer [4, n, 256] so that the four planes travel in ONE collective (payload "hits")
             self.local = torch.empty((4, n, 256), dtype=torch.float32, device=dev)
             self.planes = (self.local[0], self.local[1], self.local[2], self.local[3].view(torch.int32))
+            nbuf = 2  # double buffering: gather(i) overlaps trace(i+1)
+            self.bgr = [torch.empty((n, 256, 3), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
             if rank == 0:
-                self.gathered = [torch.empty_like(self.local) for _ in range(world_size)]
                 self.all_xy = [torch.from_numpy(self.plan.padded_packets(r)).to(dev) for r in range(world_size)]
+                if payload == "hits":
+                    self.gathered = [torch.empty_like(self.local) for _ in range(world_size)]
+                else:
+                    self.gathered = [[torch.empty_like(self.bgr[0]) for _ in range(world_size)] for _ in range(nbuf)]
             else:
-                self.gathered = None
+                self.gathered = [None, None]
 
     def rays_per_frame(self) -> int:
         return self.plan.total_rays()
@@ -133,15 +148,39 @@ class DistributedRenderer:
     def local_rays(self) -> int:
         return len(self.plan.packets[self.rank]) * 256
 
+    def _finish(self, pending):
+        work, slot = pending
+        work.wait()
+        if self.rank == 0:
+            for r in range(self.world):
+                self.scene.packets_bgr_to_frame(self.all_xy[r], self.gathered[slot][r], self.frame_rgb8)
+
     def render(self, cam, stats=None):
         torch = self.torch
+        import torch.distributed as dist
         sc, p = self.scene, self.plan
         if self.world == 1:
             return sc.trace_primary(cam, p.resx, p.resy, out=self.frame, stats=stats)
         sc.trace_packets(cam, p.resx, p.resy, self.packet_xy, out=self.planes, stats=stats)
-        gather_planes(self.local, self.rank, self.world, self.group, self.gathered)
-        if self.rank == 0:
-            for r in range(self.world):
-                g = self.gathered[r]
-                sc.packets_to_frame(self.all_xy[r], (g[0], g[1], g[2], g[3].view(torch.int32)), self.frame)
-        return self.frame
+        if self.payload == "hits":
+            gather_planes(self.local, self.rank, self.world, self.group, self.gathered if self.rank == 0 else None)
+            if self.rank == 0:
+                for r in range(self.world):
+                    g = self.gathered[r]
+                    sc.packets_to_frame(self.all_xy[r], (g[0], g[1], g[2], g[3].view(torch.int32)), self.frame)
+            return self.frame
+        slot = self.step & 1
+        self.step += 1
+        sc.shade_depth(self.planes[0], out=self.bgr[slot])
+        work = dist.gather(self.bgr[slot], self.gathered[slot] if self.rank == 0 else None, dst=0, group=self.group, async_op=True)
+        prev, self.pending = self.pending, (work, slot)
+        if prev is not None:
+            self._finish(prev)
+        return self.frame_rgb8
+
+    def flush(self):
+        """Complete the in-flight gather (call after the last render() of a sequence)."""
+        if self.pending is not None:
+            self._finish(self.pending)
+            self.pending = None
+        return self.frame_rgb8 if self.frame_rgb8 is not None else self.frame

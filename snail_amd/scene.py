@@ -166,6 +166,26 @@ class Scene:
         _lib.check(rc, "snail_packets_to_frame_dev")
         return frame
 
+    # ---- framebuffer: gVals[1] depth shading + RGB8 store (src/scene_trace.cpp:128-137, src/render.cpp:11-17,171-198)
+    @staticmethod
+    def shade_depth(t_packets, out=None, stream=None):
+        """packet-major distances [n,256] -> packet-major bytes [n,256,3] (B,G,R per pixel)."""
+        torch = _torch()
+        n = int(t_packets.shape[0])
+        if out is None:
+            out = torch.empty((n, 256, 3), dtype=torch.uint8, device=t_packets.device)
+        _lib.check(_lib.lib().snail_shade_depth_dev(_lib.ptr(t_packets), n, _lib.ptr(out), _stream_ptr(stream)), "snail_shade_depth_dev")
+        return out
+
+    @staticmethod
+    def packets_bgr_to_frame(packet_xy, bgr_packets, frame_rgb8, stream=None):
+        """scatter [n,256,3] bytes into an interleaved [resy,resx,3] uint8 frame."""
+        resy, resx = int(frame_rgb8.shape[0]), int(frame_rgb8.shape[1])
+        rc = _lib.lib().snail_packets_bgr_to_frame_dev(_lib.ptr(packet_xy), int(packet_xy.shape[0]), resx, resy, _lib.ptr(bgr_packets),
+                                                       _lib.ptr(frame_rgb8), resx * 3, _stream_ptr(stream))
+        _lib.check(rc, "snail_packets_bgr_to_frame_dev")
+        return frame_rgb8
+
     def trace_primary_host(self, cam: Camera, resx: int, resy: int, rect=None):
         """Host-buffer entry point (what a C++ host would call): numpy planes in, numpy planes out."""
         x0, y0, w, h = rect if rect is not None else (0, 0, resx, resy)

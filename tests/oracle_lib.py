@@ -45,6 +45,7 @@ def lib():
         L.orc_trace_shadow.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, u64p, i32]
         L.orc_render_primary.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, u64p, i32, i32]
         L.orc_account_primary.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, u64p, i32, i32]
+        L.orc_shade_depth.argtypes = [vp, i32, vp, i32]
         for f in (L.orc_inv, L.orc_rsqrt):
             f.argtypes = [C.c_float, i32]
             f.restype = C.c_float
@@ -123,3 +124,10 @@ def gen_packet(cam13, resx, resy, px, py, mode=MODE_IEEE):
     i = np.zeros(768, dtype=np.float32)
     lib().orc_gen_packet(_p(cam), resx, resy, px, py, mode, _p(d), _p(i))
     return d, i
+
+
+def shade_depth(t: np.ndarray, mode=MODE_IEEE) -> np.ndarray:
+    tt = np.ascontiguousarray(t, dtype=np.float32).reshape(-1)
+    out = np.zeros((len(tt), 3), dtype=np.uint8)
+    lib().orc_shade_depth(_p(tt), len(tt), _p(out), mode)
+    return out

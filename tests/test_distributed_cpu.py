@@ -59,6 +59,20 @@ def _worker(rank, world, port, resx, resy, q):
         local = torch.from_numpy(np.stack([frame_to_packets(t, xy), frame_to_packets(u, xy), frame_to_packets(v, xy),
                                            frame_to_packets(tid, xy).view(np.float32)], axis=0))
         got = R.gather_planes(local, rank, world)
+        # the rgb8 payload of the GPU path: shaded bytes, asynchronous gather (same call DistributedRenderer makes)
+        bgr_full = O.shade_depth(t).reshape(resy, resx, 3)
+        bgr_local = torch.from_numpy(np.stack([frame_to_packets(bgr_full[:, :, c], xy) for c in range(3)], axis=2).copy())
+        glist = [torch.empty_like(bgr_local) for _ in range(world)] if rank == 0 else None
+        work = dist.gather(bgr_local, glist, dst=0, async_op=True)
+        work.wait()
+        if rank == 0:
+            fb = np.zeros((resy, resx, 3), np.uint8)
+            for r in range(world):
+                g = glist[r].numpy(); rxy = plan.padded_packets(r)
+                for c in range(3):
+                    plane = fb[:, :, c].copy(); packets_to_frame(g[:, :, c], rxy, plane); fb[:, :, c] = plane
+            if fb.tobytes() != bgr_full.tobytes():
+                q.put(("rgb8 frame mismatch", 0, [])); return
         if rank == 0:
             ft = np.full((resy, resx), np.nan, np.float32); fu = ft.copy(); fv = ft.copy(); fi = np.full((resy, resx), -1, np.int32)
             for r in range(world):

@@ -335,3 +335,34 @@ def test_cpp_adapter_end_to_end(torch_mod, tmp_path):
     tid = raw[resx * resy * 4:].view(np.int32).reshape(resy, resx)
     ref = osc.render_primary(cam.as_array13(), resx, resy, mode=O.MODE_IEEE)
     util.assert_bit_equal(t, ref[0], "adapter t"); util.assert_bit_equal(tid, ref[3], "adapter triId")
+
+
+def test_depth_shading_and_tile_pipeline(torch_mod):
+    """f2 row: gVals[1] depth shading + ConvColor + RGB8 store, and the multi-rank tile pipeline executed rank by
+    rank in one process (plan -> trace_packets -> shade_depth -> scatter); the collective itself is covered on
+    CPU by tests/test_distributed_cpu.py."""
+    from snail_amd import render as R
+    name = "atrium:0.05"
+    tv, sc, osc = gpu_scene(name)
+    cam = util.camera_for(name, tv)
+    resx, resy = 328, 200
+    t_ref = osc.render_primary(cam.as_array13(), resx, resy, mode=O.MODE_IEEE)[0]
+    want = O.shade_depth(t_ref).reshape(resy, resx, 3)
+    assert want.max() > 0 and (want.reshape(-1, 3).max(axis=0) > 0).all()
+    for world in (1, 2, 3):
+        plan = R.ShardPlan.make(resx, resy, world)
+        frame = torch_mod.zeros((resy, resx, 3), dtype=torch_mod.uint8, device="cuda")
+        for r in range(world):
+            xy = torch_mod.from_numpy(plan.padded_packets(r)).cuda()
+            planes = sc.trace_packets(cam, resx, resy, xy)
+            bgr = sc.shade_depth(planes[0])
+            sc.packets_bgr_to_frame(xy, bgr, frame)
+        torch_mod.cuda.synchronize()
+        got = frame.cpu().numpy()
+        assert np.array_equal(got, want), (world, int((got != want).sum()))
+    # special values: miss (+inf) -> black, tiny t -> saturated, NaN -> black
+    t = torch_mod.tensor([[float("inf"), 1e-6, float("nan"), 1.0] + [2.0] * 252], dtype=torch_mod.float32, device="cuda")
+    b = sc.shade_depth(t).cpu().numpy().reshape(-1, 3)
+    assert np.array_equal(b[:4], O.shade_depth(t.cpu().numpy())[:4])
+    assert tuple(b[0]) == (0, 0, 0) and tuple(b[1]) == (255, 255, 255) and tuple(b[2]) == (0, 0, 0)
+    sc.close()
