@@ -116,7 +116,7 @@ __device__ __forceinline__ Tri loadTriScalar(const uint4 *tris, int idx) { // wa
 //            (never observed by a comparison); BBox::TestInterval is implied by the per-lane test
 //            (monotonic rounding) and skipped.
 //   M_COH  : M_FAST + every ray of the packet has the same idir sign bit per axis, so min(l1,l2)/max(l1,l2)
-//            of a slab are known without comparing: near/far planes are picked once per node (scalar).
+//            of a slab are known without comparing: near/far planes are picked once per node (scalar XOR-swap).
 enum { M_EXACT = 0, M_FAST = 1, M_COH = 2 };
 
 // raw VALU min/max: clang would wrap llvm.minnum in sNaN-quieting canonicalisations (v_max_f32 x,x,x)
@@ -313,30 +313,6 @@ __device__ __forceinline__ TriTerms triTerms(const Tri &t, float ox, float oy, f
 	return r;
 }
 
-// M_COH slab test for one sign octant OCT (bit k set = idir negative on axis k): the near plane of axis k is
-// bmax when the rays travel in -k, else bmin -- resolved at compile time, so no select is executed.
-template <bool SHARED, int OCT>
-__device__ __forceinline__ void slabsCoherent(const Node &n, const float (&org)[3][4], const Quad &Q, float (&tn)[4], float (&tf)[4]) {
-	float pn[3], pf[3];
-#pragma unroll
-	for(int k = 0; k < 3; k++) {
-		const float nr = ((OCT >> k) & 1) ? n.bmax[k] : n.bmin[k], fr = ((OCT >> k) & 1) ? n.bmin[k] : n.bmax[k];
-		pn[k] = SHARED ? nr - org[k][0] : nr;
-		pf[k] = SHARED ? fr - org[k][0] : fr;
-	}
-#pragma unroll
-	for(int l = 0; l < 4; l++) {
-		float lo[3], hi[3];
-#pragma unroll
-		for(int k = 0; k < 3; k++) {
-			lo[k] = Q.id[k][l] * (SHARED ? pn[k] : pn[k] - org[k][l]);
-			hi[k] = Q.id[k][l] * (SHARED ? pf[k] : pf[k] - org[k][l]);
-		}
-		tn[l] = vmax3(lo[0], lo[1], lo[2]);
-		tf[l] = vmin3(hi[0], hi[1], hi[2]);
-	}
-}
-
 // ---- the packet walk -------------------------------------------------------------------------------
 // SHARED : one origin per packet (primary / shadow)   MASK : per-lane 4-bit masks (secondary rays)
 // SHADOW : any-hit TraverseShadow                      M    : arithmetic mode (above)
@@ -371,8 +347,8 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 	const int signBits = __builtin_amdgcn_readfirstlane((Q.d[0][0] < 0.0f ? 1 : 0) | (Q.d[1][0] < 0.0f ? 2 : 0) | (Q.d[2][0] < 0.0f ? 4 : 0));
 	// M_COH: the (packet-uniform) sign of idir per axis picks the near/far slab plane
 	// (sign BIT, so that the selects stay on the scalar unit; -0 behaves like any negative: both slab products are 0)
-	const int octant = __builtin_amdgcn_readfirstlane(((__float_as_int(Q.id[0][0]) >> 31) & 1) | ((__float_as_int(Q.id[1][0]) >> 31) & 2) |
-													  ((__float_as_int(Q.id[2][0]) >> 31) & 4));
+	const int octMask[3] = {__builtin_amdgcn_readfirstlane(__float_as_int(Q.id[0][0]) >> 31), __builtin_amdgcn_readfirstlane(__float_as_int(Q.id[1][0]) >> 31),
+							__builtin_amdgcn_readfirstlane(__float_as_int(Q.id[2][0]) >> 31)}; // 0 or -1 per axis
 
 	int stkNode = 0, stkFL = 0, stkNode2 = 0, stkFL2 = 0;
 	int sp = 0;
@@ -393,8 +369,9 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 		__builtin_amdgcn_sched_barrier(0); // keep the fetch ahead of the slab arithmetic it overlaps with
 
 		// ---- BBox::TestInterval + BBox::Test (src/bounding_box.cpp:208-236, :61-142 / :144-200) ----
-		bool anyPass = false;
+		u64 passMask = 0; // quads with a surviving lane (before clipping to [first,last])
 		if(EXACT) {
+			bool anyPass = false;
 			if(boxTestInterval(n, iv)) {
 				float tmn[3], tmx[3];
 				if(SHARED) {
@@ -417,20 +394,31 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 					anyPass |= pass;
 				}
 			}
+			passMask = __builtin_amdgcn_ballot_w64(anyPass);
 		} else {
 			// finite inputs: lane passes  <=>  lmax >= 0  &&  lmin <= lmax  &&  lmin <= dist   (both flavours)
 			float tn[4], tf[4];
 			if(M == M_COH) {
-				// eight specialisations (one per sign octant of the packet): near/far planes are compile-time picks
-				switch(octant) {
-				case 0: slabsCoherent<SHARED, 0>(n, org, Q, tn, tf); break;
-				case 1: slabsCoherent<SHARED, 1>(n, org, Q, tn, tf); break;
-				case 2: slabsCoherent<SHARED, 2>(n, org, Q, tn, tf); break;
-				case 3: slabsCoherent<SHARED, 3>(n, org, Q, tn, tf); break;
-				case 4: slabsCoherent<SHARED, 4>(n, org, Q, tn, tf); break;
-				case 5: slabsCoherent<SHARED, 5>(n, org, Q, tn, tf); break;
-				case 6: slabsCoherent<SHARED, 6>(n, org, Q, tn, tf); break;
-				default: slabsCoherent<SHARED, 7>(n, org, Q, tn, tf); break;
+				// near/far plane per axis by the packet's sign octant, as a scalar XOR-swap on the bit patterns
+				// (stays on the SALU: no VALU select, no branch): near = neg ? bmax : bmin, far = the other one
+				float pn[3], pf[3];
+#pragma unroll
+				for(int k = 0; k < 3; k++) {
+					const int lo = __float_as_int(n.bmin[k]), hi = __float_as_int(n.bmax[k]);
+					const int sw = (lo ^ hi) & octMask[k];
+					pn[k] = __int_as_float(lo ^ sw); pf[k] = __int_as_float(hi ^ sw);
+					if(SHARED) { pn[k] = pn[k] - org[k][0]; pf[k] = pf[k] - org[k][0]; }
+				}
+#pragma unroll
+				for(int l = 0; l < 4; l++) {
+					float lo[3], hi[3];
+#pragma unroll
+					for(int k = 0; k < 3; k++) {
+						lo[k] = Q.id[k][l] * (SHARED ? pn[k] : pn[k] - org[k][l]);
+						hi[k] = Q.id[k][l] * (SHARED ? pf[k] : pf[k] - org[k][l]);
+					}
+					tn[l] = vmax3(lo[0], lo[1], lo[2]);
+					tf[l] = vmin3(hi[0], hi[1], hi[2]);
 				}
 			} else {
 				float pn[3], pf[3];
@@ -453,13 +441,16 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 			if(DISTPOS) { // dist >= 0 on every lane (primary packets): lmax>=0 && lmin<=lmax && lmin<=dist  <=>  max(lmin,0) <= min(lmax,dist)
 #pragma unroll
 				for(int l = 0; l < 4; l++) { tn[l] = vmax(tn[l], 0.0f); tf[l] = vmin(tf[l], Q.dist[l]); }
-				anyPass = (tn[0] <= tf[0]) | (tn[1] <= tf[1]) | (tn[2] <= tf[2]) | (tn[3] <= tf[3]);
+				// each compare IS a lane mask in an SGPR pair; OR them on the scalar unit (no bool -> VGPR -> ballot detour)
+				passMask = __builtin_amdgcn_ballot_w64(tn[0] <= tf[0]) | __builtin_amdgcn_ballot_w64(tn[1] <= tf[1]) |
+						   __builtin_amdgcn_ballot_w64(tn[2] <= tf[2]) | __builtin_amdgcn_ballot_w64(tn[3] <= tf[3]);
 			} else {
 #pragma unroll
-				for(int l = 0; l < 4; l++) anyPass |= (tf[l] >= 0.0f) & (tn[l] <= tf[l]) & (tn[l] <= Q.dist[l]);
+				for(int l = 0; l < 4; l++)
+					passMask |= __builtin_amdgcn_ballot_w64(tf[l] >= 0.0f) & __builtin_amdgcn_ballot_w64(tn[l] <= tf[l]) & __builtin_amdgcn_ballot_w64(tn[l] <= Q.dist[l]);
 			}
 		}
-		const u64 alive = __builtin_amdgcn_ballot_w64(anyPass) & rangeMask(first, last);
+		const u64 alive = passMask & rangeMask(first, last);
 		if(alive != 0) {
 			first = __builtin_ctzll(alive);
 			last = 63 - __builtin_clzll(alive);
