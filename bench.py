@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--scene", default="atrium")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=2, help="frames in flight at N=1 (HIP streams); 1 = strictly serial frames")
+    ap.add_argument("--streams", type=int, default=3, help="frames in flight at N=1 (HIP streams); 1 = strictly serial frames")
     args = ap.parse_args()
 
     import numpy as np

@@ -267,7 +267,20 @@ def stress(seed: int = 7, detail: float = 1.0) -> np.ndarray:
 
 
 def stress_camera() -> "tuple":
-    return (np.array([-34.0, 9.0, -30.0], dtype=F32), 0.82, -0.22)
+    return (np.array([-34.0, 9.0, -30.0], dtype=F32), -0.85, 0.2)   # looking across the terrain, slightly down
+
+
+def chain(n: int = 400, ratio: float = 1.2) -> np.ndarray:
+    """Adversarial scene for the builder and the traversal stack: a geometric chain of shrinking triangles.
+    The SAH sweep peels one triangle per level, so the tree reaches BVH::maxDepth - 1 = 63 (where a leaf is
+    forced, src/bvh/tree.cpp:54) and that last leaf holds far more than 4 (here > 64) triangles."""
+    tris = []
+    for i in range(n):
+        s = ratio ** (-i)
+        x = 10.0 * s
+        y, z = 2.0 * s * ((i % 3) - 1), 2.0 * s * (((i // 3) % 3) - 1)      # sway so that many triangles are visible
+        tris.append([[x, y, z], [x + 0.3 * s, y, z + 2.0 * s], [x, y + 2.0 * s, z]])
+    return np.asarray(tris, dtype=F32)
 
 
 def drop_degenerate(tri_verts: np.ndarray) -> np.ndarray:
@@ -290,6 +303,8 @@ def scene_by_name(name: str, scenes_dir: str | None = None) -> np.ndarray:
     if name.startswith("stress"):
         d = float(name.split(":")[1]) if ":" in name else 1.0
         return drop_degenerate(stress(detail=d))
+    if name.startswith("chain"):
+        return chain()
     path = name
     if not os.path.exists(path) and scenes_dir:
         path = os.path.join(scenes_dir, name)

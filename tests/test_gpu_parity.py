@@ -44,6 +44,8 @@ def compare_frames(frame, oracle_out, what):
     ("box", 250, 130),            # ragged: not a multiple of 16 (and resx % 4 != 0 -> scalar stores)
     ("atrium:0.05", 640, 368),
     ("atrium:0.05", 328, 200),
+    ("chain", 256, 144),          # depth-63 tree (second stack register pair) and a > 64-triangle leaf (chunked leaf loop)
+    ("stress:0.05", 320, 192),
 ])
 def test_primary_frame_bit_exact(torch_mod, name, resx, resy):
     tv, sc, osc = gpu_scene(name)

@@ -45,12 +45,15 @@ def test_scene_needs_a_gpu():
         Scene(hb, 0)
 
 
-@pytest.mark.parametrize("name", ["box", "atrium:0.05", "stress:0.01"])
+@pytest.mark.parametrize("name", ["box", "atrium:0.05", "stress:0.01", "chain"])
 def test_builder_bit_identical_to_oracle(name):
     tv, hb, osc = util.scene_pair(name)
     assert hb.tris.tobytes() == osc.tris.tobytes()
     assert hb.nodes.tobytes() == osc.nodes.tobytes()
     assert hb.depth == osc.depth and np.array_equal(hb.perm, osc.perm)
+    if name == "chain":
+        leaf = (hb.nodes["sub"] & 0x80000000) != 0
+        assert hb.depth == 63 and hb.nodes["aux"][leaf].max() > 64        # forced leaf at maxDepth-1 with a long triangle list
 
 
 @pytest.mark.parametrize("name", ["box", "atrium:0.05"])

@@ -25,6 +25,8 @@ def camera_for(name: str, tv):
     if name.startswith("stress"):
         pos, ang, pitch = scenes.stress_camera()
         return FPSCamera(pos, ang, pitch).camera()
+    if name.startswith("chain"):
+        return FPSCamera(np.array([-0.25, 0.004, 0.002], dtype=np.float32), -math.pi / 2, 0.0).camera()   # looking down +x through the chain
     return survey_camera(tv)
 
 
