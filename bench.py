@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--scene", default="atrium")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=3, help="frames in flight at N=1 (HIP streams); 1 = strictly serial frames")
+    ap.add_argument("--streams", type=int, default=3, help="frames in flight (HIP streams); 1 = strictly serial frames")
     args = ap.parse_args()
 
     import numpy as np
@@ -134,7 +134,7 @@ def main():
     cam = FPSCamera(pos, ang, pitch).camera()
     scene = Scene(hbvh, local_rank)
     resx, resy = frame_size_for(world)
-    rnd = DistributedRenderer(scene, resx, resy, rank, world)
+    rnd = DistributedRenderer(scene, resx, resy, rank, world, slots=args.streams)
     total_rays = rnd.rays_per_frame() if world > 1 else resx * ((resy + 15) // 16 * 16)
 
     # ---- algorithmic bytes (outside the timed region) ----
@@ -150,44 +150,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    streams = [torch.cuda.Stream() for _ in range(max(1, args.streams))]
-    frames = [rnd.frame] + [scene.alloc_frame(resx, resy) for _ in range(len(streams) - 1)] if world == 1 else []
-    for i in range(args.warmup):
-        if world == 1:
-            with torch.cuda.stream(streams[i % len(streams)]):
-                scene.trace_primary(cam, resx, resy, out=frames[i % len(frames)], stream=streams[i % len(streams)])
-        else:
-            rnd.render(cam)
-    barrier()
-
-    # ---- timed region: EXACTLY K steps ----
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for _ in range(args.warmup):
+        rnd.render(cam)
     rnd.flush()
     barrier()
+
+    # ---- timed region: EXACTLY K steps (frames are pipelined over args.streams HIP streams, see DistributedRenderer) ----
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    if world == 1:
-        # frames are double-buffered over two HIP streams, as a real-time renderer pipelines them: the next
-        # frame's packets fill the CUs that the previous frame's last (heaviest) packets leave idle
-        for i, (e0, e1) in enumerate(ev):
-            st_ = streams[i % len(streams)]
-            with torch.cuda.stream(st_):
-                e0.record(st_)
-                scene.trace_primary(cam, resx, resy, out=frames[i % len(frames)], stream=st_)
-                e1.record(st_)
-    else:
-        # same sequence as DistributedRenderer.render(), with HIP events around the traversal launch
-        for e0, e1 in ev:
-            e0.record()
-            scene.trace_packets(cam, resx, resy, rnd.packet_xy, out=rnd.planes)
-            e1.record()
-            slot = rnd.step & 1
-            rnd.step += 1
-            scene.shade_depth(rnd.planes[0], out=rnd.bgr[slot])
-            work = dist.gather(rnd.bgr[slot], rnd.gathered[slot] if rank == 0 else None, dst=0, async_op=True)
-            prev, rnd.pending = rnd.pending, (work, slot)
-            if prev is not None:
-                rnd._finish(prev)
-        rnd.flush()
+    for e in ev:
+        rnd.render(cam, events=e)
+    rnd.flush()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -209,7 +182,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s (%d tris, sponza.obj stand-in) %dx%d primary rays, hit records (t,u,v,triId)" % (args.scene, hbvh.n_tris, resx, resy),
                        "rays_per_step": total_rays, "packets": "16x16 px = 1 wavefront", "bvh_nodes": hbvh.n_nodes, "bvh_depth": hbvh.depth,
-                       "bvh_build_s": round(build_s, 3), "hit_fraction": round(hit_frac, 5), "frames_in_flight": len(streams) if world == 1 else 2,
+                       "bvh_build_s": round(build_s, 3), "hit_fraction": round(hit_frac, 5), "frames_in_flight": rnd.nslots,
                        "parallelism": "tiles16x64-roundrobin-x%d + depth-shade + async RCCL gather of rgb8 tiles to rank 0" % world if world > 1 else "single-gpu"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_bytes_per_launch": tr["bytes_per_launch"] if tr else None,

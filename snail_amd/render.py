@@ -108,11 +108,14 @@ class DistributedRenderer:
     device-side shader consumes them), shades them to RGB8 with the reference's depth shading
     (Scene.shade_depth) and rank 0 gathers the RGB8 tiles -- what a render node returns in the reference
     (src/node.cpp:336-349: rgb8 per tile) -- and scatters them into the frame.  `payload="hits"` gathers the
-    16-B/px hit records instead (5.3x the bytes).  The gather of frame i is asynchronous and overlaps the
-    traversal of frame i+1 (RCCL runs on its own stream); flush() completes the last frame."""
+    16-B/px hit records instead (5.3x the bytes, synchronous).
+
+    Frames are pipelined over `slots` HIP streams (default 3 frames in flight): the traversal of frame i+1 fills the
+    CUs that frame i's heaviest packets leave idle, and the asynchronous gather of frame i (RCCL's own stream)
+    overlaps both.  flush() completes the frames still in flight."""
 
     def __init__(self, scene, resx: int, resy: int, rank: int = 0, world_size: int = 1, group=None, seed: int = 20090501,
-                 payload: str = "rgb8"):
+                 payload: str = "rgb8", slots: int = 3):
         import torch
         self.torch = torch
         self.scene = scene
@@ -121,26 +124,28 @@ class DistributedRenderer:
         self.payload = payload
         self.plan = ShardPlan.make(resx, resy, world_size, seed)
         dev = scene._dev()
-        self.frame = scene.alloc_frame(resx, resy) if (rank == 0 and (world_size == 1 or payload == "hits")) else None
-        self.frame_rgb8 = torch.zeros((resy, resx, 3), dtype=torch.uint8, device=dev) if (rank == 0 and world_size > 1 and payload == "rgb8") else None
-        self.pending = None
+        self.nslots = max(1, slots)
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.nslots)]
         self.step = 0
+        self.frames = [scene.alloc_frame(resx, resy) for _ in range(self.nslots if world_size == 1 else (1 if payload == "hits" else 0))] if rank == 0 else []
+        self.frame = self.frames[0] if self.frames else None
+        self.frame_rgb8 = torch.zeros((resy, resx, 3), dtype=torch.uint8, device=dev) if (rank == 0 and world_size > 1 and payload == "rgb8") else None
+        self.pending = [None] * self.nslots
         if world_size > 1:
             n = self.plan.padded
             self.packet_xy = torch.from_numpy(self.plan.padded_packets(rank)).to(dev)
-            # one buffer [4, n, 256] so that the four planes travel in ONE collective (payload "hits")
-            self.local = torch.empty((4, n, 256), dtype=torch.float32, device=dev)
-            self.planes = (self.local[0], self.local[1], self.local[2], self.local[3].view(torch.int32))
-            nbuf = 2  # double buffering: gather(i) overlaps trace(i+1)
-            self.bgr = [torch.empty((n, 256, 3), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+            # per slot one buffer [4, n, 256] (t, u, v, triId) so that the four planes can travel in ONE collective (payload "hits")
+            self.local = [torch.empty((4, n, 256), dtype=torch.float32, device=dev) for _ in range(self.nslots)]
+            self.planes = [(b[0], b[1], b[2], b[3].view(torch.int32)) for b in self.local]
+            self.bgr = [torch.empty((n, 256, 3), dtype=torch.uint8, device=dev) for _ in range(self.nslots)]
             if rank == 0:
                 self.all_xy = [torch.from_numpy(self.plan.padded_packets(r)).to(dev) for r in range(world_size)]
                 if payload == "hits":
-                    self.gathered = [torch.empty_like(self.local) for _ in range(world_size)]
+                    self.gathered = [[torch.empty_like(self.local[0]) for _ in range(world_size)] for _ in range(self.nslots)]
                 else:
-                    self.gathered = [[torch.empty_like(self.bgr[0]) for _ in range(world_size)] for _ in range(nbuf)]
+                    self.gathered = [[torch.empty_like(self.bgr[0]) for _ in range(world_size)] for _ in range(self.nslots)]
             else:
-                self.gathered = [None, None]
+                self.gathered = [None] * self.nslots
 
     def rays_per_frame(self) -> int:
         return self.plan.total_rays()
@@ -148,39 +153,53 @@ class DistributedRenderer:
     def local_rays(self) -> int:
         return len(self.plan.packets[self.rank]) * 256
 
-    def _finish(self, pending):
-        work, slot = pending
+    def _finish(self, slot):
+        """complete the gather issued from `slot` and (rank 0) scatter it; runs on the slot's stream"""
+        work = self.pending[slot]
+        if work is None:
+            return
+        self.pending[slot] = None
         work.wait()
         if self.rank == 0:
             for r in range(self.world):
                 self.scene.packets_bgr_to_frame(self.all_xy[r], self.gathered[slot][r], self.frame_rgb8)
 
-    def render(self, cam, stats=None):
+    def render(self, cam, stats=None, events=None):
+        """Enqueue one frame; returns immediately.  `events` = optional (start, end) torch events recorded around the
+        traversal launch on the stream it is launched on (bench.py)."""
         torch = self.torch
         import torch.distributed as dist
         sc, p = self.scene, self.plan
-        if self.world == 1:
-            return sc.trace_primary(cam, p.resx, p.resy, out=self.frame, stats=stats)
-        sc.trace_packets(cam, p.resx, p.resy, self.packet_xy, out=self.planes, stats=stats)
-        if self.payload == "hits":
-            gather_planes(self.local, self.rank, self.world, self.group, self.gathered if self.rank == 0 else None)
-            if self.rank == 0:
-                for r in range(self.world):
-                    g = self.gathered[r]
-                    sc.packets_to_frame(self.all_xy[r], (g[0], g[1], g[2], g[3].view(torch.int32)), self.frame)
-            return self.frame
-        slot = self.step & 1
+        slot = self.step % self.nslots
         self.step += 1
-        sc.shade_depth(self.planes[0], out=self.bgr[slot])
-        work = dist.gather(self.bgr[slot], self.gathered[slot] if self.rank == 0 else None, dst=0, group=self.group, async_op=True)
-        prev, self.pending = self.pending, (work, slot)
-        if prev is not None:
-            self._finish(prev)
+        st = self.streams[slot]
+        with torch.cuda.stream(st):
+            if self.world == 1:
+                if events: events[0].record(st)
+                out = sc.trace_primary(cam, p.resx, p.resy, out=self.frames[slot], stats=stats, stream=st)
+                if events: events[1].record(st)
+                return out
+            self._finish(slot)                       # the slot's buffers are free again after this
+            if events: events[0].record(st)
+            sc.trace_packets(cam, p.resx, p.resy, self.packet_xy, out=self.planes[slot], stats=stats, stream=st)
+            if events: events[1].record(st)
+            if self.payload == "hits":
+                gather_planes(self.local[slot], self.rank, self.world, self.group, self.gathered[slot] if self.rank == 0 else None)
+                if self.rank == 0:
+                    for r in range(self.world):
+                        g = self.gathered[slot][r]
+                        sc.packets_to_frame(self.all_xy[r], (g[0], g[1], g[2], g[3].view(torch.int32)), self.frame, stream=st)
+                return self.frame
+            sc.shade_depth(self.planes[slot][0], out=self.bgr[slot], stream=st)
+            self.pending[slot] = dist.gather(self.bgr[slot], self.gathered[slot] if self.rank == 0 else None, dst=0, group=self.group, async_op=True)
         return self.frame_rgb8
 
     def flush(self):
-        """Complete the in-flight gather (call after the last render() of a sequence)."""
-        if self.pending is not None:
-            self._finish(self.pending)
-            self.pending = None
+        """Complete every frame still in flight (call after the last render() of a sequence)."""
+        torch = self.torch
+        for slot in range(self.nslots):
+            with torch.cuda.stream(self.streams[slot]):
+                self._finish(slot)
+        for st in self.streams:
+            st.synchronize()
         return self.frame_rgb8 if self.frame_rgb8 is not None else self.frame
