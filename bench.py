@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--scene", default="atrium")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal only: all ranks share GPU 0 and the per-frame gather is staged through host memory")
     ap.add_argument("--streams", type=int, default=3, help="frames in flight (HIP streams); 1 = strictly serial frames")
     args = ap.parse_args()
 
@@ -113,10 +115,16 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    rehearsal = world > 1 and args.backend == "gloo"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from snail_amd import FPSCamera, HostBVH, scenes
     from snail_amd.render import DistributedRenderer
@@ -134,7 +142,7 @@ def main():
     cam = FPSCamera(pos, ang, pitch).camera()
     scene = Scene(hbvh, local_rank)
     resx, resy = frame_size_for(world)
-    rnd = DistributedRenderer(scene, resx, resy, rank, world, slots=args.streams)
+    rnd = DistributedRenderer(scene, resx, resy, rank, world, slots=args.streams, stage_cpu=rehearsal)
     total_rays = rnd.rays_per_frame() if world > 1 else resx * ((resy + 15) // 16 * 16)
 
     # ---- algorithmic bytes (outside the timed region) ----
@@ -164,7 +172,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev) / max(1, len(ev))
@@ -179,7 +187,7 @@ def main():
         out = {
             "metric": "Mrays/sec (primary)", "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: gloo, ranks share one GPU -- not a measurement)",
             "config": {"workload": "%s (%d tris, sponza.obj stand-in) %dx%d primary rays, hit records (t,u,v,triId)" % (args.scene, hbvh.n_tris, resx, resy),
                        "rays_per_step": total_rays, "packets": "16x16 px = 1 wavefront", "bvh_nodes": hbvh.n_nodes, "bvh_depth": hbvh.depth,
                        "bvh_build_s": round(build_s, 3), "hit_fraction": round(hit_frac, 5), "frames_in_flight": rnd.nslots,

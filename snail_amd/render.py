@@ -115,13 +115,16 @@ class DistributedRenderer:
     overlaps both.  flush() completes the frames still in flight."""
 
     def __init__(self, scene, resx: int, resy: int, rank: int = 0, world_size: int = 1, group=None, seed: int = 20090501,
-                 payload: str = "rgb8", slots: int = 3):
+                 payload: str = "rgb8", slots: int = 3, stage_cpu: bool = False):
         import torch
         self.torch = torch
         self.scene = scene
         self.rank, self.world = rank, world_size
         self.group = group
         self.payload = payload
+        # stage_cpu: move the payload through host memory so that a CPU backend (gloo) can carry the collective --
+        # used to rehearse the multi-rank path on a box whose ranks share one GPU; the product path is RCCL on device buffers
+        self.stage_cpu = stage_cpu
         self.plan = ShardPlan.make(resx, resy, world_size, seed)
         dev = scene._dev()
         self.nslots = max(1, slots)
@@ -191,6 +194,14 @@ class DistributedRenderer:
                         sc.packets_to_frame(self.all_xy[r], (g[0], g[1], g[2], g[3].view(torch.int32)), self.frame, stream=st)
                 return self.frame
             sc.shade_depth(self.planes[slot][0], out=self.bgr[slot], stream=st)
+            if self.stage_cpu:
+                host = self.bgr[slot].cpu()                      # synchronises the slot stream
+                glist = [torch.empty_like(host) for _ in range(self.world)] if self.rank == 0 else None
+                dist.gather(host, glist, dst=0, group=self.group)
+                if self.rank == 0:
+                    for r in range(self.world):
+                        sc.packets_bgr_to_frame(self.all_xy[r], glist[r].to(self.bgr[slot].device), self.frame_rgb8, stream=st)
+                return self.frame_rgb8
             self.pending[slot] = dist.gather(self.bgr[slot], self.gathered[slot] if self.rank == 0 else None, dst=0, group=self.group, async_op=True)
         return self.frame_rgb8
 

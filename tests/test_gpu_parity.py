@@ -368,3 +368,23 @@ def test_depth_shading_and_tile_pipeline(torch_mod):
     assert np.array_equal(b[:4], O.shade_depth(t.cpu().numpy())[:4])
     assert tuple(b[0]) == (0, 0, 0) and tuple(b[1]) == (255, 255, 255) and tuple(b[2]) == (0, 0, 0)
     sc.close()
+
+
+def test_two_rank_bench_rehearsal(torch_mod):
+    """The N>1 flow of bench.py end to end with two ranks sharing this GPU (gloo, payload staged through the host --
+    NCCL refuses two ranks on one device): plan, packet-list launches, shading, per-frame gather, rank-0 scatter,
+    JSON contract.  The RCCL transport itself is the only part not exercised."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--backend", "gloo", "--scene", "atrium:0.05"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["config"]["rays_per_step"] == (2720 // 16) * ((1528 + 15) // 16) * 256
+    assert d["config"]["hit_fraction"] > 0.5
