@@ -114,6 +114,20 @@ int snail_shade_depth_dev(const float *d_t, int nPackets, uint8_t *d_bgr, void *
 int snail_packets_bgr_to_frame_dev(const int32_t *d_packet_xy, int nPackets, int resx, int resy, const uint8_t *d_bgr,
                                    uint8_t *d_frame, int pitch, void *stream);
 
+/* Scene::RayTrace for primary packets in the reference's "simple shading" configuration, entirely on the device
+ * (BASELINE config 3: primary + one shadow packet per light): TraversePrimary<1,0>; samples (position = d*t + o,
+ * normal = triangle plane normal, diffuse = specular = color*|d.n|: src/scene_trace.cpp:359-452,
+ * src/shading/simple_material.h:14-30); per light the packet-level cull BoxPointDistanceSq(bbox of the packet's hit
+ * points) > radSq (src/scene_trace.cpp:494-501) and Scene::TraceLight (src/scene_trace.cpp:523-601): shadow-ray
+ * generation, TraverseShadow, attenuation max(0, (1-d/r)*0.2 + Inv(16 (d/r)^2) - 0.0625), diffuse += N.L*atten,
+ * specular += (N.L)^16*atten; outColor = diffuse*lDiffuse + specular*lSpecular; ConvColor -> B,G,R bytes.
+ * lights7 (HOST pointer) = nLights (<= 8) x {pos[3], color[3], radius}; d_frame_bgr = resy rows of `pitch` bytes.
+ * Shadow dir/idir of lanes the reference leaves uninitialised (misses; src/scene_trace.cpp:538-541) are zeros; they are
+ * masked (distance = -inf) and cannot influence a result.  d_stats[2] += primary rays + shadow lanes with N.L > 0. */
+#define SNAIL_MAX_LIGHTS 8
+int snail_render_whitted_dev(SnailScene *, const float cam[13], int resx, int resy, const float *lights7, int nLights,
+                             const float ambient[3], const float color[3], uint8_t *d_frame_bgr, int pitch, uint64_t *d_stats, void *stream);
+
 /* ---- measurement support ------------------------------------------------------------------------- */
 /* Single-ray, cache-less accounting walk of SURVEY.md section 8(d) over the same padded packet set as
  * snail_trace_primary: d_out[0] += rays, [1] += sum V_n (node boxes tested), [2] += sum V_t

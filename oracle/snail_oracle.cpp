@@ -581,6 +581,132 @@ void accountPrimary(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *c
 	for(int t = 0; t < threads; t++) for(int k = 0; k < 4; k++) out[k] += acc[(size_t)t * 4 + k];
 }
 
+// src/funcs.cpp:8-49
+float boxPointDistanceSq(V3 mn, V3 mx, V3 p) {
+	float sq = 0.0f, delta;
+	for(int k = 0; k < 3; k++) {
+		if(p[k] < mn[k]) { delta = p[k] - mn[k]; sq += delta * delta; }
+		else if(p[k] > mx[k]) { delta = p[k] - mx[k]; sq += delta * delta; }
+	}
+	return sq;
+}
+
+// Scene::RayTrace, simple-shading configuration, for one primary packet (see snail_oracle.h)
+template <int MODE>
+void whittedPacket(const OrcNode *nodes, const OrcTri *tris, const OrcCamera &cam, const RayGen &g, int px, int py, const float *lights7,
+				   int nLights, const float *ambient, const float *color, float (*outColor)[3] /*256*/, Stats &st) {
+	float origin[12], dir[768], idir[768], dist[256], bary[512];
+	int32_t obj[256];
+	for(int c = 0; c < 3; c++) for(int l = 0; l < 4; l++) origin[c * 4 + l] = cam.pos[c];
+	genPacket<MODE>(g, px, py, dir, idir);
+	for(int i = 0; i < 256; i++) { dist[i] = kInf; obj[i] = 0; }
+	memset(bary, 0, sizeof(bary));
+	Rays r{64, true, origin, dir, idir, nullptr};
+	st.rays += 256;
+	traversePrimary<MODE>(nodes, tris, r, dist, obj, bary, st);
+
+	// samples (src/scene_trace.cpp:366-379, 397-452; simple_material.h:19-28)
+	float pos[256][3], nrm[256][3], sdiff[256];
+	bool hit[256];
+	float mnP[3][4], mxP[3][4];
+	for(int c = 0; c < 3; c++) for(int l = 0; l < 4; l++) { mnP[c][l] = kInf; mxP[c][l] = -kInf; }
+	for(int q = 0; q < 64; q++) for(int l = 0; l < 4; l++) {
+		const int i = q * 4 + l;
+		hit[i] = dist[i] < kInf;
+		for(int c = 0; c < 3; c++) pos[i][c] = dir[q * 12 + c * 4 + l] * dist[i] + origin[c * 4 + l];
+		if(hit[i]) {
+			for(int c = 0; c < 3; c++) { mnP[c][l] = Min(mnP[c][l], pos[i][c]); mxP[c][l] = Max(mxP[c][l], pos[i][c]); }
+			const OrcTri &t = tris[obj[i]];
+			for(int c = 0; c < 3; c++) nrm[i][c] = t.plane[c];
+			V3 d{dir[q * 12 + l], dir[q * 12 + 4 + l], dir[q * 12 + 8 + l]};
+			float dn = dot(d, mk(nrm[i]));
+			sdiff[i] = dn < 0.0f ? -dn : dn;          // Abs(rays.Dir | normal); colour applied below
+		} else { nrm[i][0] = nrm[i][1] = nrm[i][2] = 0.0f; sdiff[i] = 0.0f; }
+	}
+	V3 tMin{Min(Min(mnP[0][0], mnP[0][1]), Min(mnP[0][2], mnP[0][3])), Min(Min(mnP[1][0], mnP[1][1]), Min(mnP[1][2], mnP[1][3])),
+		   Min(Min(mnP[2][0], mnP[2][1]), Min(mnP[2][2], mnP[2][3]))};
+	V3 tMax{Max(Max(mxP[0][0], mxP[0][1]), Max(mxP[0][2], mxP[0][3])), Max(Max(mxP[1][0], mxP[1][1]), Max(mxP[1][2], mxP[1][3])),
+		   Max(Max(mxP[2][0], mxP[2][1]), Max(mxP[2][2], mxP[2][3]))};
+
+	float lDiff[256][3], lSpec[256][3];
+	for(int i = 0; i < 256; i++) for(int c = 0; c < 3; c++) { lDiff[i][c] = ambient[c]; lSpec[i][c] = 0.0f; }
+
+	for(int n = 0; n < nLights; n++) {
+		const float *L = lights7 + n * 7;
+		const V3 lpos = mk(L), lcol = mk(L + 3);
+		const float radius = L[6], iRadius = 1.0f / radius, radSq = radius * radius;   // src/light.h:9-13
+		if(boxPointDistanceSq(tMin, tMax, lpos) > radSq) continue;
+
+		// Scene::TraceLight (src/scene_trace.cpp:523-601)
+		float sdir[768], sidir[768], sdist[256], distance[256], dotv[256];
+		memset(sdir, 0, sizeof(sdir)); memset(sidir, 0, sizeof(sidir));
+		for(int q = 0; q < 64; q++) {
+			bool any = hit[q * 4] || hit[q * 4 + 1] || hit[q * 4 + 2] || hit[q * 4 + 3];
+			for(int l = 0; l < 4; l++) {
+				const int i = q * 4 + l;
+				sdist[i] = -kInf; distance[i] = 0.0f; dotv[i] = 0.0f;
+				if(!any || !hit[i]) continue;         // reference: uninitialised / masked; zeros here (see header)
+				V3 lv = mk(pos[i]) - lpos;
+				if(dot(lv, lv) < 0.0001f) lv = V3{0.0f, 1.0f, 0.0f};
+				distance[i] = sqrtf(dot(lv, lv));
+				const float inv = Inv<MODE>(distance[i]);
+				V3 fl = lv * inv;
+				const float f[3] = {fl.x, fl.y, fl.z};
+				for(int c = 0; c < 3; c++) { sdir[q * 12 + c * 4 + l] = f[c]; sidir[q * 12 + c * 4 + l] = Inv<MODE>(f[c] + 0.00000001f); }
+				dotv[i] = dot(mk(nrm[i]), fl);
+				if(dotv[i] > 0.0f) { sdist[i] = distance[i] * 0.9999f; st.rays++; }
+			}
+		}
+		float lorg[12];
+		for(int c = 0; c < 3; c++) for(int l = 0; l < 4; l++) lorg[c * 4 + l] = lpos[c];
+		Rays sr{64, true, lorg, sdir, sidir, nullptr};
+		traverseShadow(nodes, tris, sr, sdist, st);
+
+		for(int i = 0; i < 256; i++) {
+			if(!(sdist[i] > 0.0f)) continue;          // += Condition(msk, ...) adds +0 otherwise
+			float atten = distance[i] * iRadius;
+			const float finv = MODE == ORC_MODE_SSE ? _mm_cvtss_f32(_mm_rcp_ps(_mm_set1_ps(16.0f * atten * atten))) : 1.0f / (16.0f * atten * atten);
+			atten = Max(0.0f, ((1.0f - atten) * 0.2f + finv) - 0.0625f);
+			const float diffMul = dotv[i] * atten;
+			float specMul = dotv[i];
+			specMul *= specMul; specMul *= specMul; specMul *= specMul; specMul *= specMul;
+			specMul *= atten;
+			const float lc[3] = {lcol.x, lcol.y, lcol.z};
+			for(int c = 0; c < 3; c++) { lDiff[i][c] += lc[c] * diffMul; lSpec[i][c] += lc[c] * specMul; }
+		}
+	}
+	for(int i = 0; i < 256; i++)
+		for(int c = 0; c < 3; c++) {
+			const float sd = color[c] * sdiff[i];     // diffuse = specular = color * |d.n| (0 for missed lanes)
+			outColor[i][c] = nLights ? sd * lDiff[i][c] + sd * lSpec[i][c] : sd;
+		}
+}
+
+template <int MODE>
+void renderWhitted(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam, int resx, int resy, const float *lights7, int nLights,
+				   const float *ambient, const float *color, uint8_t *frame, int pitch, uint64_t *stats, int threads) {
+	RayGen g = makeRayGen(*cam, resx, resy);
+	int pw = (resx + 15) / 16, ph = (resy + 15) / 16;
+	threads = std::max(threads, 1);
+	std::vector<Stats> tstats(threads);
+	parallelFor(pw * ph, threads, [&](int p, int tid) {
+		int px = (p % pw) * 16, py = (p / pw) * 16;
+		float col[256][3];
+		whittedPacket<MODE>(nodes, tris, *cam, g, px, py, lights7, nLights, ambient, color, col, tstats[tid]);
+		for(int q = 0; q < 64; q++) {
+			int yy = py + (q >> 2);
+			if(yy >= resy) continue;
+			for(int l = 0; l < 4; l++) {
+				int xx = px + (q & 3) * 4 + l;
+				if(xx >= resx) continue;
+				uint8_t *d = frame + (size_t)yy * pitch + (size_t)xx * 3;
+				for(int c = 0; c < 3; c++) d[2 - c] = (uint8_t)(int)Min(Max(col[q * 4 + l][c] * 255.0f, 0.0f), 255.0f); // r,g,b -> B,G,R
+			}
+		}
+	});
+	if(stats) for(auto &s : tstats) { stats[0] += s.intersects; stats[1] += s.iters; stats[2] += s.rays; stats[3] += s.skips; }
+}
+
 uint64_t fnv1a(uint64_t h, const void *p, size_t n) {
 	const unsigned char *b = (const unsigned char *)p;
 	for(size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001b3ull; }
@@ -687,6 +813,12 @@ void orc_shade_depth(const float *t, int n, uint8_t *bgr, int mode) {
 		for(int k = 0; k < 3; k++) q[k] = (int)Min(Max(c[k] * 255.0f, 0.0f), 255.0f); // Trunc(Clamp(..)), src/render.cpp:11-17
 		bgr[i * 3 + 0] = (uint8_t)q[2]; bgr[i * 3 + 1] = (uint8_t)q[1]; bgr[i * 3 + 2] = (uint8_t)q[0];
 	}
+}
+
+void orc_render_whitted(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam, int resx, int resy, const float *lights7, int nLights,
+						const float ambient[3], const float color[3], uint8_t *frame_bgr, int pitch, uint64_t *stats, int mode, int threads) {
+	if(mode == ORC_MODE_SSE) renderWhitted<ORC_MODE_SSE>(nodes, tris, cam, resx, resy, lights7, nLights, ambient, color, frame_bgr, pitch, stats, threads);
+	else renderWhitted<ORC_MODE_IEEE>(nodes, tris, cam, resx, resy, lights7, nLights, ambient, color, frame_bgr, pitch, stats, threads);
 }
 
 float orc_inv(float x, int mode) { return mode == ORC_MODE_SSE ? Inv<ORC_MODE_SSE>(x) : Inv<ORC_MODE_IEEE>(x); }

@@ -95,6 +95,20 @@ void orc_account_primary(const OrcNode *nodes, const OrcTri *tris, const OrcCame
 /* gVals[1] depth shading + ConvColor -> 3 bytes (B,G,R) per ray (src/scene_trace.cpp:128-137, src/render.cpp:11-17,171-198) */
 void orc_shade_depth(const float *t, int n, uint8_t *bgr, int mode);
 
+/* Scene::RayTrace for primary packets in the reference's "simple shading" configuration (no shading data, gVals all
+ * zero): TraversePrimary, samples (position = d*t + o, normal = triangle plane normal, diffuse = specular =
+ * color*|d.n|; src/scene_trace.cpp:359-452, src/shading/simple_material.h:14-30), per light the packet-level cull
+ * BoxPointDistanceSq(bbox of hit points) > radSq (src/scene_trace.cpp:494-501, src/funcs.cpp:8-49) and
+ * Scene::TraceLight = shadow-ray generation + TraverseShadow + attenuation/accumulation
+ * (src/scene_trace.cpp:523-601), outColor = diffuse*lDiffuse + specular*lSpecular, ConvColor -> B,G,R bytes
+ * (src/render.cpp:11-17,171-198).  lights = nLights x {pos[3], color[3], radius}; frame_bgr = resy rows of `pitch`
+ * bytes.  Lanes/quads the reference leaves UNINITIALISED (shadow dir/idir of missed lanes and of quads without any
+ * hit, src/scene_trace.cpp:538-541) are zeros here; they are masked (distance = -inf) and cannot influence a result.
+ * stats[4] += {intersects, iters, rays (primary + shadow lanes with N.L > 0), skips}. */
+void orc_render_whitted(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam, int resx, int resy,
+                        const float *lights7, int nLights, const float ambient[3], const float color[3],
+                        uint8_t *frame_bgr, int pitch, uint64_t *stats, int mode, int threads);
+
 /* arithmetic primitives exposed for the veclib pin test */
 float orc_inv(float x, int mode);
 float orc_rsqrt(float x, int mode);

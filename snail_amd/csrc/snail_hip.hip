@@ -596,6 +596,9 @@ __device__ __forceinline__ int classify(bool fastOK, bool laneFinite, bool live,
 	return coh ? M_COH : M_FAST;
 }
 
+__device__ __forceinline__ bool originSaneDev(const float (&o)[3]) {
+	return __builtin_fabsf(o[0]) <= 1.0e9f && __builtin_fabsf(o[1]) <= 1.0e9f && __builtin_fabsf(o[2]) <= 1.0e9f;
+}
 __device__ __forceinline__ bool finite4(const float (&v)[3][4]) {
 	bool f = true;
 #pragma unroll
@@ -740,6 +743,178 @@ __global__ __launch_bounds__(64) void k_primary(PrimaryArgs A) {
 					}
 			}
 		}
+	}
+}
+
+// ---- Scene::RayTrace, simple-shading configuration, fused per packet (primary walk + one shadow walk per light) ----
+struct WhittedArgs {
+	const uint4 *nodes, *tris;
+	GenConst g;
+	int resx, resy, pw, ph, fastOK;
+	int nLights;
+	float lights[SNAIL_MAX_LIGHTS][7];
+	float ambient[3], color[3];
+	unsigned char *frame;
+	int pitch;
+	u64 *stats;
+};
+
+__device__ __forceinline__ int convChannelW(float c) {
+	float v = c * 255.0f;
+	v = v > 0.0f ? v : 0.0f;
+	v = v < 255.0f ? v : 255.0f;
+	return (int)v;
+}
+
+template <bool DEEP>
+__global__ __launch_bounds__(64) void k_whitted(WhittedArgs A) {
+	__shared__ float lds[LDS_FLOATS_PER_WAVE];
+	const int lane = threadIdx.x & 63;
+	const int li = interleave16((int)blockIdx.x);
+	const int nrx = (A.pw + 3) >> 2;
+	const int region = li >> 4, kk = li & 15;
+	const int cx = (region % nrx) * 4 + (kk & 3), cy = (region / nrx) * 4 + (kk >> 2);
+	if(cx >= A.pw || cy >= A.ph) return;
+	const int px = cx * 16, py = cy * 16;
+	const float inf = __builtin_inff();
+
+	Quad Q;
+	const int ty = lane >> 2, k4 = lane & 3;
+#pragma unroll
+	for(int l = 0; l < 4; l++) {
+		const float xoff = (float)(px + (l >= 2 ? 2 : 0)), yoff = (float)(py - (l >= 2 ? 1 : 0));
+		const float tposx = (float)(4 * k4) + xoff, tposy = (float)ty + yoff;
+		const float p0 = A.g.tright[0] * tposx + (A.g.tup[0] * tposy + A.g.txyz[0][l]);
+		const float p1 = A.g.tright[1] * tposx + (A.g.tup[1] * tposy + A.g.txyz[1][l]);
+		const float p2 = A.g.tright[2] * tposx + (A.g.tup[2] * tposy + A.g.txyz[2][l]);
+		const float rs = 1.0f / __builtin_sqrtf(p0 * p0 + p1 * p1 + p2 * p2);
+		Q.d[0][l] = p0 * rs; Q.d[1][l] = p1 * rs; Q.d[2][l] = p2 * rs;
+#pragma unroll
+		for(int c = 0; c < 3; c++) Q.id[c][l] = 1.0f / (Q.d[c][l] + 0.00000001f);
+		Q.dist[l] = inf;
+	}
+	int tid[4] = {0, 0, 0, 0};
+	float bu[4], bv[4];
+	float org[3][4];
+#pragma unroll
+	for(int c = 0; c < 3; c++)
+#pragma unroll
+		for(int l = 0; l < 4; l++) org[c][l] = A.g.org[c];
+
+	Counters st = {0, 0, 0};
+	unsigned rays = 256u;
+	{
+		const int mode = classify(A.fastOK != 0, finite4(Q.id) && finite4(Q.d), true, Q.id);
+		if(mode == M_COH) walk<true, false, false, M_COH, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st);
+		else if(mode == M_FAST) walk<true, false, false, M_FAST, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st);
+		else walk<true, false, false, M_EXACT, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st);
+	}
+
+	// ---- samples: src/scene_trace.cpp:366-379,397-452 + SimpleMaterial::Shade_ (src/shading/simple_material.h:19-28) ----
+	bool hit[4];
+	float pos[3][4], nrm[3][4], sdiff[4];
+	float mnP[3][4], mxP[3][4];
+#pragma unroll
+	for(int l = 0; l < 4; l++) {
+		hit[l] = Q.dist[l] < inf;
+#pragma unroll
+		for(int c = 0; c < 3; c++) pos[c][l] = Q.d[c][l] * Q.dist[l] + org[c][l];
+		const Tri t = loadTriVector(A.tris, hit[l] ? tid[l] : 0);
+#pragma unroll
+		for(int c = 0; c < 3; c++) {
+			nrm[c][l] = hit[l] ? t.n[c] : 0.0f;
+			mnP[c][l] = waveMin(hit[l] ? pos[c][l] : inf);   // per SSE slot over the packet's quads (minPos/maxPos)
+			mxP[c][l] = waveMax(hit[l] ? pos[c][l] : -inf);
+		}
+		const float dn = Q.d[0][l] * nrm[0][l] + Q.d[1][l] * nrm[1][l] + Q.d[2][l] * nrm[2][l];
+		sdiff[l] = hit[l] ? __builtin_fabsf(dn) : 0.0f;
+	}
+	float tMin[3], tMax[3]; // Minimize / Maximize (src/rtbase_math.h:63-64)
+#pragma unroll
+	for(int c = 0; c < 3; c++) {
+		tMin[c] = Min<M_EXACT>(Min<M_EXACT>(mnP[c][0], mnP[c][1]), Min<M_EXACT>(mnP[c][2], mnP[c][3]));
+		tMax[c] = Max<M_EXACT>(Max<M_EXACT>(mxP[c][0], mxP[c][1]), Max<M_EXACT>(mxP[c][2], mxP[c][3]));
+	}
+
+	float lDiff[3][4], lSpec[3][4];
+#pragma unroll
+	for(int c = 0; c < 3; c++)
+#pragma unroll
+		for(int l = 0; l < 4; l++) { lDiff[c][l] = A.ambient[c]; lSpec[c][l] = 0.0f; }
+
+	for(int n = 0; n < A.nLights; n++) {
+		const float lp[3] = {A.lights[n][0], A.lights[n][1], A.lights[n][2]};
+		const float lc[3] = {A.lights[n][3], A.lights[n][4], A.lights[n][5]};
+		const float radius = A.lights[n][6], iRadius = 1.0f / radius, radSq = radius * radius;
+		{ // BoxPointDistanceSq (src/funcs.cpp:8-49), wave-uniform
+			float sq = 0.0f;
+#pragma unroll
+			for(int c = 0; c < 3; c++) {
+				if(lp[c] < tMin[c]) { const float dl = lp[c] - tMin[c]; sq += dl * dl; }
+				else if(lp[c] > tMax[c]) { const float dl = lp[c] - tMax[c]; sq += dl * dl; }
+			}
+			if(sq > radSq) continue;
+		}
+		// ---- Scene::TraceLight (src/scene_trace.cpp:523-601) ----
+		Quad S;
+		float distance[4], dotv[4];
+		float lorg[3][4];
+		unsigned cnt = 0;
+#pragma unroll
+		for(int l = 0; l < 4; l++) {
+#pragma unroll
+			for(int c = 0; c < 3; c++) { S.d[c][l] = 0.0f; S.id[c][l] = 0.0f; lorg[c][l] = lp[c]; }
+			S.dist[l] = -inf; distance[l] = 0.0f; dotv[l] = 0.0f;
+			if(hit[l]) {
+				float lv[3] = {pos[0][l] - lp[0], pos[1][l] - lp[1], pos[2][l] - lp[2]};
+				if(lv[0] * lv[0] + lv[1] * lv[1] + lv[2] * lv[2] < 0.0001f) { lv[0] = 0.0f; lv[1] = 1.0f; lv[2] = 0.0f; }
+				distance[l] = __builtin_sqrtf(lv[0] * lv[0] + lv[1] * lv[1] + lv[2] * lv[2]);
+				const float inv = 1.0f / distance[l];
+#pragma unroll
+				for(int c = 0; c < 3; c++) { S.d[c][l] = lv[c] * inv; S.id[c][l] = 1.0f / (S.d[c][l] + 0.00000001f); }
+				dotv[l] = nrm[0][l] * S.d[0][l] + nrm[1][l] * S.d[1][l] + nrm[2][l] * S.d[2][l];
+				if(dotv[l] > 0.0f) S.dist[l] = distance[l] * 0.9999f;
+			}
+			cnt += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(S.dist[l] > 0.0f));
+		}
+		rays += cnt;
+		{
+			bool fin = finite4(S.id) && finite4(S.d);
+			const int mode = classify(A.fastOK != 0 && originSaneDev(lp), fin, true, S.id);
+			int stid[4];
+			if(mode == M_COH) walk<true, false, true, M_COH, false, DEEP, false>(A.nodes, A.tris, 64, lane, lorg, S, 15u, stid, bu, bv, lds, st);
+			else if(mode == M_FAST) walk<true, false, true, M_FAST, false, DEEP, false>(A.nodes, A.tris, 64, lane, lorg, S, 15u, stid, bu, bv, lds, st);
+			else walk<true, false, true, M_EXACT, false, DEEP, false>(A.nodes, A.tris, 64, lane, lorg, S, 15u, stid, bu, bv, lds, st);
+		}
+#pragma unroll
+		for(int l = 0; l < 4; l++)
+			if(S.dist[l] > 0.0f) {
+				float atten = distance[l] * iRadius;
+				atten = Max<M_EXACT>(0.0f, ((1.0f - atten) * 0.2f + 1.0f / (16.0f * atten * atten)) - 0.0625f);
+				const float diffMul = dotv[l] * atten;
+				float specMul = dotv[l];
+				specMul *= specMul; specMul *= specMul; specMul *= specMul; specMul *= specMul;
+				specMul *= atten;
+#pragma unroll
+				for(int c = 0; c < 3; c++) { lDiff[c][l] += lc[c] * diffMul; lSpec[c][l] += lc[c] * specMul; }
+			}
+	}
+	flushStats(A.stats, st, rays, lane);
+
+	const int yy = py + ty, xx = px + k4 * 4;
+	if(yy < A.resy) {
+		unsigned char *d = A.frame + (size_t)yy * A.pitch + (size_t)xx * 3;
+#pragma unroll
+		for(int l = 0; l < 4; l++)
+			if(xx + l < A.resx) {
+				float col[3];
+#pragma unroll
+				for(int c = 0; c < 3; c++) {
+					const float sd = A.color[c] * sdiff[l];
+					col[c] = A.nLights ? sd * lDiff[c][l] + sd * lSpec[c][l] : sd;
+				}
+				d[l * 3 + 0] = (unsigned char)convChannelW(col[2]); d[l * 3 + 1] = (unsigned char)convChannelW(col[1]); d[l * 3 + 2] = (unsigned char)convChannelW(col[0]);
+			}
 	}
 }
 
@@ -1317,6 +1492,32 @@ int snail_trace_shadow(SnailScene *s, int nPackets, int size, const float *origi
 		HIP_TRY(hipMemcpy(hs, s->dStats, 32, hipMemcpyDeviceToHost));
 		for(int k = 0; k < 4; k++) stats[k] += hs[k];
 	}
+	return 0;
+}
+
+int snail_render_whitted_dev(SnailScene *s, const float cam[13], int resx, int resy, const float *lights7, int nLights, const float ambient[3],
+							 const float color[3], uint8_t *frame, int pitch, uint64_t *dStats, void *stream) {
+	if(int rc = checkScene(s, "snail_render_whitted_dev")) return rc;
+	if(resx <= 0 || resy <= 0 || !frame || pitch < resx * 3 || nLights < 0 || nLights > SNAIL_MAX_LIGHTS || (nLights && !lights7) || !ambient || !color) {
+		snail_set_error("snail_render_whitted_dev: bad arguments (at most %d lights)", SNAIL_MAX_LIGHTS);
+		return 1;
+	}
+	DeviceGuard guard(s->device);
+	dev::WhittedArgs A;
+	memset(&A, 0, sizeof(A));
+	A.nodes = s->dNodes; A.tris = s->dTris;
+	A.g = makeGen(cam, resx, resy);
+	A.resx = resx; A.resy = resy; A.pw = (resx + 15) / 16; A.ph = (resy + 15) / 16;
+	A.fastOK = s->fastOK && originSane(cam);
+	A.nLights = nLights;
+	for(int n = 0; n < nLights; n++) for(int k = 0; k < 7; k++) A.lights[n][k] = lights7[n * 7 + k];
+	for(int c = 0; c < 3; c++) { A.ambient[c] = ambient[c]; A.color[c] = color[c]; }
+	A.frame = frame; A.pitch = pitch; A.stats = (dev::u64 *)dStats;
+	const int nRegions = ((A.pw + 3) / 4) * ((A.ph + 3) / 4);
+	const int blocks = ((nRegions + 7) / 8) * 8 * 16;
+	if(s->depth > 62) hipLaunchKernelGGL(dev::k_whitted<true>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, A);
+	else hipLaunchKernelGGL(dev::k_whitted<false>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, A);
+	HIP_TRY(hipGetLastError());
 	return 0;
 }
 

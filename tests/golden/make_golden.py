@@ -114,8 +114,30 @@ def oracle_packets():
     print("oracle_packets_atrium_005.npz written")
 
 
+def whitted_lights(osc, cam, nl):
+    bmin, bmax = osc.nodes[0]["bmin"], osc.nodes[0]["bmax"]
+    c, e = (bmin + bmax) * 0.5, (bmax - bmin)
+    return np.array([[c[0], c[1] + 0.35 * e[1], c[2], 1.0, 0.9, 0.8, 2.0 * float(e.max())],
+                     [c[0] - 0.3 * e[0], c[1] + 0.1 * e[1], c[2] + 0.2 * e[2], 0.3, 0.5, 1.0, 0.6 * float(e.max())],
+                     [cam.pos[0], cam.pos[1], cam.pos[2], 0.6, 0.6, 0.6, 0.25 * float(e.max())]], dtype=np.float32)[:nl]
+
+
+def oracle_whitted():
+    """BASELINE config 3 (primary + shadow packets, simple shading) on atrium:0.05: rgb8 frame digest + counters."""
+    name, resx, resy = "atrium:0.05", 640, 368
+    tv, hb, osc = util.scene_pair(name)
+    cam = util.camera_for(name, tv)
+    lights = whitted_lights(osc, cam, 2)
+    frame, st = osc.render_whitted(cam.as_array13(), resx, resy, lights, mode=O.MODE_IEEE)
+    json.dump({"scene": name, "res": [resx, resy], "lights": lights.tolist(), "sha_bgr": sha(frame), "stats": [int(x) for x in st],
+               "mean_bgr": [float(x) for x in frame.reshape(-1, 3).mean(axis=0)]}, open(os.path.join(HERE, "oracle_whitted.json"), "w"), indent=1)
+    np.savez_compressed(os.path.join(HERE, "oracle_whitted_samples.npz"), bgr=frame[::8, ::8])
+    print("oracle_whitted.json written")
+
+
 if __name__ == "__main__":
     veclib_prims()
     survey_digests()
     oracle_frames()
     oracle_packets()
+    oracle_whitted()

@@ -46,6 +46,7 @@ def lib():
         L.orc_render_primary.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, u64p, i32, i32]
         L.orc_account_primary.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, u64p, i32, i32]
         L.orc_shade_depth.argtypes = [vp, i32, vp, i32]
+        L.orc_render_whitted.argtypes = [vp, vp, vp, i32, i32, vp, i32, vp, vp, vp, i32, u64p, i32, i32]
         for f in (L.orc_inv, L.orc_rsqrt):
             f.argtypes = [C.c_float, i32]
             f.restype = C.c_float
@@ -104,6 +105,16 @@ class OracleScene:
         out = np.zeros(4, dtype=np.uint64)
         lib().orc_account_primary(_p(self.nodes), _p(self.tris), _p(cam), resx, resy, x0, y0, w, h, _p(out), mode, threads)
         return out
+
+    def render_whitted(self, cam13, resx, resy, lights7, ambient=(0.1, 0.1, 0.1), color=(1.0, 1.0, 1.0), mode=MODE_IEEE, threads=8):
+        cam = np.ascontiguousarray(cam13, dtype=np.float32)
+        lights = np.ascontiguousarray(lights7, dtype=np.float32).reshape(-1, 7)
+        amb = np.asarray(ambient, dtype=np.float32); col = np.asarray(color, dtype=np.float32)
+        frame = np.zeros((resy, resx, 3), dtype=np.uint8)
+        stats = np.zeros(4, dtype=np.uint64)
+        lib().orc_render_whitted(_p(self.nodes), _p(self.tris), _p(cam), resx, resy, _p(lights), len(lights), _p(amb), _p(col), _p(frame), resx * 3,
+                                 _p(stats), mode, threads)
+        return frame, stats
 
     def trace_rays(self, origin, dir, idir, mask, distance, obj, bary, npackets, size, shared, mode=MODE_IEEE):
         stats = np.zeros(4, dtype=np.uint64)

@@ -388,3 +388,44 @@ def test_two_rank_bench_rehearsal(torch_mod):
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["config"]["rays_per_step"] == (2720 // 16) * ((1528 + 15) // 16) * 256
     assert d["config"]["hit_fraction"] > 0.5
+
+
+@pytest.mark.parametrize("name,resx,resy,nl", [("atrium:0.05", 640, 368, 2), ("atrium:0.05", 250, 130, 1), ("box", 256, 256, 1), ("stress:0.05", 320, 192, 3),
+                                                ("atrium:0.05", 320, 192, 0)])
+def test_whitted_primary_plus_shadow_bit_exact(torch_mod, name, resx, resy, nl):
+    """BASELINE config 3 (primary + one shadow packet per point light), fused on the device: the rgb8 frame and the
+    TreeStats counters (incl. the traced-ray count = primary + shadow lanes with N.L > 0) equal the oracle's
+    Scene::RayTrace restatement byte for byte."""
+    tv, sc, osc = gpu_scene(name)
+    cam = util.camera_for(name, tv)
+    bmin, bmax = osc.nodes[0]["bmin"], osc.nodes[0]["bmax"]
+    c, e = (bmin + bmax) * 0.5, (bmax - bmin)
+    lights = np.array([[c[0], c[1] + 0.35 * e[1], c[2], 1.0, 0.9, 0.8, 2.0 * float(e.max())],
+                       [c[0] - 0.3 * e[0], c[1] + 0.1 * e[1], c[2] + 0.2 * e[2], 0.3, 0.5, 1.0, 0.6 * float(e.max())],
+                       [cam.pos[0], cam.pos[1], cam.pos[2], 0.6, 0.6, 0.6, 0.25 * float(e.max())]], dtype=np.float32)[:nl]
+    want, wst = osc.render_whitted(cam.as_array13(), resx, resy, lights, mode=O.MODE_IEEE)
+    stats = sc.new_stats()
+    got = sc.render_whitted(cam, resx, resy, lights, stats=stats)
+    torch_mod.cuda.synchronize()
+    g = got.cpu().numpy()
+    assert np.array_equal(g, want), (int((g != want).sum()), g.shape)
+    assert np.array_equal(stats.cpu().numpy().astype(np.uint64), wst), (stats.cpu().numpy(), wst)
+    assert want.max() > 0
+    if nl and name != "box":                          # (the box's lights sit inside the cube: no lane has N.L > 0)
+        assert wst[2] > ((resx + 15) // 16) * ((resy + 15) // 16) * 256        # shadow rays were traced
+    sc.close()
+
+
+def test_whitted_against_committed_fixture(torch_mod):
+    import hashlib
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_whitted.json")))
+    tv, sc, osc = gpu_scene(g["scene"])
+    cam = util.camera_for(g["scene"], tv)
+    stats = sc.new_stats()
+    fr = sc.render_whitted(cam, g["res"][0], g["res"][1], np.asarray(g["lights"], dtype=np.float32), stats=stats)
+    torch_mod.cuda.synchronize()
+    assert hashlib.sha256(fr.cpu().numpy().tobytes()).hexdigest() == g["sha_bgr"]
+    assert stats.cpu().numpy().tolist() == g["stats"]
+    sc.close()
