@@ -429,3 +429,39 @@ def test_whitted_against_committed_fixture(torch_mod):
     assert hashlib.sha256(fr.cpu().numpy().tobytes()).hexdigest() == g["sha_bgr"]
     assert stats.cpu().numpy().tolist() == g["stats"]
     sc.close()
+
+
+def test_config4_4k_frame_via_tile_plan(torch_mod):
+    """BASELINE config 4 size (3840x2160), traced as eight rank-shards of the reference's 16x64 tiles one after the
+    other on this GPU and reassembled; hit records bit-exact vs the oracle frame."""
+    from snail_amd import render as R
+    name = "atrium"
+    tv, sc, osc = gpu_scene(name)
+    cam = util.camera_for(name, tv)
+    resx, resy = 3840, 2160
+    ref = osc.render_primary(cam.as_array13(), resx, resy, mode=O.MODE_IEEE, threads=16)
+    plan = R.ShardPlan.make(resx, resy, 8)
+    frame = sc.alloc_frame(resx, resy)
+    for r in range(8):
+        xy = torch_mod.from_numpy(plan.padded_packets(r)).cuda()
+        planes = sc.trace_packets(cam, resx, resy, xy)
+        sc.packets_to_frame(xy, planes, frame)
+    torch_mod.cuda.synchronize()
+    compare_frames(frame, ref, "atrium 3840x2160 (8 shards)")
+    sc.close()
+
+
+def test_config5_stress_1m_full_size(torch_mod):
+    """BASELINE config 5 scene class: ~1 M triangles (stress), 1920x1080, deep tree; bit-exact vs the oracle."""
+    name = "stress"
+    tv, sc, osc = gpu_scene(name)
+    assert len(tv) > 900000
+    cam = util.camera_for(name, tv)
+    stats = sc.new_stats()
+    frame = sc.trace_primary(cam, 1920, 1080, stats=stats)
+    torch_mod.cuda.synchronize()
+    ref = osc.render_primary(cam.as_array13(), 1920, 1080, mode=O.MODE_IEEE, threads=16)
+    compare_frames(frame, ref, "stress-1M 1920x1080")
+    assert np.array_equal(stats.cpu().numpy().astype(np.uint64), ref[4])
+    assert np.isfinite(ref[0]).mean() > 0.5
+    sc.close()
