@@ -319,8 +319,10 @@ __device__ __forceinline__ TriTerms triTerms(const Tri &t, float ox, float oy, f
 // BARY   : keep barycentrics up to date in registers (else the caller derives them from the final triId)
 // DEEP   : scene depth > 62, stack slots >= 64 live in a second VGPR pair
 // DISTPOS: every lane's distance is >= 0 on entry (primary packets) -> single-compare slab test
+// OCT    : M_COH only: the packet's sign octant as a compile-time constant (0..7; bit k = idir negative on axis k), so that
+//          the near/far plane choice costs nothing at run time; -1 = decide per node with a scalar XOR-swap
 // Stack: lane i of (stkNode, stkFL) is slot i.
-template <bool SHARED, bool MASK, bool SHADOW, int M, bool BARY, bool DEEP, bool DISTPOS>
+template <bool SHARED, bool MASK, bool SHADOW, int M, bool BARY, bool DEEP, bool DISTPOS, int OCT = -1>
 __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint4 *__restrict__ tris, int size, int lane,
 									 const float (&org)[3][4] /* SHARED: [c][0] uniform */, Quad &Q, unsigned mask4, int (&tid)[4],
 									 float (&bu)[4], float (&bv)[4], float *lds, Counters &st) {
@@ -404,9 +406,13 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				float pn[3], pf[3];
 #pragma unroll
 				for(int k = 0; k < 3; k++) {
-					const int lo = __float_as_int(n.bmin[k]), hi = __float_as_int(n.bmax[k]);
-					const int sw = (lo ^ hi) & octMask[k];
-					pn[k] = __int_as_float(lo ^ sw); pf[k] = __int_as_float(hi ^ sw);
+					if(OCT >= 0) { // compile-time octant: the scalar unit (one per CU, the scarcest issue resource of this kernel) does nothing
+						pn[k] = ((OCT >> k) & 1) ? n.bmax[k] : n.bmin[k]; pf[k] = ((OCT >> k) & 1) ? n.bmin[k] : n.bmax[k];
+					} else {
+						const int lo = __float_as_int(n.bmin[k]), hi = __float_as_int(n.bmax[k]);
+						const int sw = (lo ^ hi) & octMask[k];
+						pn[k] = __int_as_float(lo ^ sw); pf[k] = __int_as_float(hi ^ sw);
+					}
 					if(SHARED) { pn[k] = pn[k] - org[k][0]; pf[k] = pf[k] - org[k][0]; }
 				}
 #pragma unroll
@@ -441,9 +447,10 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 			if(DISTPOS) { // dist >= 0 on every lane (primary packets): lmax>=0 && lmin<=lmax && lmin<=dist  <=>  max(lmin,0) <= min(lmax,dist)
 #pragma unroll
 				for(int l = 0; l < 4; l++) { tn[l] = vmax(tn[l], 0.0f); tf[l] = vmin(tf[l], Q.dist[l]); }
-				// each compare IS a lane mask in an SGPR pair; OR them on the scalar unit (no bool -> VGPR -> ballot detour)
-				passMask = __builtin_amdgcn_ballot_w64(tn[0] <= tf[0]) | __builtin_amdgcn_ballot_w64(tn[1] <= tf[1]) |
-						   __builtin_amdgcn_ballot_w64(tn[2] <= tf[2]) | __builtin_amdgcn_ballot_w64(tn[3] <= tf[3]);
+				// any lane with tn <= tf  <=>  max_l (tf_l - tn_l) >= 0: both operands are finite here and fp32 denormals are on
+				// (.amdhsa_float_denorm_mode_32 3), so the sign of the difference is exact -- ONE compare, nothing for the scalar unit to OR
+				const float slack = vmax3(tf[0] - tn[0], tf[1] - tn[1], vmax(tf[2] - tn[2], tf[3] - tn[3]));
+				passMask = __builtin_amdgcn_ballot_w64(slack >= 0.0f);
 			} else {
 #pragma unroll
 				for(int l = 0; l < 4; l++)
@@ -651,7 +658,7 @@ __device__ __forceinline__ int interleave16(int b) { // -> logical index; 16 con
 }
 
 template <bool DEEP>
-__global__ __launch_bounds__(64) void k_primary(PrimaryArgs A) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_primary(PrimaryArgs A) {
 	__shared__ float ldsAll[1][LDS_FLOATS_PER_WAVE];
 	const int lane = threadIdx.x & 63;
 	const int wave = 0;
@@ -704,8 +711,15 @@ __global__ __launch_bounds__(64) void k_primary(PrimaryArgs A) {
 
 	Counters st = {0, 0, 0};
 	const int mode = classify(A.fastOK != 0, finite4(Q.id) && finite4(Q.d), true, Q.id);
-	if(mode == M_COH) walk<true, false, false, M_COH, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
-	else if(mode == M_FAST) walk<true, false, false, M_FAST, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
+	if(mode == M_COH) {
+		const int oct = __builtin_amdgcn_readfirstlane(((__float_as_int(Q.id[0][0]) >> 31) & 1) | ((__float_as_int(Q.id[1][0]) >> 31) & 2) | ((__float_as_int(Q.id[2][0]) >> 31) & 4));
+#define SNAIL_WALK_OCT(O) walk<true, false, false, M_COH, false, DEEP, true, O>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st)
+		switch(oct) { // one specialised walk per sign octant, chosen once per packet
+		case 0: SNAIL_WALK_OCT(0); break; case 1: SNAIL_WALK_OCT(1); break; case 2: SNAIL_WALK_OCT(2); break; case 3: SNAIL_WALK_OCT(3); break;
+		case 4: SNAIL_WALK_OCT(4); break; case 5: SNAIL_WALK_OCT(5); break; case 6: SNAIL_WALK_OCT(6); break; default: SNAIL_WALK_OCT(7); break;
+		}
+#undef SNAIL_WALK_OCT
+	} else if(mode == M_FAST) walk<true, false, false, M_FAST, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
 	else walk<true, false, false, M_EXACT, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
 	finalBarycentrics(A.tris, org, Q, tid, bu, bv);
 
