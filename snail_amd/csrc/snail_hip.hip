@@ -75,9 +75,12 @@ struct Node {
 __device__ __forceinline__ float asf(unsigned u) { return __uint_as_float(u); }
 __device__ __forceinline__ float asf(int u) { return __int_as_float(u); }
 
-// one 32-B record, wave-uniform index -> two s_load_dwordx4 (merged to x8 by the backend)
+// one 32-B record, wave-uniform index -> s_load_dwordx8.  The byte offset is formed in 32 bits (the node array is
+// < 4 GiB) so that the scalar unit spends one shift, not a 64-bit shift/add chain, per fetch.
+typedef const __attribute__((address_space(4))) char *scalar_bytes;
 __device__ __forceinline__ Node loadNode(const uint4 *nodes, int idx) {
-	scalar_ptr p = (scalar_ptr)(unsigned long long)(nodes + (size_t)idx * 2);
+	const unsigned off = (unsigned)idx << 5;
+	scalar_ptr p = (scalar_ptr)((scalar_bytes)(unsigned long long)nodes + off);
 	u32x4 a = p[0], b = p[1];
 	Node n;
 	n.bmin[0] = asf(a.x); n.bmin[1] = asf(a.y); n.bmin[2] = asf(a.z);
@@ -457,7 +460,9 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 					passMask |= __builtin_amdgcn_ballot_w64(tf[l] >= 0.0f) & __builtin_amdgcn_ballot_w64(tn[l] <= tf[l]) & __builtin_amdgcn_ballot_w64(tn[l] <= Q.dist[l]);
 			}
 		}
-		const u64 alive = passMask & rangeMask(first, last);
+		// clip to the quad range [first,last]: (lane - first) <= (last - first) as ONE unsigned VALU compare -- the scalar unit
+		// (shared by the CU's four SIMDs, and the busiest unit of this kernel) would need five instructions for the same mask
+		const u64 alive = passMask & __builtin_amdgcn_ballot_w64((unsigned)(lane - first) <= (unsigned)(last - first));
 		if(alive != 0) {
 			first = __builtin_ctzll(alive);
 			last = 63 - __builtin_clzll(alive);
