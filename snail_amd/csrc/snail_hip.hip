@@ -646,6 +646,7 @@ struct PrimaryArgs {
 	int *id;
 	u64 *stats;
 	unsigned *cost; // diagnostic: per packet {iters, intersects, shader cycles, start time low bits}
+	int *defer;		// [0] = count, [1] = finished blocks of the M_EXACT pass, [2..] = logical indices of deferred packets
 };
 
 #define WAVES_PER_BLOCK 4
@@ -662,12 +663,13 @@ __device__ __forceinline__ int interleave16(int b) { // -> logical index; 16 con
 	return (((j >> 4) << 3) + xcd) * 16 + (j & 15);
 }
 
-template <bool DEEP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_primary(PrimaryArgs A) {
-	__shared__ float ldsAll[1][LDS_FLOATS_PER_WAVE];
+// One primary packet.  EXACTPASS=false: the main kernel -- M_COH (one specialised walk per sign octant) and M_FAST;
+// a packet that needs M_EXACT (a non-finite reciprocal: practically never for camera rays) is appended to A.defer and
+// left to the second, tiny kernel (EXACTPASS=true).  Keeping the select-based M_EXACT walk out of the main kernel
+// takes its register allocation from 128 to 84-96 VGPRs, i.e. from 4 to 5 waves per SIMD.
+template <bool DEEP, bool EXACTPASS>
+__device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li, float *lds) {
 	const int lane = threadIdx.x & 63;
-	const int wave = 0;
-	const int li = interleave16((int)blockIdx.x);
 
 	int px, py, pidx;
 	if(A.packetXY) {
@@ -716,16 +718,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
 
 	Counters st = {0, 0, 0};
 	const int mode = classify(A.fastOK != 0, finite4(Q.id) && finite4(Q.d), true, Q.id);
-	if(mode == M_COH) {
+	if(EXACTPASS) walk<true, false, false, M_EXACT, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st);
+	else if(mode == M_EXACT) {
+		if(lane == 0) A.defer[2 + atomicAdd(&A.defer[0], 1)] = li;
+		return;
+	} else if(mode == M_COH) {
 		const int oct = __builtin_amdgcn_readfirstlane(((__float_as_int(Q.id[0][0]) >> 31) & 1) | ((__float_as_int(Q.id[1][0]) >> 31) & 2) | ((__float_as_int(Q.id[2][0]) >> 31) & 4));
-#define SNAIL_WALK_OCT(O) walk<true, false, false, M_COH, false, DEEP, true, O>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st)
+#define SNAIL_WALK_OCT(O) walk<true, false, false, M_COH, false, DEEP, true, O>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st)
 		switch(oct) { // one specialised walk per sign octant, chosen once per packet
 		case 0: SNAIL_WALK_OCT(0); break; case 1: SNAIL_WALK_OCT(1); break; case 2: SNAIL_WALK_OCT(2); break; case 3: SNAIL_WALK_OCT(3); break;
 		case 4: SNAIL_WALK_OCT(4); break; case 5: SNAIL_WALK_OCT(5); break; case 6: SNAIL_WALK_OCT(6); break; default: SNAIL_WALK_OCT(7); break;
 		}
 #undef SNAIL_WALK_OCT
-	} else if(mode == M_FAST) walk<true, false, false, M_FAST, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
-	else walk<true, false, false, M_EXACT, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
+	} else walk<true, false, false, M_FAST, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st);
 	finalBarycentrics(A.tris, org, Q, tid, bu, bv);
 
 	flushStats(A.stats, st, 256u, lane);
@@ -763,6 +768,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
 			}
 		}
 	}
+}
+
+template <bool DEEP>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_primary(PrimaryArgs A) {
+	__shared__ float lds[LDS_FLOATS_PER_WAVE];
+	primaryPacket<DEEP, false>(A, interleave16((int)blockIdx.x), lds);
+}
+
+// the deferred M_EXACT packets (grid-stride over the list; the last block to finish re-arms the list for its next use)
+template <bool DEEP>
+__global__ __launch_bounds__(64) void k_primary_exact(PrimaryArgs A) {
+	__shared__ float lds[LDS_FLOATS_PER_WAVE];
+	const int n = __builtin_amdgcn_readfirstlane(A.defer[0]);
+	for(int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) primaryPacket<DEEP, true>(A, __builtin_amdgcn_readfirstlane(A.defer[2 + i]), lds);
+	__threadfence();
+	if((threadIdx.x & 63) == 0 && atomicAdd(&A.defer[1], 1) == (int)gridDim.x - 1) { A.defer[0] = 0; A.defer[1] = 0; }
 }
 
 // ---- Scene::RayTrace, simple-shading configuration, fused per packet (primary walk + one shadow walk per light) ----
@@ -1189,6 +1210,10 @@ struct SnailScene {
 	int fastOK = 0; // every triangle record finite and of sane magnitude (see file header)
 	int lastBlocks = 0, lastThreads = 0;
 	unsigned long long *dStats = nullptr; // 4 x u64 scratch for the host-pointer entry points
+	enum { kDeferSlots = 8 };
+	int *dDefer[kDeferSlots] = {};        // deferred-packet lists, one per launch in flight (round-robin)
+	int deferCap = 0;
+	unsigned launchCount = 0;
 };
 
 namespace {
@@ -1267,10 +1292,28 @@ int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0
 	}
 	A.nBlocks = blocks;
 	s->lastBlocks = blocks; s->lastThreads = 64;
+	// deferred-packet list of this launch (re-allocated, synchronously, only when a larger frame than ever before arrives)
+	if(blocks + 2 > s->deferCap) {
+		HIP_TRY(hipDeviceSynchronize());
+		for(int k = 0; k < SnailScene::kDeferSlots; k++) {
+			if(s->dDefer[k]) (void)hipFree(s->dDefer[k]);
+			s->dDefer[k] = nullptr;
+			HIP_TRY(hipMalloc((void **)&s->dDefer[k], (size_t)(blocks + 2) * sizeof(int)));
+			HIP_TRY(hipMemset(s->dDefer[k], 0, 2 * sizeof(int)));
+		}
+		s->deferCap = blocks + 2;
+	}
+	A.defer = s->dDefer[s->launchCount++ % SnailScene::kDeferSlots];
 	// SNAIL_DEBUG_DYNLDS=<bytes>: occupancy experiments only (unused dynamic LDS limits waves per CU)
 	static const int dynLds = getenv("SNAIL_DEBUG_DYNLDS") ? atoi(getenv("SNAIL_DEBUG_DYNLDS")) : 0;
-	if(s->depth > 62) hipLaunchKernelGGL(dev::k_primary<true>, dim3(blocks), dim3(64), dynLds, stream, A);
-	else hipLaunchKernelGGL(dev::k_primary<false>, dim3(blocks), dim3(64), dynLds, stream, A);
+	const int exactBlocks = blocks < 256 ? blocks : 256;
+	if(s->depth > 62) {
+		hipLaunchKernelGGL(dev::k_primary<true>, dim3(blocks), dim3(64), dynLds, stream, A);
+		hipLaunchKernelGGL(dev::k_primary_exact<true>, dim3(exactBlocks), dim3(64), 0, stream, A);
+	} else {
+		hipLaunchKernelGGL(dev::k_primary<false>, dim3(blocks), dim3(64), dynLds, stream, A);
+		hipLaunchKernelGGL(dev::k_primary_exact<false>, dim3(exactBlocks), dim3(64), 0, stream, A);
+	}
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
@@ -1338,6 +1381,7 @@ void snail_scene_destroy(SnailScene *s) {
 	if(s->dNodes) (void)hipFree(s->dNodes);
 	if(s->dTris) (void)hipFree(s->dTris);
 	if(s->dStats) (void)hipFree(s->dStats);
+	for(int k = 0; k < SnailScene::kDeferSlots; k++) if(s->dDefer[k]) (void)hipFree(s->dDefer[k]);
 	delete s;
 }
 

@@ -465,3 +465,31 @@ def test_config5_stress_1m_full_size(torch_mod):
     assert np.array_equal(stats.cpu().numpy().astype(np.uint64), ref[4])
     assert np.isfinite(ref[0]).mean() > 0.5
     sc.close()
+
+
+def test_exact_mode_primary_frame_with_degenerate_triangles(torch_mod):
+    """A scene holding zero-area triangles (t0 = 0, it0 = inf, NaN normal: what the reference gets when Repair's
+    1e-8 threshold lets one through) disables the FAST/COH arithmetic for the whole scene: every primary packet
+    is deferred to the M_EXACT kernel (select-based Min/Max, interval culls).  Results must still be the oracle's, bit for bit."""
+    from snail_amd import HostBVH, scenes, survey_camera
+    from snail_amd.scene import Scene
+    tv = scenes.box_scene()
+    p = np.array([[0.2, 0.3, -0.5]] * 3, dtype=np.float32)          # a point-triangle inside the cube
+    q = np.array([[-0.4, 0.1, 0.2], [0.4, 0.1, 0.2], [0.0, 0.1, 0.2]], dtype=np.float32)   # collinear
+    tv2 = np.concatenate([tv, p[None], q[None]], axis=0)
+    hb, osc = HostBVH.build(tv2), O.OracleScene(tv2)
+    assert hb.nodes.tobytes() == osc.nodes.tobytes()
+    assert not np.isfinite(hb.tris["it0"]).all()
+    cam = survey_camera(tv)
+    sc = Scene(hb, 0)
+    stats = sc.new_stats()
+    frame = sc.trace_primary(cam, 256, 256, stats=stats)
+    torch_mod.cuda.synchronize()
+    ref = osc.render_primary(cam.as_array13(), 256, 256, mode=O.MODE_IEEE)
+    compare_frames(frame, ref, "box + degenerate triangles (M_EXACT)")
+    assert np.array_equal(stats.cpu().numpy().astype(np.uint64), ref[4])
+    # a second launch reuses the re-armed deferred-packet list
+    frame2 = sc.trace_primary(cam, 256, 256)
+    torch_mod.cuda.synchronize()
+    compare_frames(frame2, ref, "second launch")
+    sc.close()
