@@ -341,7 +341,11 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				for(int l = 0; l < 4; l++) act4 |= (Q.dist[l] >= 0.0f ? 1u : 0u) << l;
 		} else if(MASK) act4 = lane < size ? (mask4 & 15u) : 0u;
 		computeMinMax<EXACT, (MASK || SHADOW)>(Q.d, act4, size, lane, lds, iv.minDir, iv.maxDir);
-		computeMinMax<EXACT, (MASK || SHADOW)>(Q.id, act4, size, lane, lds, iv.minIDir, iv.maxIDir);
+		if(EXACT) computeMinMax<EXACT, (MASK || SHADOW)>(Q.id, act4, size, lane, lds, iv.minIDir, iv.maxIDir);   // only BBox::TestInterval reads it
+		else {
+#pragma unroll
+			for(int k = 0; k < 3; k++) iv.minIDir[k] = iv.maxIDir[k] = 0.0f;
+		}
 		if(SHARED) {
 #pragma unroll
 			for(int k = 0; k < 3; k++) iv.minOrg[k] = iv.maxOrg[k] = org[k][0];
