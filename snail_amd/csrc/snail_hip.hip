@@ -1310,7 +1310,8 @@ int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0
 	A.defer = s->dDefer[s->launchCount++ % SnailScene::kDeferSlots];
 	// SNAIL_DEBUG_DYNLDS=<bytes>: occupancy experiments only (unused dynamic LDS limits waves per CU)
 	static const int dynLds = getenv("SNAIL_DEBUG_DYNLDS") ? atoi(getenv("SNAIL_DEBUG_DYNLDS")) : 0;
-	const int exactBlocks = blocks < 256 ? blocks : 256;
+	// a scene with sane records defers (practically) nothing: a handful of blocks suffices; an unsafe scene defers every packet
+	const int exactBlocks = A.fastOK ? (blocks < 8 ? blocks : 8) : (blocks < 2048 ? blocks : 2048);
 	if(s->depth > 62) {
 		hipLaunchKernelGGL(dev::k_primary<true>, dim3(blocks), dim3(64), dynLds, stream, A);
 		hipLaunchKernelGGL(dev::k_primary_exact<true>, dim3(exactBlocks), dim3(64), 0, stream, A);
