@@ -131,15 +131,17 @@ def main():
     from snail_amd.scene import Scene
 
     # ---- scene (host build, once; replicated into every GPU's HBM) ----
-    tv = scenes.scene_by_name(args.scene)
+    tv = scenes.scene_by_name(args.scene, scenes_dir=os.path.join(ROOT, "scenes"))
     t0 = time.perf_counter()
     hbvh = HostBVH.build(tv)
     build_s = time.perf_counter() - t0
     if args.scene.startswith("stress"):
-        pos, ang, pitch = scenes.stress_camera()
-    else:
-        pos, ang, pitch = scenes.atrium_camera()
-    cam = FPSCamera(pos, ang, pitch).camera()
+        cam = FPSCamera(*scenes.stress_camera()).camera()
+    elif args.scene.startswith("atrium"):
+        cam = FPSCamera(*scenes.atrium_camera()).camera()
+    else:   # an OBJ dropped into scenes/ (e.g. the real sponza.obj): the survey's far camera looking at the whole model
+        from snail_amd import survey_camera
+        cam = survey_camera(tv)
     scene = Scene(hbvh, local_rank)
     resx, resy = frame_size_for(world)
     rnd = DistributedRenderer(scene, resx, resy, rank, world, slots=args.streams, stage_cpu=rehearsal)
