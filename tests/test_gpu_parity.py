@@ -184,12 +184,16 @@ def test_trace_rays_bit_exact(torch_mod, shared, masked, size, poison):
     sc.close()
 
 
-@pytest.mark.parametrize("size", [64, 16])
-def test_trace_shadow_bit_exact(torch_mod, size):
+@pytest.mark.parametrize("size,poison", [(64, False), (16, False), (64, True)])
+def test_trace_shadow_bit_exact(torch_mod, size, poison):
     name = "atrium:0.05"
     tv, sc, osc = gpu_scene(name)
     npk = 32
     origin, dirs, idir, dist = util.shadow_packets(osc, npk, seed=5, size=size)
+    if poison:   # SafeInv singularity (dir == -1e-8 -> idir = inf) and axis-parallel rays: the M_EXACT shadow walk,
+        # including ComputeMinMax's distance-mask variant (src/rtbase.cpp:99-121) on packets with NaN-producing lanes
+        dirs[3, 0:4] = np.float32(-0.00000001); dirs[70, 4:8] = 0.0; dirs[200, 8:12] = np.float32(-0.00000001)
+        idir = (np.float32(1.0) / (dirs + np.float32(0.00000001))).astype(np.float32)
     d2 = dist.copy()
     ost = osc.trace_shadow(origin, dirs, idir, d2, npk, size)
     from snail_amd.scene import ShadowContext
