@@ -146,7 +146,11 @@ class DistributedRenderer:
                 if payload == "hits":
                     self.gathered = [[torch.empty_like(self.local[0]) for _ in range(world_size)] for _ in range(self.nslots)]
                 else:
-                    self.gathered = [[torch.empty_like(self.bgr[0]) for _ in range(world_size)] for _ in range(self.nslots)]
+                    # ONE contiguous receive buffer per slot, handed to the collective as per-rank views, so that rank 0
+                    # scatters all ranks' tiles with a single launch over the concatenated packet list
+                    self.gathered_all = [torch.empty((world_size, n, 256, 3), dtype=torch.uint8, device=dev) for _ in range(self.nslots)]
+                    self.gathered = [[g[r] for r in range(world_size)] for g in self.gathered_all]
+                    self.all_xy_cat = torch.cat(self.all_xy, dim=0).contiguous()
             else:
                 self.gathered = [None] * self.nslots
 
@@ -164,8 +168,7 @@ class DistributedRenderer:
         self.pending[slot] = None
         work.wait()
         if self.rank == 0:
-            for r in range(self.world):
-                self.scene.packets_bgr_to_frame(self.all_xy[r], self.gathered[slot][r], self.frame_rgb8)
+            self.scene.packets_bgr_to_frame(self.all_xy_cat, self.gathered_all[slot].view(-1, 256, 3), self.frame_rgb8)
 
     def render(self, cam, stats=None, events=None):
         """Enqueue one frame; returns immediately.  `events` = optional (start, end) torch events recorded around the
@@ -195,12 +198,18 @@ class DistributedRenderer:
                 return self.frame
             sc.shade_depth(self.planes[slot][0], out=self.bgr[slot], stream=st)
             if self.stage_cpu:
+                # rehearsal transport: same buffers and the same completion path as the RCCL route, bytes moved through the host
                 host = self.bgr[slot].cpu()                      # synchronises the slot stream
                 glist = [torch.empty_like(host) for _ in range(self.world)] if self.rank == 0 else None
                 dist.gather(host, glist, dst=0, group=self.group)
                 if self.rank == 0:
                     for r in range(self.world):
-                        sc.packets_bgr_to_frame(self.all_xy[r], glist[r].to(self.bgr[slot].device), self.frame_rgb8, stream=st)
+                        self.gathered[slot][r].copy_(glist[r], non_blocking=False)
+
+                class _Done:
+                    def wait(self):
+                        return True
+                self.pending[slot] = _Done()
                 return self.frame_rgb8
             self.pending[slot] = dist.gather(self.bgr[slot], self.gathered[slot] if self.rank == 0 else None, dst=0, group=self.group, async_op=True)
         return self.frame_rgb8
