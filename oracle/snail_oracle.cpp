@@ -356,6 +356,10 @@ struct Stats { uint64_t intersects = 0, iters = 0, rays = 0, skips = 0; };
 
 struct StackElem { int node; short first, last; };
 
+// optional instrumentation (tools/range_hist.py): [0,64) inner visits by (last-first) on entry, [64,128) leaf visits likewise,
+// [128,192) leaf visits by (last-first) after the box test.  Single-threaded use only.
+uint64_t *g_rangeHist = nullptr;
+
 // src/bvh/traverse.cpp:14-80
 template <int MODE>
 void traversePrimary(const OrcNode *nodes, const OrcTri *tris, const Rays &r, float *dist, int32_t *obj, float *bary, Stats &st) {
@@ -369,11 +373,13 @@ void traversePrimary(const OrcNode *nodes, const OrcTri *tris, const Rays &r, fl
 		for(;;) {
 			st.iters++;
 			const OrcNode &n = nodes[nNode];
+			if(g_rangeHist) g_rangeHist[((n.sub & 0x80000000u) ? 64 : 0) + (last - first)]++;
 			if(n.sub & 0x80000000u) {
 				int count = n.aux, firstTri = (int)(n.sub & 0x7fffffffu);
 				if(!boxTestInterval(n, iv)) break;
 				if(boxTest<false>(n, r, dist, first, last))
 					for(int k = 0; k < count; k++) {
+						if(g_rangeHist && k == 0) g_rangeHist[128 + (last - first)]++;
 						const OrcTri &t = tris[firstTri + k];
 						if(r.shared ? triTestInterval(t, iv) : true) {
 							collidePrimary<MODE>(t, r, dist, obj, bary, firstTri + k, first, last);
@@ -821,6 +827,7 @@ void orc_render_whitted(const OrcNode *nodes, const OrcTri *tris, const OrcCamer
 	else renderWhitted<ORC_MODE_IEEE>(nodes, tris, cam, resx, resy, lights7, nLights, ambient, color, frame_bgr, pitch, stats, threads);
 }
 
+void orc_debug_range_hist(uint64_t *hist) { g_rangeHist = hist; }
 float orc_inv(float x, int mode) { return mode == ORC_MODE_SSE ? Inv<ORC_MODE_SSE>(x) : Inv<ORC_MODE_IEEE>(x); }
 float orc_rsqrt(float x, int mode) { return mode == ORC_MODE_SSE ? RSqrt<ORC_MODE_SSE>(x) : RSqrt<ORC_MODE_IEEE>(x); }
 float orc_min(float a, float b) { return Min(a, b); }

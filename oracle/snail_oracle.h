@@ -109,6 +109,9 @@ void orc_render_whitted(const OrcNode *nodes, const OrcTri *tris, const OrcCamer
                         const float *lights7, int nLights, const float ambient[3], const float color[3],
                         uint8_t *frame_bgr, int pitch, uint64_t *stats, int mode, int threads);
 
+/* instrumentation for tools/range_hist.py: hist[192] (see snail_oracle.cpp); NULL switches it off. Single-threaded only. */
+void orc_debug_range_hist(uint64_t *hist);
+
 /* arithmetic primitives exposed for the veclib pin test */
 float orc_inv(float x, int mode);
 float orc_rsqrt(float x, int mode);
