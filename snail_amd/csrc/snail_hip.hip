@@ -316,6 +316,68 @@ __device__ __forceinline__ TriTerms triTerms(const Tri &t, float ox, float oy, f
 	return r;
 }
 
+// ---- leaf, shared origin (src/bvh/traverse.cpp:34-56 / :98-124): lanes 0..chunk-1 each take one triangle (packet-level
+// cull + shared-origin terms in parallel), survivors are broadcast one by one to the whole packet.  Returns true when a
+// shadow packet is fully occluded (the walk ends, src/bvh/traverse.cpp:117-121).
+template <bool MASK, bool SHADOW, int M, bool BARY>
+__device__ __forceinline__ bool leafShared(const uint4 *__restrict__ tris, int count, int firstTri, int size, int lane, int first, int last,
+										   const float (&org)[3][4], Quad &Q, unsigned mask4, int (&tid)[4], float (&bu)[4], float (&bv)[4],
+										   const Interval &iv, Counters &st) {
+	const float inf = __builtin_inff();
+	const bool inRange = lane >= first && lane <= last;
+	const int width = last - first + 1;
+	const u64 curRange = rangeMask(first, last);
+	for(int base = 0; base < count; base += 64) {
+		const int chunk = count - base < 64 ? count - base : 64;
+		const bool mine = lane < chunk;
+		const Tri t = loadTriVector(tris, firstTri + base + (mine ? lane : 0));
+		const TriTerms tt = triTerms(t, org[0][0], org[1][0], org[2][0]);
+		u64 keep = __ballot(mine & triTestInterval<M>(t, iv));
+
+		while(keep) {
+			const int k = __builtin_ctzll(keep);
+			keep &= keep - 1;
+			const float nx = readlanef(t.n[0], k), ny = readlanef(t.n[1], k), nz = readlanef(t.n[2], k);
+			const float ax = readlanef(tt.t0v[0], k), ay = readlanef(tt.t0v[1], k), az = readlanef(tt.t0v[2], k);
+			const float bx = readlanef(tt.t1v[0], k), by = readlanef(tt.t1v[1], k), bz = readlanef(tt.t1v[2], k);
+			const float tmul = readlanef(tt.tmul, k);
+			const int idx = firstTri + base + k;
+			bool all4 = true;
+#pragma unroll
+			for(int l = 0; l < 4; l++) {
+				const float det = Q.d[0][l] * nx + Q.d[1][l] * ny + Q.d[2][l] * nz;
+				const float v = Q.d[0][l] * ax + Q.d[1][l] * ay + Q.d[2][l] * az;
+				const float u = Q.d[0][l] * bx + Q.d[1][l] * by + Q.d[2][l] * bz;
+				if(SHADOW) { // src/triangle.cpp:91-98
+					bool test = (Min<M>(u, v) >= 0.0f) & (u + v <= det);
+					test = test & (tmul > 0.0f) & (tmul < Q.dist[l] * det);
+					all4 = all4 & test;
+					if(inRange && test) Q.dist[l] = -inf;
+				} else { // src/triangle.cpp:44-60
+					const float duv = det - u - v;
+					const float uvmin = Min3<M>(u, v, duv), uvmax = Max3<M>(u, v, duv);
+					bool test = ((uvmax <= 0.0f) | (uvmin >= 0.0f)) & inRange;
+					if(MASK) test = test & (((mask4 >> l) & 1u) != 0);
+					if(test) {
+						const float idet = 1.0f / det;
+						const float dd = idet * tmul;
+						if(dd < Q.dist[l] && dd > 0.0f) {
+							Q.dist[l] = dd; tid[l] = idx;
+							if(BARY) { bu[l] = u * idet; bv[l] = v * idet; }
+						}
+					}
+				}
+			}
+			if(SHADOW) {
+				const bool full = width == size && (__ballot(all4) & curRange) == curRange;
+				if(full) { st.skips++; return true; }
+			}
+			st.intersects += width;
+		}
+	}
+	return false;
+}
+
 // ---- the packet walk -------------------------------------------------------------------------------
 // SHARED : one origin per packet (primary / shadow)   MASK : per-lane 4-bit masks (secondary rays)
 // SHADOW : any-hit TraverseShadow                      M    : arithmetic mode (above)
@@ -329,7 +391,6 @@ template <bool SHARED, bool MASK, bool SHADOW, int M, bool BARY, bool DEEP, bool
 __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint4 *__restrict__ tris, int size, int lane,
 									 const float (&org)[3][4] /* SHARED: [c][0] uniform */, Quad &Q, unsigned mask4, int (&tid)[4],
 									 float (&bu)[4], float (&bv)[4], float *lds, Counters &st) {
-	const float inf = __builtin_inff();
 	constexpr bool EXACT = M == M_EXACT;
 	Interval iv;
 	{ // RayInterval ctor (src/ray_group.h:296-333)
@@ -484,58 +545,9 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 		const int count = n.aux, firstTri = (int)(n.sub & 0x7fffffffu);
 		const bool inRange = lane >= first && lane <= last;
 		const int width = last - first + 1;
-		const u64 curRange = rangeMask(first, last);
 
 		if(SHARED) {
-			for(int base = 0; base < count; base += 64) {
-				const int chunk = count - base < 64 ? count - base : 64;
-				const bool mine = lane < chunk;
-				// lanes 0..chunk-1 each take one triangle: packet-level cull + shared-origin terms in parallel
-				const Tri t = loadTriVector(tris, firstTri + base + (mine ? lane : 0));
-				const TriTerms tt = triTerms(t, org[0][0], org[1][0], org[2][0]);
-				u64 keep = __ballot(mine & triTestInterval<M>(t, iv));
-
-				while(keep) {
-					const int k = __builtin_ctzll(keep);
-					keep &= keep - 1;
-					const float nx = readlanef(t.n[0], k), ny = readlanef(t.n[1], k), nz = readlanef(t.n[2], k);
-					const float ax = readlanef(tt.t0v[0], k), ay = readlanef(tt.t0v[1], k), az = readlanef(tt.t0v[2], k);
-					const float bx = readlanef(tt.t1v[0], k), by = readlanef(tt.t1v[1], k), bz = readlanef(tt.t1v[2], k);
-					const float tmul = readlanef(tt.tmul, k);
-					const int idx = firstTri + base + k;
-					bool all4 = true;
-#pragma unroll
-					for(int l = 0; l < 4; l++) {
-						const float det = Q.d[0][l] * nx + Q.d[1][l] * ny + Q.d[2][l] * nz;
-						const float v = Q.d[0][l] * ax + Q.d[1][l] * ay + Q.d[2][l] * az;
-						const float u = Q.d[0][l] * bx + Q.d[1][l] * by + Q.d[2][l] * bz;
-						if(SHADOW) { // src/triangle.cpp:91-98
-							bool test = (Min<M>(u, v) >= 0.0f) & (u + v <= det);
-							test = test & (tmul > 0.0f) & (tmul < Q.dist[l] * det);
-							all4 = all4 & test;
-							if(inRange && test) Q.dist[l] = -inf;
-						} else { // src/triangle.cpp:44-60
-							const float duv = det - u - v;
-							const float uvmin = Min3<M>(u, v, duv), uvmax = Max3<M>(u, v, duv);
-							bool test = ((uvmax <= 0.0f) | (uvmin >= 0.0f)) & inRange;
-							if(MASK) test = test & (((mask4 >> l) & 1u) != 0);
-							if(test) {
-								const float idet = 1.0f / det;
-								const float dd = idet * tmul;
-								if(dd < Q.dist[l] && dd > 0.0f) {
-									Q.dist[l] = dd; tid[l] = idx;
-									if(BARY) { bu[l] = u * idet; bv[l] = v * idet; }
-								}
-							}
-						}
-					}
-					if(SHADOW) {
-						const bool full = width == size && (__ballot(all4) & curRange) == curRange;
-						if(full) { st.skips++; return; }
-					}
-					st.intersects += width;
-				}
-			}
+			if(leafShared<MASK, SHADOW, M, BARY>(tris, count, firstTri, size, lane, first, last, org, Q, mask4, tid, bu, bv, iv, st)) return;
 		} else {
 			// per-ray origins (reflection / transparency packets, src/triangle.cpp:30-38): wave-uniform scalar triangle fetch
 			for(int k = 0; k < count; k++) {
@@ -575,6 +587,110 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 		first = fl & 0xff; last = fl >> 8;
 		n = loadNode(nodes, cur);
 	}
+}
+
+// ---- the primary packet walk of the main kernel, node loop in assembly ---------------------------------------------------
+// Same algorithm and the same IEEE operations as walk<true,false,false,M_COH,false,false,true,OCT> (shared origin, no masks,
+// every ray of the packet in sign octant OCT, distances >= 0, tree depth <= 62); only the descend / cull / push / pop loop is
+// written by hand, because the compiler's version of it carries ~25 % register-shuffling (loop-carried copies around the
+// stack VGPRs and the node SGPRs, hazard padding around its inline v_min/v_max): 82 instead of ~103 instructions per inner
+// node, and this kernel's time is its instruction count (profiles/README.md).  One asm statement = "pop, then descend until
+// a leaf survives its box test (-> the C++ leaf code) or the stack is empty".
+//   node record  s[84:91] = bmin.xyz, bmax.xyz, sub, aux            stack: lane i of (stkN, stkF) = slot i
+//   slab test    tn = max3_k(id_k * (near_k - o_k)), tf = min3_k(id_k * (far_k - o_k));  lane passes <=> max(tn,0) <= min(tf,dist)
+//                quad passes <=> max_l(min(tf,dist) - max(tn,0)) >= 0   (finite operands, fp32 denormals on: exact sign)
+//   range clip   (unsigned)(lane - first) <= (unsigned)(last - first)
+//   child order  near = sub + (firstNode ^ sign[axis]) with sign from lane 0 of quad 0 (src/bvh/traverse.cpp:21,71-74):
+//                sign16 = signBits << 16, so bit 16 of (sign16 >> axis) ^ aux is that XOR (aux = axis | firstNode << 16)
+//   iters        every chain of visits starts with a pop (the root is pushed by the caller) and every push is popped, so
+//                visits = 2 * pops - 1: only the pops are counted
+#ifndef SNAIL_EXP_PAD
+#define SNAIL_EXP_PAD "" // experiment hook: extra instructions per node visit (tools/exp_pad.sh)
+#endif
+#define SNAIL_RAY_SLAB(L, S)                                                                                                               \
+	"v_mul_f32 %[t0], %[ix" L "], %[pnx]\n v_mul_f32 %[t1], %[iy" L "], %[pny]\n v_mul_f32 %[t2], %[iz" L "], %[pnz]\n"                    \
+	"v_mul_f32 %[t3], %[ix" L "], %[pfx]\n v_mul_f32 %[t4], %[iy" L "], %[pfy]\n v_mul_f32 %[t5], %[iz" L "], %[pfz]\n"                    \
+	"v_max3_f32 %[t0], %[t0], %[t1], %[t2]\n v_min3_f32 %[t3], %[t3], %[t4], %[t5]\n"                                                      \
+	"v_max_f32 %[t0], 0, %[t0]\n v_min_f32 %[t3], %[t3], %[d" L "]\n v_sub_f32 %[" S "], %[t3], %[t0]\n"
+#define SNAIL_DESCEND_ASM(NX, FX, NY, FY, NZ, FZ)                                                                                          \
+	asm volatile("L_pop_%=:\n"                                                                                                             \
+				 " s_cmp_eq_u32 %[sp], 0\n s_cbranch_scc1 L_done_%=\n"                                                                     \
+				 " s_sub_u32 %[sp], %[sp], 1\n s_add_u32 %[pops], %[pops], 1\n"                                                            \
+				 " v_readlane_b32 %[cur], %[stkN], %[sp]\n v_readlane_b32 %[fl], %[stkF], %[sp]\n"                                         \
+				 " s_lshl_b32 %[off], %[cur], 5\n s_load_dwordx8 s[84:91], %[base], %[off]\n"                                              \
+				 " s_and_b32 %[first], %[fl], 0xff\n s_lshr_b32 %[last], %[fl], 8\n s_sub_u32 %[width], %[last], %[first]\n"               \
+				 " s_waitcnt lgkmcnt(0)\n"                                                                                                 \
+				 "L_visit_%=:\n"                                                                                                           \
+				 " v_sub_f32 %[pnx], " NX ", %[ox]\n v_sub_f32 %[pny], " NY ", %[oy]\n v_sub_f32 %[pnz], " NZ ", %[oz]\n"                  \
+				 " v_sub_f32 %[pfx], " FX ", %[ox]\n v_sub_f32 %[pfy], " FY ", %[oy]\n v_sub_f32 %[pfz], " FZ ", %[oz]\n"                  \
+				 SNAIL_RAY_SLAB("0", "s0") SNAIL_RAY_SLAB("1", "s1") SNAIL_RAY_SLAB("2", "s2") SNAIL_RAY_SLAB("3", "s3")                   \
+				 " v_max_f32 %[s2], %[s2], %[s3]\n v_max3_f32 %[s0], %[s0], %[s1], %[s2]\n"                                                \
+				 SNAIL_EXP_PAD                                                                                                                            \
+				 " v_cmp_le_f32 vcc, 0, %[s0]\n"                                                                                           \
+				 " v_subrev_u32 %[t0], %[first], %[lane]\n v_cmp_ge_u32 %[rng], %[width], %[t0]\n"                                         \
+				 " s_and_b64 %[alive], vcc, %[rng]\n s_cbranch_scc0 L_pop_%=\n"                                                            \
+				 " s_ff1_i32_b64 %[first], %[alive]\n s_flbit_i32_b64 %[last], %[alive]\n s_xor_b32 %[last], %[last], 63\n"                \
+				 " s_sub_u32 %[width], %[last], %[first]\n"                                                                                \
+				 " s_cmp_lt_i32 s90, 0\n s_cbranch_scc1 L_leaf_%=\n"                                                                       \
+				 " s_lshr_b32 %[cur], %[sign16], s91\n s_xor_b32 %[cur], %[cur], s91\n s_bfe_u32 %[cur], %[cur], 0x10010\n"                \
+				 " s_add_u32 %[fl], s90, 1\n s_sub_u32 %[fl], %[fl], %[cur]\n"                                                             \
+				 " s_add_u32 %[cur], s90, %[cur]\n s_lshl_b32 %[off], %[cur], 5\n"                                                         \
+				 " s_load_dwordx8 s[84:91], %[base], %[off]\n"                                                                             \
+				 " s_lshl_b32 %[off], %[last], 8\n s_or_b32 %[off], %[off], %[first]\n"                                                    \
+				 " s_mov_b32 m0, %[sp]\n v_writelane_b32 %[stkN], %[fl], m0\n v_writelane_b32 %[stkF], %[off], m0\n"                       \
+				 " s_add_u32 %[sp], %[sp], 1\n"                                                                                            \
+				 " s_waitcnt lgkmcnt(0)\n s_branch L_visit_%=\n"                                                                           \
+				 "L_leaf_%=:\n s_mov_b32 %[leafSub], s90\n s_mov_b32 %[leafAux], s91\n s_branch L_end_%=\n"                                \
+				 "L_done_%=:\n s_mov_b32 %[leafSub], 0\n s_mov_b32 %[leafAux], 0\n"                                                        \
+				 "L_end_%=:\n"                                                                                                             \
+				 : [sp] "+s"(sp), [first] "+s"(first), [last] "+s"(last), [pops] "+s"(pops), [stkN] "+v"(stkN), [stkF] "+v"(stkF),         \
+				   [leafSub] "=&s"(leafSub), [leafAux] "=&s"(leafAux), [cur] "=&s"(sCur), [fl] "=&s"(sFl), [off] "=&s"(sOff),              \
+				   [width] "=&s"(sWidth), [rng] "=&s"(sRng), [alive] "=&s"(sAlive), [pnx] "=&v"(vt[0]), [pny] "=&v"(vt[1]),                \
+				   [pnz] "=&v"(vt[2]), [pfx] "=&v"(vt[3]), [pfy] "=&v"(vt[4]), [pfz] "=&v"(vt[5]), [t0] "=&v"(vt[6]), [t1] "=&v"(vt[7]),   \
+				   [t2] "=&v"(vt[8]), [t3] "=&v"(vt[9]), [t4] "=&v"(vt[10]), [t5] "=&v"(vt[11]), [s0] "=&v"(vt[12]), [s1] "=&v"(vt[13]),   \
+				   [s2] "=&v"(vt[14]), [s3] "=&v"(vt[15])                                                                                  \
+				 : [base] "s"(nodeBase), [sign16] "s"(sign16), [lane] "v"(lane), [ox] "v"(org[0][0]), [oy] "v"(org[1][0]),                 \
+				   [oz] "v"(org[2][0]), [ix0] "v"(Q.id[0][0]), [ix1] "v"(Q.id[0][1]), [ix2] "v"(Q.id[0][2]), [ix3] "v"(Q.id[0][3]),        \
+				   [iy0] "v"(Q.id[1][0]), [iy1] "v"(Q.id[1][1]), [iy2] "v"(Q.id[1][2]), [iy3] "v"(Q.id[1][3]), [iz0] "v"(Q.id[2][0]),      \
+				   [iz1] "v"(Q.id[2][1]), [iz2] "v"(Q.id[2][2]), [iz3] "v"(Q.id[2][3]), [d0] "v"(Q.dist[0]), [d1] "v"(Q.dist[1]),          \
+				   [d2] "v"(Q.dist[2]), [d3] "v"(Q.dist[3])                                                                                \
+				 : "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "vcc", "scc", "m0")
+
+template <int OCT>
+__device__ __forceinline__ void walkPrimaryCoh(const uint4 *__restrict__ nodes, const uint4 *__restrict__ tris, int lane, const float (&org)[3][4],
+											   Quad &Q, int (&tid)[4], float *lds, Counters &st) {
+	Interval iv;
+	computeMinMax<false, false>(Q.d, 15u, 64, lane, lds, iv.minDir, iv.maxDir);
+#pragma unroll
+	for(int k = 0; k < 3; k++) { iv.minIDir[k] = iv.maxIDir[k] = 0.0f; iv.minOrg[k] = iv.maxOrg[k] = org[k][0]; }
+	const int signBits = __builtin_amdgcn_readfirstlane((Q.d[0][0] < 0.0f ? 1 : 0) | (Q.d[1][0] < 0.0f ? 2 : 0) | (Q.d[2][0] < 0.0f ? 4 : 0));
+	const int sign16 = signBits << 16;
+	const u64 nodeBase = (u64)nodes;
+	float bu[4], bv[4]; // not maintained here (finalBarycentrics)
+	int stkN = 0, stkF = 63 << 8; // slot 0 = the root with the full quad range
+	int sp = 1, first = 0, last = 63, pops = 0;
+	for(;;) {
+		int leafSub, leafAux, sCur, sFl, sOff, sWidth;
+		u64 sRng, sAlive;
+		float vt[16];
+		if(OCT == 0) SNAIL_DESCEND_ASM("s84", "s87", "s85", "s88", "s86", "s89");
+		else if(OCT == 1) SNAIL_DESCEND_ASM("s87", "s84", "s85", "s88", "s86", "s89");
+		else if(OCT == 2) SNAIL_DESCEND_ASM("s84", "s87", "s88", "s85", "s86", "s89");
+		else if(OCT == 3) SNAIL_DESCEND_ASM("s87", "s84", "s88", "s85", "s86", "s89");
+		else if(OCT == 4) SNAIL_DESCEND_ASM("s84", "s87", "s85", "s88", "s89", "s86");
+		else if(OCT == 5) SNAIL_DESCEND_ASM("s87", "s84", "s85", "s88", "s89", "s86");
+		else if(OCT == 6) SNAIL_DESCEND_ASM("s84", "s87", "s88", "s85", "s89", "s86");
+		else SNAIL_DESCEND_ASM("s87", "s84", "s88", "s85", "s89", "s86");
+		// every result is consumed HERE, in the block of the asm statement (no code is emitted for this): LLVM classes the whole
+		// result tuple of an asm with mixed SGPR/VGPR outputs as scalar once the tuple itself is live across a block boundary
+		// (SITargetLowering::requiresUniformRegister), i.e. once the optimiser sinks one of the extractions into a successor
+		asm volatile("" ::"s"(sp), "s"(first), "s"(last), "s"(pops), "v"(stkN), "v"(stkF), "s"(leafSub), "s"(leafAux), "s"(sCur), "s"(sFl), "s"(sOff),
+					 "s"(sWidth), "s"(sRng), "s"(sAlive), "v"(vt[0]), "v"(vt[1]), "v"(vt[2]), "v"(vt[3]), "v"(vt[4]), "v"(vt[5]), "v"(vt[6]), "v"(vt[7]),
+					 "v"(vt[8]), "v"(vt[9]), "v"(vt[10]), "v"(vt[11]), "v"(vt[12]), "v"(vt[13]), "v"(vt[14]), "v"(vt[15]));
+		if(leafSub == 0) break;
+		leafShared<false, false, M_COH, false>(tris, leafAux, (int)((unsigned)leafSub & 0x7fffffffu), 64, lane, first, last, org, Q, 15u, tid, bu, bv, iv, st);
+	}
+	st.iters += 2u * (unsigned)pops - 1u;
 }
 
 // barycentrics of the final hits, derived after the walk (primary kernel): the same operations on the same
@@ -728,7 +844,11 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 		return;
 	} else if(mode == M_COH) {
 		const int oct = __builtin_amdgcn_readfirstlane(((__float_as_int(Q.id[0][0]) >> 31) & 1) | ((__float_as_int(Q.id[1][0]) >> 31) & 2) | ((__float_as_int(Q.id[2][0]) >> 31) & 4));
-#define SNAIL_WALK_OCT(O) walk<true, false, false, M_COH, false, DEEP, true, O>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st)
+#define SNAIL_WALK_OCT(O)                                                                                                                  \
+	do {                                                                                                                                   \
+		if(DEEP) walk<true, false, false, M_COH, false, DEEP, true, O>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st);        \
+		else walkPrimaryCoh<O>(A.nodes, A.tris, lane, org, Q, tid, lds, st);                                                               \
+	} while(0)
 		switch(oct) { // one specialised walk per sign octant, chosen once per packet
 		case 0: SNAIL_WALK_OCT(0); break; case 1: SNAIL_WALK_OCT(1); break; case 2: SNAIL_WALK_OCT(2); break; case 3: SNAIL_WALK_OCT(3); break;
 		case 4: SNAIL_WALK_OCT(4); break; case 5: SNAIL_WALK_OCT(5); break; case 6: SNAIL_WALK_OCT(6); break; default: SNAIL_WALK_OCT(7); break;

@@ -1,0 +1,14 @@
+#!/bin/bash
+# experiment: throughput sensitivity to extra VALU / SALU / s_nop per node visit (variants built into snail_amd/exp/ by hand,
+# see profiles/README.md).  Runs on the GPU box; overwrites the box's copy of libsnailhip.so.
+set -u
+cp snail_amd/libsnailhip.so /tmp/lib_base.so
+for v in base valu20 salu20 nop20; do
+  if [ $v = base ]; then cp /tmp/lib_base.so snail_amd/libsnailhip.so; else cp snail_amd/exp/lib_$v.so snail_amd/libsnailhip.so; fi
+  timeout -k 10 200 python bench.py --no-cpu-baseline > gpurun_out/exp_$v.json 2> gpurun_out/exp_$v.err || exit 1
+  python - $v <<'PY'
+import json,sys
+d=json.load(open('gpurun_out/exp_%s.json'%sys.argv[1])); print(sys.argv[1], d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])
+PY
+done
+cp /tmp/lib_base.so snail_amd/libsnailhip.so
