@@ -114,6 +114,19 @@ int snail_shade_depth_dev(const float *d_t, int nPackets, uint8_t *d_bgr, void *
 int snail_packets_bgr_to_frame_dev(const int32_t *d_packet_xy, int nPackets, int resx, int resy, const uint8_t *d_bgr,
                                    uint8_t *d_frame, int pitch, void *stream);
 
+/* The render node's wire format for a tile and its inverse.  Encode = the `compress` store of RenderTask::Work
+ * (src/render.cpp:140-163): tile (x, y, w, h) -> three w*h byte planes R, G-R, B-R (mod 256) at d_out + d_out_offsets[tile]
+ * (the layout the reference hands to its LZ compressor; the compressor and the sockets are out of scope).  The packets of
+ * tile k are d_first_packet[k], +1, ... in RenderTask::Work loop order (16-row bands outer, 16-column steps inner); d_bgr is
+ * packet-major as produced by snail_shade_depth_dev / snail_render_whitted_dev.  The reference leaves tiles other than
+ * 16x64 unwritten (a TODO, src/render.cpp:142-145); here every tile is written with the same formula.
+ * Decode = DecompressTask::Work's plane loop (src/compression.cpp:112-141): pixel bytes (B,G,R) = (b'+r, g'+r, r) into an
+ * interleaved frame of `pitch` bytes per row, clipped to resx x resy.  d_tiles: int32 [nTiles][4] = x, y, w, h. */
+int snail_packets_bgr_to_planar_dev(const int32_t *d_tiles, const int32_t *d_first_packet, const int64_t *d_out_offsets, int nTiles,
+                                    const uint8_t *d_bgr, uint8_t *d_out, void *stream);
+int snail_planar_to_frame_dev(const int32_t *d_tiles, const int64_t *d_in_offsets, int nTiles, const uint8_t *d_planar, uint8_t *d_frame,
+                              int pitch, int resx, int resy, void *stream);
+
 /* Scene::RayTrace for primary packets in the reference's "simple shading" configuration, entirely on the device
  * (BASELINE config 3: primary + one shadow packet per light): TraversePrimary<1,0>; samples (position = d*t + o,
  * normal = triangle plane normal, diffuse = specular = color*|d.n|: src/scene_trace.cpp:359-452,

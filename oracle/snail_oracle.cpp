@@ -827,6 +827,28 @@ void orc_render_whitted(const OrcNode *nodes, const OrcTri *tris, const OrcCamer
 	else renderWhitted<ORC_MODE_IEEE>(nodes, tris, cam, resx, resy, lights7, nLights, ambient, color, frame_bgr, pitch, stats, threads);
 }
 
+// the `compress` store of RenderTask::Work (src/render.cpp:140-163): planes R, G-R, B-R of a tile, from the interleaved B,G,R frame
+void orc_planar_encode_tile(const uint8_t *frame_bgr, int pitch, int x, int y, int w, int h, uint8_t *out) {
+	for(int ty = 0; ty < h; ty++)
+		for(int tx = 0; tx < w; tx++) {
+			const uint8_t *s = frame_bgr + (size_t)(y + ty) * pitch + (size_t)(x + tx) * 3;
+			uint8_t *dr = out + (size_t)ty * w + tx, *dg = dr + (size_t)w * h, *db = dg + (size_t)w * h;
+			*dr = s[2]; *dg = s[1]; *db = s[0];
+			*dg -= *dr; *db -= *dr; // src/render.cpp:157-160
+		}
+}
+// DecompressTask::Work, plane loop (src/compression.cpp:112-141)
+void orc_planar_decode_tile(const uint8_t *planes, int x, int y, int w, int h, uint8_t *frame_bgr, int pitch) {
+	const uint8_t *srcr = planes, *srcg = planes + (size_t)w * h, *srcb = planes + (size_t)2 * w * h;
+	for(int ty = 0; ty < h; ty++) {
+		uint8_t *tdst = frame_bgr + (size_t)(y + ty) * pitch + (size_t)x * 3;
+		for(int tx = 0; tx < w; tx++) {
+			const uint8_t red = srcr[(size_t)ty * w + tx];
+			tdst[2] = red; tdst[1] = (uint8_t)(srcg[(size_t)ty * w + tx] + red); tdst[0] = (uint8_t)(srcb[(size_t)ty * w + tx] + red);
+			tdst += 3;
+		}
+	}
+}
 void orc_debug_range_hist(uint64_t *hist) { g_rangeHist = hist; }
 float orc_inv(float x, int mode) { return mode == ORC_MODE_SSE ? Inv<ORC_MODE_SSE>(x) : Inv<ORC_MODE_IEEE>(x); }
 float orc_rsqrt(float x, int mode) { return mode == ORC_MODE_SSE ? RSqrt<ORC_MODE_SSE>(x) : RSqrt<ORC_MODE_IEEE>(x); }

@@ -109,6 +109,12 @@ void orc_render_whitted(const OrcNode *nodes, const OrcTri *tris, const OrcCamer
                         const float *lights7, int nLights, const float ambient[3], const float color[3],
                         uint8_t *frame_bgr, int pitch, uint64_t *stats, int mode, int threads);
 
+/* The render node's tile wire format: the `compress` store of RenderTask::Work (src/render.cpp:140-163) -- planes R, G-R, B-R
+ * (mod 256) of tile (x, y, w, h) taken from an interleaved B,G,R frame -- and its inverse, DecompressTask::Work's plane loop
+ * (src/compression.cpp:112-141). */
+void orc_planar_encode_tile(const uint8_t *frame_bgr, int pitch, int x, int y, int w, int h, uint8_t *out);
+void orc_planar_decode_tile(const uint8_t *planes, int x, int y, int w, int h, uint8_t *frame_bgr, int pitch);
+
 /* instrumentation for tools/range_hist.py: hist[192] (see snail_oracle.cpp); NULL switches it off. Single-threaded only. */
 void orc_debug_range_hist(uint64_t *hist);
 

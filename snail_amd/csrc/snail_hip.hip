@@ -1244,6 +1244,43 @@ __global__ __launch_bounds__(256) void k_bgr_to_frame(const int2 *packetXY, int 
 		if(xx + l < resx) { d[l * 3 + 0] = s[l * 3 + 0]; d[l * 3 + 1] = s[l * 3 + 1]; d[l * 3 + 2] = s[l * 3 + 2]; }
 }
 
+// ---- the render node's tile wire format (src/render.cpp:140-163) and its inverse (src/compression.cpp:112-141) ----------
+// A tile (x, y, w, h) travels as three w*h byte planes: R, G-R, B-R (mod 256), R = the channel ConvColor shifts by 16, i.e. byte 2
+// of a stored pixel.  Source: packet-major BGR bytes (in-packet index = 16*row + column, the reference's quad order); the
+// packets of a tile are consecutive, row bands outer, columns inner (RenderTask::Work loop order).
+__global__ __launch_bounds__(256) void k_bgr_to_planar(const int4 *tiles, const int *firstPacket, const long long *outOff, int nTiles,
+														 const unsigned char *src, unsigned char *out) {
+	const int tile = (int)blockIdx.y;
+	if(tile >= nTiles) return;
+	const int4 T = tiles[tile];
+	const int n = T.z * T.w;
+	const int ppr = (T.z + 15) >> 4;
+	unsigned char *o = out + outOff[tile];
+	for(int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n; i += (int)(gridDim.x * blockDim.x)) {
+		const int ty = i / T.z, tx = i - ty * T.z;
+		const size_t pk = (size_t)firstPacket[tile] + (size_t)(ty >> 4) * ppr + (size_t)(tx >> 4);
+		const unsigned char *s = src + (pk * 256 + (size_t)((ty & 15) * 16 + (tx & 15))) * 3;
+		const unsigned char b = s[0], g = s[1], r = s[2];
+		o[i] = r; o[(size_t)n + i] = (unsigned char)(g - r); o[(size_t)2 * n + i] = (unsigned char)(b - r);
+	}
+}
+__global__ __launch_bounds__(256) void k_planar_to_frame(const int4 *tiles, const long long *inOff, int nTiles, const unsigned char *in, unsigned char *frame,
+														   int pitch, int resx, int resy) {
+	const int tile = (int)blockIdx.y;
+	if(tile >= nTiles) return;
+	const int4 T = tiles[tile];
+	const int n = T.z * T.w;
+	const unsigned char *p = in + inOff[tile];
+	for(int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n; i += (int)(gridDim.x * blockDim.x)) {
+		const int ty = i / T.z, tx = i - ty * T.z;
+		const int xx = T.x + tx, yy = T.y + ty;
+		if(xx >= resx || yy >= resy) continue;
+		const unsigned char red = p[i];
+		unsigned char *d = frame + (size_t)yy * pitch + (size_t)xx * 3;
+		d[2] = red; d[1] = (unsigned char)(p[(size_t)n + i] + red); d[0] = (unsigned char)(p[(size_t)2 * n + i] + red);
+	}
+}
+
 // ---- single-ray accounting walk: V_n, V_t per ray ----------------------------
 struct AccountArgs {
 	const uint4 *nodes, *tris;
@@ -1724,6 +1761,28 @@ int snail_packets_bgr_to_frame_dev(const int32_t *dPacketXY, int nPackets, int r
 	if(!dPacketXY || !bgr || !frame || pitch < resx * 3) { snail_set_error("snail_packets_bgr_to_frame_dev: bad arguments"); return 1; }
 	hipLaunchKernelGGL(dev::k_bgr_to_frame, dim3((nPackets + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const int2 *)dPacketXY, nPackets, resx,
 					   resy, bgr, frame, pitch);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+int snail_packets_bgr_to_planar_dev(const int32_t *dTiles, const int32_t *dFirstPacket, const int64_t *dOutOffsets, int nTiles, const uint8_t *bgr,
+									uint8_t *out, void *stream) {
+	if(nTiles <= 0) return 0;
+	if(!dTiles || !dFirstPacket || !dOutOffsets || !bgr || !out) { snail_set_error("snail_packets_bgr_to_planar_dev: bad arguments"); return 1; }
+	if(nTiles > 65535) { snail_set_error("snail_packets_bgr_to_planar_dev: at most 65535 tiles per call (got %d)", nTiles); return 1; }
+	hipLaunchKernelGGL(dev::k_bgr_to_planar, dim3(4, nTiles), dim3(256), 0, (hipStream_t)stream, (const int4 *)dTiles, dFirstPacket,
+					   (const long long *)dOutOffsets, nTiles, bgr, out);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+int snail_planar_to_frame_dev(const int32_t *dTiles, const int64_t *dInOffsets, int nTiles, const uint8_t *planar, uint8_t *frame, int pitch, int resx,
+							  int resy, void *stream) {
+	if(nTiles <= 0) return 0;
+	if(!dTiles || !dInOffsets || !planar || !frame || pitch < resx * 3) { snail_set_error("snail_planar_to_frame_dev: bad arguments"); return 1; }
+	if(nTiles > 65535) { snail_set_error("snail_planar_to_frame_dev: at most 65535 tiles per call (got %d)", nTiles); return 1; }
+	hipLaunchKernelGGL(dev::k_planar_to_frame, dim3(4, nTiles), dim3(256), 0, (hipStream_t)stream, (const int4 *)dTiles, (const long long *)dInOffsets,
+					   nTiles, planar, frame, pitch, resx, resy);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }

@@ -186,6 +186,35 @@ class Scene:
         _lib.check(rc, "snail_packets_bgr_to_frame_dev")
         return frame_rgb8
 
+    @staticmethod
+    def tile_layout(tiles: np.ndarray):
+        """For a list of tiles (x, y, w, h) whose packets are stored tile after tile (render.tile_packets order): the index of
+        each tile's first packet and the byte offset of each tile's planes in a buffer that holds the tiles back to back
+        (3*w*h bytes each -- the per-tile buffers of src/node.cpp:245-258).  Returns (first_packet int32[n], offsets int64[n], total)."""
+        t = np.asarray(tiles, dtype=np.int64).reshape(-1, 4)
+        npk = ((t[:, 2] + 15) // 16) * ((t[:, 3] + 15) // 16)
+        first = np.concatenate([[0], np.cumsum(npk)[:-1]]).astype(np.int32)
+        size = 3 * t[:, 2] * t[:, 3]
+        off = np.concatenate([[0], np.cumsum(size)[:-1]]).astype(np.int64)
+        return first, off, int(size.sum())
+
+    @staticmethod
+    def packets_bgr_to_planar(tiles_dev, first_packet_dev, offsets_dev, bgr_packets, out, stream=None):
+        """The render node's tile wire format (src/render.cpp:140-163): per tile the planes R, G-R, B-R."""
+        rc = _lib.lib().snail_packets_bgr_to_planar_dev(_lib.ptr(tiles_dev), _lib.ptr(first_packet_dev), _lib.ptr(offsets_dev), int(tiles_dev.shape[0]),
+                                                        _lib.ptr(bgr_packets), _lib.ptr(out), _stream_ptr(stream))
+        _lib.check(rc, "snail_packets_bgr_to_planar_dev")
+        return out
+
+    @staticmethod
+    def planar_to_frame(tiles_dev, offsets_dev, planar, frame_rgb8, stream=None):
+        """Inverse of packets_bgr_to_planar (src/compression.cpp:112-141) into an interleaved [resy,resx,3] uint8 frame."""
+        resy, resx = int(frame_rgb8.shape[0]), int(frame_rgb8.shape[1])
+        rc = _lib.lib().snail_planar_to_frame_dev(_lib.ptr(tiles_dev), _lib.ptr(offsets_dev), int(tiles_dev.shape[0]), _lib.ptr(planar),
+                                                  _lib.ptr(frame_rgb8), resx * 3, resx, resy, _stream_ptr(stream))
+        _lib.check(rc, "snail_planar_to_frame_dev")
+        return frame_rgb8
+
     def render_whitted(self, cam: Camera, resx: int, resy: int, lights7, ambient=(0.1, 0.1, 0.1), color=(1.0, 1.0, 1.0), out=None, stats=None,
                        stream=None):
         """Scene::RayTrace in the reference's simple-shading configuration (primary + one shadow packet per point light),

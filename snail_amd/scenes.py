@@ -48,18 +48,35 @@ def _repair(tri_idx: np.ndarray, verts: np.ndarray) -> np.ndarray:
     return tri_idx[np.asarray(order, dtype=np.int64)]
 
 
-def load_obj(path: str, flip: bool = True) -> np.ndarray:
+def _libc_strtof():
+    """sscanf("%f") of the reference (src/formats/wavefront_obj.cpp:98-101) rounds the decimal text to float32 ONCE; Python's
+    float() rounds to float64 first, and the second rounding to float32 can land on the other neighbour when the text sits
+    within 2^-29 (relative) of a float32 midpoint.  The C library's strtof is the same conversion as sscanf's."""
+    import ctypes
+    import ctypes.util
+    try:
+        libc = ctypes.CDLL(ctypes.util.find_library("c") or "libc.so.6")
+        fn = libc.strtof
+        fn.restype = ctypes.c_float
+        fn.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
+        return lambda tok: fn(tok.encode("ascii", "replace"), None)
+    except (OSError, AttributeError):   # no C library to bind: double rounding (differs only in the rare midpoint case)
+        return lambda tok: float(np.float32(float(tok)))
+
+
+def load_obj(path: str, flip: bool = True, swap_yz: bool = False) -> np.ndarray:
     """LoadWavefrontObj -> Repair -> (FlipNormals) -> ToTriVector: returns float32 [n,3,3] vertex
     positions in the order the reference hands them to BVH::Construct."""
     verts: list[tuple[float, float, float]] = []
     faces: list[tuple[int, int, int]] = []
+    strtof = _libc_strtof()
     with open(path, "r", errors="replace") as fh:
         for line in fh:
             parts = line.split()
             if not parts:
                 continue
             if parts[0] == "v" and len(parts) >= 4:
-                verts.append((float(parts[1]), float(parts[2]), float(parts[3])))
+                verts.append((strtof(parts[1]), strtof(parts[2]), strtof(parts[3])))
             elif parts[0] == "f" and len(parts) >= 4:
                 idx = []
                 for tok in parts[1:5]:
@@ -75,8 +92,10 @@ def load_obj(path: str, flip: bool = True) -> np.ndarray:
     if len(f) and (f.min() < 0 or f.max() >= len(v)):
         raise ValueError("Wrong vertex index in %s" % path)
     f = _repair(f, v)
-    if flip:
+    if flip:          # Object::FlipNormals (src/base_scene.cpp:326-335): swap the first two corners
         f = f[:, [1, 0, 2]]
+    if swap_yz:       # Object::SwapYZ (src/base_scene.cpp:337-343)
+        v = np.ascontiguousarray(v[:, [0, 2, 1]])
     return np.ascontiguousarray(v[f])
 
 

@@ -46,6 +46,8 @@ def lib():
         L.orc_render_primary.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, u64p, i32, i32]
         L.orc_account_primary.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, u64p, i32, i32]
         L.orc_shade_depth.argtypes = [vp, i32, vp, i32]
+        L.orc_planar_encode_tile.argtypes = [vp, i32, i32, i32, i32, i32, vp]
+        L.orc_planar_decode_tile.argtypes = [vp, i32, i32, i32, i32, vp, i32]
         L.orc_render_whitted.argtypes = [vp, vp, vp, i32, i32, vp, i32, vp, vp, vp, i32, u64p, i32, i32]
         for f in (L.orc_inv, L.orc_rsqrt):
             f.argtypes = [C.c_float, i32]
@@ -142,3 +144,21 @@ def shade_depth(t: np.ndarray, mode=MODE_IEEE) -> np.ndarray:
     out = np.zeros((len(tt), 3), dtype=np.uint8)
     lib().orc_shade_depth(_p(tt), len(tt), _p(out), mode)
     return out
+
+
+def planar_encode(frame_bgr: np.ndarray, tiles) -> list:
+    """per tile (x, y, w, h) the 3*w*h bytes of src/render.cpp:140-163"""
+    f = np.ascontiguousarray(frame_bgr, dtype=np.uint8)
+    out = []
+    for x, y, w, h in np.asarray(tiles).reshape(-1, 4).tolist():
+        o = np.zeros(3 * w * h, dtype=np.uint8)
+        lib().orc_planar_encode_tile(_p(f), f.shape[1] * 3, x, y, w, h, _p(o))
+        out.append(o)
+    return out
+
+
+def planar_decode(planes: list, tiles, resx: int, resy: int) -> np.ndarray:
+    f = np.zeros((resy, resx, 3), dtype=np.uint8)
+    for o, (x, y, w, h) in zip(planes, np.asarray(tiles).reshape(-1, 4).tolist()):
+        lib().orc_planar_decode_tile(_p(np.ascontiguousarray(o)), x, y, w, h, _p(f), resx * 3)
+    return f

@@ -366,6 +366,23 @@ def test_depth_shading_and_tile_pipeline(torch_mod):
         torch_mod.cuda.synchronize()
         got = frame.cpu().numpy()
         assert np.array_equal(got, want), (world, int((got != want).sum()))
+    # the render node's tile wire format (planes R, G-R, B-R per 16x64 tile) and its inverse, against the oracle
+    plan = R.ShardPlan.make(resx, resy, 2)
+    for r in range(2):
+        tiles = plan.tiles[plan.owner == r]
+        xy = torch_mod.from_numpy(R.tile_packets(tiles)).cuda()
+        bgr = sc.shade_depth(sc.trace_packets(cam, resx, resy, xy)[0])
+        first, off, total = sc.tile_layout(tiles)
+        td, fd, od = (torch_mod.from_numpy(np.ascontiguousarray(a)).cuda() for a in (tiles, first, off))
+        planar = sc.packets_bgr_to_planar(td, fd, od, bgr, torch_mod.zeros(total, dtype=torch_mod.uint8, device="cuda"))
+        # oracle: tiles cut from the oracle's frame, padded rows/columns of edge tiles do not exist in the frame -> compare per tile
+        want_planes = O.planar_encode(want, tiles)
+        got_planar = planar.cpu().numpy()
+        for k, wp in enumerate(want_planes):
+            assert np.array_equal(got_planar[off[k]:off[k] + len(wp)], wp), (r, k)
+        back = sc.planar_to_frame(td, od, planar, torch_mod.zeros((resy, resx, 3), dtype=torch_mod.uint8, device="cuda")).cpu().numpy()
+        for x, y, w, h in tiles.tolist():
+            assert np.array_equal(back[y:y + h, x:x + w], want[y:y + h, x:x + w])
     # special values: miss (+inf) -> black, tiny t -> saturated, NaN -> black
     t = torch_mod.tensor([[float("inf"), 1e-6, float("nan"), 1.0] + [2.0] * 252], dtype=torch_mod.float32, device="cuda")
     b = sc.shade_depth(t).cpu().numpy().reshape(-1, 3)

@@ -123,6 +123,17 @@ f -5 -4 -1
     q = tmp_path / "a.obj"
     scenes.save_obj(str(q), a)
     assert np.array_equal(scenes.load_obj(str(q), flip=False), a)
+    # sscanf("%f") rounds the text to float32 once: a decimal just above a float32 midpoint, which a double parse rounds onto
+    # the midpoint and then (ties-to-even) down
+    lo = np.float32(1.0); hi = np.nextafter(lo, np.float32(2.0))
+    txt = "1.00000005960464481"          # midpoint of (lo, hi) = 1.000000059604644775390625, plus 3.5e-17
+    assert float(np.float32(float(txt))) == float(lo)            # the double-rounding answer
+    r = tmp_path / "r.obj"
+    r.write_text("v %s 0 0\nv 0 1 0\nv 0 0 1\nf 1 2 3\n" % txt)
+    assert scenes.load_obj(str(r), flip=False)[0, 0, 0] == hi    # the reference's answer
+    # -swapYZ (src/base_scene.cpp:337-343) after the flip (src/rtracer.cpp:555-557)
+    sw = scenes.load_obj(str(p), flip=True, swap_yz=True)
+    assert np.array_equal(sw, want[:, [1, 0, 2]][:, :, [0, 2, 1]])
 
 
 def test_box_restatement_matches_reference_asset(reference_scenes):

@@ -132,3 +132,15 @@ def test_edge_cases_empty_and_masked_packets():
     osc.trace_rays(origin, dirs, idir, None, d4, o4, b4, 1, 64, False)
     assert np.array_equal(np.isfinite(d3), np.isfinite(d4))
     assert np.allclose(d3[np.isfinite(d3)], d4[np.isfinite(d4)], rtol=1e-5)
+
+
+def test_planar_tile_format_known_answer_and_round_trip():
+    """src/render.cpp:140-163 / src/compression.cpp:112-141: planes R, G-R, B-R with byte wrap-around; decode restores B,G,R."""
+    rng = np.random.RandomState(5)
+    frame = rng.randint(0, 256, size=(64, 48, 3)).astype(np.uint8)
+    frame[0, 0] = (10, 20, 200)       # B, G, R: R=200 -> planes 200, 20-200=76 (mod 256), 10-200=66
+    tiles = [(0, 0, 16, 64), (16, 0, 16, 64), (32, 0, 16, 64)]
+    planes = O.planar_encode(frame, tiles)
+    assert planes[0][0] == 200 and planes[0][16 * 64] == 76 and planes[0][2 * 16 * 64] == 66
+    assert all(len(p) == 3 * 16 * 64 for p in planes)
+    assert np.array_equal(O.planar_decode(planes, tiles, 48, 64), frame)
