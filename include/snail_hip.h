@@ -138,8 +138,18 @@ int snail_planar_to_frame_dev(const int32_t *d_tiles, const int64_t *d_in_offset
  * Shadow dir/idir of lanes the reference leaves uninitialised (misses; src/scene_trace.cpp:538-541) are zeros; they are
  * masked (distance = -inf) and cannot influence a result.  d_stats[2] += primary rays + shadow lanes with N.L > 0. */
 #define SNAIL_MAX_LIGHTS 8
+/* flags: SNAIL_WHITTED_REFLECTIONS = gVals[7], one bounce (src/scene_trace.cpp:454-466): Scene::TraceReflection (:603-618)
+ * mirrors every hit ray about its normal (Reflect, src/rtbase_math.h:54-58; origin = hit point + 0.001 direction), traces the
+ * packet as RayGroup<0,1> (per-ray origins, lane masks = hit lanes) through the same RayTrace -- samples, lights, shadow packets,
+ * no further bounce -- and blends diffuse += (reflected colour - diffuse) * 0.3 before the primary's own lights.  Direction and
+ * origin of lanes the mirrored packet masks off (no primary hit; uninitialised or non-finite in the reference) are zeros: such
+ * a lane has distance -inf and is culled by every box test, so a finite value there cannot influence a result.
+ * d_stats[2] += primary rays + mirrored lanes + shadow lanes with N.L > 0.  The frame is shaded in stages over packet-major
+ * intermediates held by the scene handle (8 frames may be in flight on different streams). */
+#define SNAIL_WHITTED_REFLECTIONS 1
 int snail_render_whitted_dev(SnailScene *, const float cam[13], int resx, int resy, const float *lights7, int nLights,
-                             const float ambient[3], const float color[3], uint8_t *d_frame_bgr, int pitch, uint64_t *d_stats, void *stream);
+                             const float ambient[3], const float color[3], int flags, uint8_t *d_frame_bgr, int pitch, uint64_t *d_stats,
+                             void *stream);
 
 /* ---- measurement support ------------------------------------------------------------------------- */
 /* Single-ray, cache-less accounting walk of SURVEY.md section 8(d) over the same padded packet set as

@@ -597,50 +597,90 @@ float boxPointDistanceSq(V3 mn, V3 mx, V3 p) {
 	return sq;
 }
 
-// Scene::RayTrace, simple-shading configuration, for one primary packet (see snail_oracle.h)
+// Scene::RayTrace (src/scene_trace.cpp:86-520), simple-shading configuration, for one packet of 64 quads: shared origin
+// (primary) or per-ray origins with lane masks (reflection packets).  `reflections` = gVals[7]; `depth` = cache.reflections.
+// Lanes the reference leaves uninitialised or non-finite (direction / origin of lanes that are masked off) are zeros here:
+// a masked lane has distance = -inf, so any FINITE value in it is culled by every box test and cannot influence a result.
+struct Lighting { const float *lights7; int nLights; const float *ambient, *color; bool reflections; };
+
 template <int MODE>
-void whittedPacket(const OrcNode *nodes, const OrcTri *tris, const OrcCamera &cam, const RayGen &g, int px, int py, const float *lights7,
-				   int nLights, const float *ambient, const float *color, float (*outColor)[3] /*256*/, Stats &st) {
-	float origin[12], dir[768], idir[768], dist[256], bary[512];
+void rayTracePacket(const OrcNode *nodes, const OrcTri *tris, const Rays &r, const Lighting &L, int depth, float (*outColor)[3] /*256*/, Stats &st) {
+	float dist[256], bary[512];
 	int32_t obj[256];
-	for(int c = 0; c < 3; c++) for(int l = 0; l < 4; l++) origin[c * 4 + l] = cam.pos[c];
-	genPacket<MODE>(g, px, py, dir, idir);
-	for(int i = 0; i < 256; i++) { dist[i] = kInf; obj[i] = 0; }
+	auto maskBit = [&](int q, int l) { return r.mask ? ((r.mask[q] >> l) & 1) != 0 : true; };
+	for(int q = 0; q < 64; q++) for(int l = 0; l < 4; l++) {
+		dist[q * 4 + l] = maskBit(q, l) ? kInf : -kInf;       // src/scene_trace.cpp:112-115
+		obj[q * 4 + l] = 0;
+		if(maskBit(q, l)) st.rays++;                          // stats.TracingRays(CountMaskBits(...)), :116-117
+	}
 	memset(bary, 0, sizeof(bary));
-	Rays r{64, true, origin, dir, idir, nullptr};
-	st.rays += 256;
 	traversePrimary<MODE>(nodes, tris, r, dist, obj, bary, st);
 
 	// samples (src/scene_trace.cpp:366-379, 397-452; simple_material.h:19-28)
-	float pos[256][3], nrm[256][3], sdiff[256];
+	float pos[256][3], nrm[256][3], sdiff[256][3], sspec[256][3];
 	bool hit[256];
 	float mnP[3][4], mxP[3][4];
 	for(int c = 0; c < 3; c++) for(int l = 0; l < 4; l++) { mnP[c][l] = kInf; mxP[c][l] = -kInf; }
 	for(int q = 0; q < 64; q++) for(int l = 0; l < 4; l++) {
 		const int i = q * 4 + l;
-		hit[i] = dist[i] < kInf;
-		for(int c = 0; c < 3; c++) pos[i][c] = dir[q * 12 + c * 4 + l] * dist[i] + origin[c * 4 + l];
+		hit[i] = dist[i] < kInf && maskBit(q, l);
+		for(int c = 0; c < 3; c++) pos[i][c] = r.D(q, c, l) * dist[i] + r.O(q, c, l);
 		if(hit[i]) {
 			for(int c = 0; c < 3; c++) { mnP[c][l] = Min(mnP[c][l], pos[i][c]); mxP[c][l] = Max(mxP[c][l], pos[i][c]); }
 			const OrcTri &t = tris[obj[i]];
 			for(int c = 0; c < 3; c++) nrm[i][c] = t.plane[c];
-			V3 d{dir[q * 12 + l], dir[q * 12 + 4 + l], dir[q * 12 + 8 + l]};
+			V3 d{r.D(q, 0, l), r.D(q, 1, l), r.D(q, 2, l)};
 			float dn = dot(d, mk(nrm[i]));
-			sdiff[i] = dn < 0.0f ? -dn : dn;          // Abs(rays.Dir | normal); colour applied below
-		} else { nrm[i][0] = nrm[i][1] = nrm[i][2] = 0.0f; sdiff[i] = 0.0f; }
+			dn = dn < 0.0f ? -dn : dn;                        // Abs(rays.Dir | normal)
+			for(int c = 0; c < 3; c++) sdiff[i][c] = sspec[i][c] = L.color[c] * dn;
+		} else for(int c = 0; c < 3; c++) { nrm[i][c] = 0.0f; sdiff[i][c] = sspec[i][c] = 0.0f; }
 	}
+
+	// reflections (src/scene_trace.cpp:454-466, TraceReflection :603-618, Reflect src/rtbase_math.h:54-58)
+	if(L.reflections && depth < 1) {
+		std::vector<float> rorg(768, 0.0f), rdir(768, 0.0f), ridir(768, 0.0f);
+		uint8_t sel[64];
+		bool all = true;
+		for(int q = 0; q < 64; q++) {
+			sel[q] = 0;
+			for(int l = 0; l < 4; l++) {
+				const int i = q * 4 + l;
+				if(!hit[i]) continue;
+				sel[q] |= (uint8_t)(1 << l);
+				V3 d{r.D(q, 0, l), r.D(q, 1, l), r.D(q, 2, l)}, n = mk(nrm[i]);
+				const float dt = dot(n, d);
+				const V3 rd = d - n * (dt + dt);
+				const float f[3] = {rd.x, rd.y, rd.z};
+				for(int c = 0; c < 3; c++) {
+					rdir[q * 12 + c * 4 + l] = f[c];
+					rorg[q * 12 + c * 4 + l] = pos[i][c] + f[c] * 0.001f;
+					ridir[q * 12 + c * 4 + l] = Inv<MODE>(f[c] + 0.00000001f);
+				}
+			}
+			for(int l = 0; l < 4; l++) if(!hit[q * 4 + l]) for(int c = 0; c < 3; c++) ridir[q * 12 + c * 4 + l] = Inv<MODE>(0.0f + 0.00000001f);
+			all = all && sel[q] == 15;
+		}
+		// selector.All() ? RayGroup<0,0> : RayGroup<0,1> -- the same walk either way; a full mask selects nothing away
+		Rays rr{64, false, rorg.data(), rdir.data(), ridir.data(), all ? nullptr : sel};
+		float (*reflColor)[3] = new float[256][3];
+		rayTracePacket<MODE>(nodes, tris, rr, L, depth + 1, reflColor, st);
+		for(int i = 0; i < 256; i++)
+			if(hit[i]) for(int c = 0; c < 3; c++) sdiff[i][c] = sdiff[i][c] + (reflColor[i][c] - sdiff[i][c]) * 0.3f;
+		delete[] reflColor;
+	}
+
 	V3 tMin{Min(Min(mnP[0][0], mnP[0][1]), Min(mnP[0][2], mnP[0][3])), Min(Min(mnP[1][0], mnP[1][1]), Min(mnP[1][2], mnP[1][3])),
 		   Min(Min(mnP[2][0], mnP[2][1]), Min(mnP[2][2], mnP[2][3]))};
 	V3 tMax{Max(Max(mxP[0][0], mxP[0][1]), Max(mxP[0][2], mxP[0][3])), Max(Max(mxP[1][0], mxP[1][1]), Max(mxP[1][2], mxP[1][3])),
 		   Max(Max(mxP[2][0], mxP[2][1]), Max(mxP[2][2], mxP[2][3]))};
 
 	float lDiff[256][3], lSpec[256][3];
-	for(int i = 0; i < 256; i++) for(int c = 0; c < 3; c++) { lDiff[i][c] = ambient[c]; lSpec[i][c] = 0.0f; }
+	for(int i = 0; i < 256; i++) for(int c = 0; c < 3; c++) { lDiff[i][c] = L.ambient[c]; lSpec[i][c] = 0.0f; }
 
-	for(int n = 0; n < nLights; n++) {
-		const float *L = lights7 + n * 7;
-		const V3 lpos = mk(L), lcol = mk(L + 3);
-		const float radius = L[6], iRadius = 1.0f / radius, radSq = radius * radius;   // src/light.h:9-13
+	for(int n = 0; n < L.nLights; n++) {
+		const float *LL = L.lights7 + n * 7;
+		const V3 lpos = mk(LL), lcol = mk(LL + 3);
+		const float radius = LL[6], iRadius = 1.0f / radius, radSq = radius * radius;   // src/light.h:9-13
 		if(boxPointDistanceSq(tMin, tMax, lpos) > radSq) continue;
 
 		// Scene::TraceLight (src/scene_trace.cpp:523-601)
@@ -682,15 +722,24 @@ void whittedPacket(const OrcNode *nodes, const OrcTri *tris, const OrcCamera &ca
 		}
 	}
 	for(int i = 0; i < 256; i++)
-		for(int c = 0; c < 3; c++) {
-			const float sd = color[c] * sdiff[i];     // diffuse = specular = color * |d.n| (0 for missed lanes)
-			outColor[i][c] = nLights ? sd * lDiff[i][c] + sd * lSpec[i][c] : sd;
-		}
+		for(int c = 0; c < 3; c++)      // diffuse = specular = color * |d.n| (0 for missed lanes); diffuse possibly blended with the reflection
+			outColor[i][c] = L.nLights ? sdiff[i][c] * lDiff[i][c] + sspec[i][c] * lSpec[i][c] : sdiff[i][c];
+}
+
+template <int MODE>
+void whittedPacket(const OrcNode *nodes, const OrcTri *tris, const OrcCamera &cam, const RayGen &g, int px, int py, const Lighting &L,
+				   float (*outColor)[3] /*256*/, Stats &st) {
+	float origin[12], dir[768], idir[768];
+	for(int c = 0; c < 3; c++) for(int l = 0; l < 4; l++) origin[c * 4 + l] = cam.pos[c];
+	genPacket<MODE>(g, px, py, dir, idir);
+	Rays r{64, true, origin, dir, idir, nullptr};
+	rayTracePacket<MODE>(nodes, tris, r, L, 0, outColor, st);
 }
 
 template <int MODE>
 void renderWhitted(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam, int resx, int resy, const float *lights7, int nLights,
-				   const float *ambient, const float *color, uint8_t *frame, int pitch, uint64_t *stats, int threads) {
+				   const float *ambient, const float *color, int flags, uint8_t *frame, int pitch, uint64_t *stats, int threads) {
+	const Lighting L{lights7, nLights, ambient, color, (flags & 1) != 0};
 	RayGen g = makeRayGen(*cam, resx, resy);
 	int pw = (resx + 15) / 16, ph = (resy + 15) / 16;
 	threads = std::max(threads, 1);
@@ -698,7 +747,7 @@ void renderWhitted(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *ca
 	parallelFor(pw * ph, threads, [&](int p, int tid) {
 		int px = (p % pw) * 16, py = (p / pw) * 16;
 		float col[256][3];
-		whittedPacket<MODE>(nodes, tris, *cam, g, px, py, lights7, nLights, ambient, color, col, tstats[tid]);
+		whittedPacket<MODE>(nodes, tris, *cam, g, px, py, L, col, tstats[tid]);
 		for(int q = 0; q < 64; q++) {
 			int yy = py + (q >> 2);
 			if(yy >= resy) continue;
@@ -822,9 +871,9 @@ void orc_shade_depth(const float *t, int n, uint8_t *bgr, int mode) {
 }
 
 void orc_render_whitted(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam, int resx, int resy, const float *lights7, int nLights,
-						const float ambient[3], const float color[3], uint8_t *frame_bgr, int pitch, uint64_t *stats, int mode, int threads) {
-	if(mode == ORC_MODE_SSE) renderWhitted<ORC_MODE_SSE>(nodes, tris, cam, resx, resy, lights7, nLights, ambient, color, frame_bgr, pitch, stats, threads);
-	else renderWhitted<ORC_MODE_IEEE>(nodes, tris, cam, resx, resy, lights7, nLights, ambient, color, frame_bgr, pitch, stats, threads);
+						const float ambient[3], const float color[3], int flags, uint8_t *frame_bgr, int pitch, uint64_t *stats, int mode, int threads) {
+	if(mode == ORC_MODE_SSE) renderWhitted<ORC_MODE_SSE>(nodes, tris, cam, resx, resy, lights7, nLights, ambient, color, flags, frame_bgr, pitch, stats, threads);
+	else renderWhitted<ORC_MODE_IEEE>(nodes, tris, cam, resx, resy, lights7, nLights, ambient, color, flags, frame_bgr, pitch, stats, threads);
 }
 
 // the `compress` store of RenderTask::Work (src/render.cpp:140-163): planes R, G-R, B-R of a tile, from the interleaved B,G,R frame

@@ -104,9 +104,14 @@ void orc_shade_depth(const float *t, int n, uint8_t *bgr, int mode);
  * (src/render.cpp:11-17,171-198).  lights = nLights x {pos[3], color[3], radius}; frame_bgr = resy rows of `pitch`
  * bytes.  Lanes/quads the reference leaves UNINITIALISED (shadow dir/idir of missed lanes and of quads without any
  * hit, src/scene_trace.cpp:538-541) are zeros here; they are masked (distance = -inf) and cannot influence a result.
- * stats[4] += {intersects, iters, rays (primary + shadow lanes with N.L > 0), skips}. */
+ * flags bit 0 = gVals[7], one reflection bounce (src/scene_trace.cpp:454-466): Scene::TraceReflection (:603-618) mirrors
+ * every hit ray about its normal (Reflect, src/rtbase_math.h:54-58), origin = hit point + 0.001 * direction, traces the
+ * packet as RayGroup<0,1> (per-ray origins, lane masks = hit lanes) through the same RayTrace -- samples, lights, shadow
+ * packets, no further bounce -- and blends diffuse += (reflected colour - diffuse) * 0.3 BEFORE the primary's own lights.
+ * Lanes that are masked off in the reflected packet (no primary hit) carry zeros here (see above).
+ * stats[4] += {intersects, iters, rays (primary + reflected lanes + shadow lanes with N.L > 0), skips}. */
 void orc_render_whitted(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam, int resx, int resy,
-                        const float *lights7, int nLights, const float ambient[3], const float color[3],
+                        const float *lights7, int nLights, const float ambient[3], const float color[3], int flags,
                         uint8_t *frame_bgr, int pitch, uint64_t *stats, int mode, int threads);
 
 /* The render node's tile wire format: the `compress` store of RenderTask::Work (src/render.cpp:140-163) -- planes R, G-R, B-R

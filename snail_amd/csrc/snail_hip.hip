@@ -761,6 +761,7 @@ struct PrimaryArgs {
 	const int2 *packetXY;		  // ... or explicit packet list (packet-major layout)
 	int nPackets, pw, ph;		  // packet grid of the rect
 	int nBlocks;
+	int packetMajor;              // rect mode: store packet-major ([cy*pw+cx][256], the reference's quad order) instead of frame layout
 	int fastOK;
 	float *t, *u, *v;
 	int *id;
@@ -864,7 +865,7 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 		A.cost[(size_t)pidx * 4 + 2] = (unsigned)(tEnd - tStart); A.cost[(size_t)pidx * 4 + 3] = (unsigned)(tStart >> 6);
 	}
 
-	if(A.packetXY) { // packet-major (Context layout)
+	if(A.packetXY || A.packetMajor) { // packet-major (Context layout)
 		const size_t o = (size_t)pidx * 256 + (size_t)lane * 4;
 		if(A.t) *(float4 *)(A.t + o) = make_float4(Q.dist[0], Q.dist[1], Q.dist[2], Q.dist[3]);
 		if(A.u) *(float4 *)(A.u + o) = make_float4(bu[0], bu[1], bu[2], bu[3]);
@@ -911,13 +912,49 @@ __global__ __launch_bounds__(64) void k_primary_exact(PrimaryArgs A) {
 }
 
 // ---- Scene::RayTrace, simple-shading configuration, fused per packet (primary walk + one shadow walk per light) ----
-struct WhittedArgs {
+__device__ __forceinline__ void loadQuad3(const float *base, size_t quad, float (&v)[3][4]) {
+	const float4 *p = (const float4 *)(base + quad * 12);
+	float4 x = p[0], y = p[1], z = p[2];
+	v[0][0] = x.x; v[0][1] = x.y; v[0][2] = x.z; v[0][3] = x.w;
+	v[1][0] = y.x; v[1][1] = y.y; v[1][2] = y.z; v[1][3] = y.w;
+	v[2][0] = z.x; v[2][1] = z.y; v[2][2] = z.z; v[2][3] = z.w;
+}
+
+// ---- Scene::RayTrace after the traversal: samples, reflection rays, lights (BASELINE config 3) --------------------------
+// The frame is shaded in stages over packet-major buffers that stay in HBM (288 GB: a 1080p frame's intermediate state is
+// ~150 MB), each stage with its own register budget instead of one kernel holding two walks and all samples at once:
+//   k_primary                        hits of the primary packets                               (the bench kernel, 5 waves/SIMD)
+//   k_light<SRC_PRIMARY>             one wave per (packet, light): samples -> shadow packet -> TraverseShadow -> the
+//                                    surviving distances, 4 B/ray/light            Scene::TraceLight, src/scene_trace.cpp:523-566
+//   k_final<SRC_PRIMARY, DST_FRAME>  samples, attenuation and accumulation per light from those distances, B,G,R store
+//                                                                                  src/scene_trace.cpp:567-601, 484-512
+// and with gVals[7] (one mirrored bounce), between k_primary and k_light:
+//   k_final<SRC_PRIMARY, DST_MIRROR> samples -> mirrored rays + lane masks          Scene::TraceReflection, :603-618
+//   k_rays<false,true>               TraversePrimary<0,1> of the mirrored packets
+//   k_light<SRC_MIRROR>, k_final<SRC_MIRROR, DST_COLOR>   the nested RayTrace of the mirrored packets -> colour per ray (float)
+// k_final<SRC_PRIMARY, DST_FRAME> then blends diffuse += (colour - diffuse) * 0.3 (:462-465).  Samples and shadow rays are
+// recomputed (the same operations on the same operands, hence the same bits) wherever they are needed: a few hundred VALU
+// instructions per packet against the thousands of a walk, and no kernel carries state across a walk that the walk does not use.
+enum { SRC_PRIMARY = 0, SRC_MIRROR = 1 };
+enum { DST_FRAME = 0, DST_MIRROR = 1, DST_COLOR = 2 };
+struct ShadeArgs {
 	const uint4 *nodes, *tris;
 	GenConst g;
 	int resx, resy, pw, ph, fastOK;
+	int nBlocks;         // grid.x of the per-packet kernels (packets padded to whole XCD regions)
 	int nLights;
 	float lights[SNAIL_MAX_LIGHTS][7];
 	float ambient[3], color[3];
+	const float *hitT;   // primary hits, packet-major
+	const int *hitId;
+	float *rOrg, *rDir, *rIDir; // mirrored packets (Context layout: per quad x[4], y[4], z[4])
+	unsigned char *rMask;
+	float *rDist;
+	int *rObj;
+	float *rCol;         // colour of the mirrored rays, [packet][256][3]
+	float *sDist;        // shadow distances after TraverseShadow, [light][packet][256]
+	int blend;           // DST_FRAME: diffuse += (rCol - diffuse) * 0.3 on hit lanes
+	int *defer;          // [0] = count, [1] = finished blocks of the M_EXACT pass, [16..] = light * nBlocks + grid index of deferred shadow packets
 	unsigned char *frame;
 	int pitch;
 	u64 *stats;
@@ -930,154 +967,309 @@ __device__ __forceinline__ int convChannelW(float c) {
 	return (int)v;
 }
 
-template <bool DEEP>
-__global__ __launch_bounds__(64) void k_whitted(WhittedArgs A) {
-	__shared__ float lds[LDS_FLOATS_PER_WAVE];
-	const int lane = threadIdx.x & 63;
-	const int li = interleave16((int)blockIdx.x);
+struct PacketPos {
+	int px, py;
+	size_t pidx;
+	bool valid;
+};
+__device__ __forceinline__ PacketPos packetOf(const ShadeArgs &A, int li) {
 	const int nrx = (A.pw + 3) >> 2;
 	const int region = li >> 4, kk = li & 15;
 	const int cx = (region % nrx) * 4 + (kk & 3), cy = (region / nrx) * 4 + (kk >> 2);
-	if(cx >= A.pw || cy >= A.ph) return;
-	const int px = cx * 16, py = cy * 16;
-	const float inf = __builtin_inff();
+	PacketPos P;
+	P.valid = cx < A.pw && cy < A.ph;
+	P.px = cx * 16; P.py = cy * 16;
+	P.pidx = (size_t)cy * A.pw + cx;
+	return P;
+}
 
-	Quad Q;
-	const int ty = lane >> 2, k4 = lane & 3;
+// the packet's rays and hits, then its samples: src/scene_trace.cpp:366-379,397-452 + SimpleMaterial::Shade_
+// (src/shading/simple_material.h:19-28).  sdn = Abs(rays.Dir | normal) (the colour is applied at the end).
+struct Samples {
+	bool hit[4];
+	float pos[3][4], nrm[3][4], sdn[4];
+};
+template <int SRC>
+__device__ __forceinline__ void loadSamples(const ShadeArgs &A, const PacketPos &P, int lane, float (&d)[3][4], Samples &S) {
+	const size_t quad = P.pidx * 64 + lane;
+	const float inf = __builtin_inff();
+	float org[3][4], dist[4];
+	int tid[4];
+	unsigned mask4 = 15u;
+	if(SRC == SRC_MIRROR) {
+		loadQuad3(A.rDir, quad, d);
+		loadQuad3(A.rOrg, quad, org);
+		mask4 = A.rMask[quad] & 15u;
+		const float4 dv = *(const float4 *)(A.rDist + quad * 4);
+		const int4 ov = *(const int4 *)(A.rObj + quad * 4);
+		dist[0] = dv.x; dist[1] = dv.y; dist[2] = dv.z; dist[3] = dv.w;
+		tid[0] = ov.x; tid[1] = ov.y; tid[2] = ov.z; tid[3] = ov.w;
+	} else {
+		const int ty = lane >> 2, k4 = lane & 3;
+#pragma unroll
+		for(int l = 0; l < 4; l++) { // RayGenerator::Generate, exactly as in primaryPacket
+			const float xoff = (float)(P.px + (l >= 2 ? 2 : 0)), yoff = (float)(P.py - (l >= 2 ? 1 : 0));
+			const float tposx = (float)(4 * k4) + xoff, tposy = (float)ty + yoff;
+			const float p0 = A.g.tright[0] * tposx + (A.g.tup[0] * tposy + A.g.txyz[0][l]);
+			const float p1 = A.g.tright[1] * tposx + (A.g.tup[1] * tposy + A.g.txyz[1][l]);
+			const float p2 = A.g.tright[2] * tposx + (A.g.tup[2] * tposy + A.g.txyz[2][l]);
+			const float rs = 1.0f / __builtin_sqrtf(p0 * p0 + p1 * p1 + p2 * p2);
+			d[0][l] = p0 * rs; d[1][l] = p1 * rs; d[2][l] = p2 * rs;
+#pragma unroll
+			for(int c = 0; c < 3; c++) org[c][l] = A.g.org[c];
+		}
+		const float4 dv = *(const float4 *)(A.hitT + quad * 4);
+		const int4 ov = *(const int4 *)(A.hitId + quad * 4);
+		dist[0] = dv.x; dist[1] = dv.y; dist[2] = dv.z; dist[3] = dv.w;
+		tid[0] = ov.x; tid[1] = ov.y; tid[2] = ov.z; tid[3] = ov.w;
+	}
 #pragma unroll
 	for(int l = 0; l < 4; l++) {
-		const float xoff = (float)(px + (l >= 2 ? 2 : 0)), yoff = (float)(py - (l >= 2 ? 1 : 0));
-		const float tposx = (float)(4 * k4) + xoff, tposy = (float)ty + yoff;
-		const float p0 = A.g.tright[0] * tposx + (A.g.tup[0] * tposy + A.g.txyz[0][l]);
-		const float p1 = A.g.tright[1] * tposx + (A.g.tup[1] * tposy + A.g.txyz[1][l]);
-		const float p2 = A.g.tright[2] * tposx + (A.g.tup[2] * tposy + A.g.txyz[2][l]);
-		const float rs = 1.0f / __builtin_sqrtf(p0 * p0 + p1 * p1 + p2 * p2);
-		Q.d[0][l] = p0 * rs; Q.d[1][l] = p1 * rs; Q.d[2][l] = p2 * rs;
+		S.hit[l] = dist[l] < inf && ((mask4 >> l) & 1u) != 0;
 #pragma unroll
-		for(int c = 0; c < 3; c++) Q.id[c][l] = 1.0f / (Q.d[c][l] + 0.00000001f);
-		Q.dist[l] = inf;
+		for(int c = 0; c < 3; c++) S.pos[c][l] = d[c][l] * dist[l] + org[c][l];
+		const float4 pl = *(const float4 *)((const float *)(A.tris + (size_t)(S.hit[l] ? tid[l] : 0) * 4) + 12); // GetNormal = plane.xyz (src/bvh/tree.h:40-42)
+		S.nrm[0][l] = S.hit[l] ? pl.x : 0.0f; S.nrm[1][l] = S.hit[l] ? pl.y : 0.0f; S.nrm[2][l] = S.hit[l] ? pl.z : 0.0f;
+		const float dn = d[0][l] * S.nrm[0][l] + d[1][l] * S.nrm[1][l] + d[2][l] * S.nrm[2][l];
+		S.sdn[l] = S.hit[l] ? __builtin_fabsf(dn) : 0.0f;
 	}
-	int tid[4] = {0, 0, 0, 0};
-	float bu[4], bv[4];
-	float org[3][4];
-#pragma unroll
-	for(int c = 0; c < 3; c++)
-#pragma unroll
-		for(int l = 0; l < 4; l++) org[c][l] = A.g.org[c];
+}
 
-	Counters st = {0, 0, 0};
-	unsigned rays = 256u;
-	{
-		const int mode = classify(A.fastOK != 0, finite4(Q.id) && finite4(Q.d), true, Q.id);
-		if(mode == M_COH) walk<true, false, false, M_COH, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st);
-		else if(mode == M_FAST) walk<true, false, false, M_FAST, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st);
-		else walk<true, false, false, M_EXACT, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st);
-	}
-
-	// ---- samples: src/scene_trace.cpp:366-379,397-452 + SimpleMaterial::Shade_ (src/shading/simple_material.h:19-28) ----
-	bool hit[4];
-	float pos[3][4], nrm[3][4], sdiff[4];
+// bbox of the packet's hit points: per SSE slot over the quads, then Minimize / Maximize (src/scene_trace.cpp:375-376,
+// src/rtbase_math.h:63-64)
+__device__ __forceinline__ void hitBounds(const Samples &S, float (&tMin)[3], float (&tMax)[3]) {
+	const float inf = __builtin_inff();
 	float mnP[3][4], mxP[3][4];
 #pragma unroll
-	for(int l = 0; l < 4; l++) {
-		hit[l] = Q.dist[l] < inf;
-#pragma unroll
-		for(int c = 0; c < 3; c++) pos[c][l] = Q.d[c][l] * Q.dist[l] + org[c][l];
-		const Tri t = loadTriVector(A.tris, hit[l] ? tid[l] : 0);
+	for(int l = 0; l < 4; l++)
 #pragma unroll
 		for(int c = 0; c < 3; c++) {
-			nrm[c][l] = hit[l] ? t.n[c] : 0.0f;
-			mnP[c][l] = waveMin(hit[l] ? pos[c][l] : inf);   // per SSE slot over the packet's quads (minPos/maxPos)
-			mxP[c][l] = waveMax(hit[l] ? pos[c][l] : -inf);
+			mnP[c][l] = waveMin(S.hit[l] ? S.pos[c][l] : inf);
+			mxP[c][l] = waveMax(S.hit[l] ? S.pos[c][l] : -inf);
 		}
-		const float dn = Q.d[0][l] * nrm[0][l] + Q.d[1][l] * nrm[1][l] + Q.d[2][l] * nrm[2][l];
-		sdiff[l] = hit[l] ? __builtin_fabsf(dn) : 0.0f;
-	}
-	float tMin[3], tMax[3]; // Minimize / Maximize (src/rtbase_math.h:63-64)
 #pragma unroll
 	for(int c = 0; c < 3; c++) {
 		tMin[c] = Min<M_EXACT>(Min<M_EXACT>(mnP[c][0], mnP[c][1]), Min<M_EXACT>(mnP[c][2], mnP[c][3]));
 		tMax[c] = Max<M_EXACT>(Max<M_EXACT>(mxP[c][0], mxP[c][1]), Max<M_EXACT>(mxP[c][2], mxP[c][3]));
 	}
+}
+// the packet-level light cull: BoxPointDistanceSq(bbox, light) > radSq (src/scene_trace.cpp:494-501, src/funcs.cpp:8-49); wave-uniform
+__device__ __forceinline__ bool lightCulled(const float (&tMin)[3], const float (&tMax)[3], const float (&lp)[3], float radSq) {
+	float sq = 0.0f;
+#pragma unroll
+	for(int c = 0; c < 3; c++) {
+		if(lp[c] < tMin[c]) { const float dl = lp[c] - tMin[c]; sq += dl * dl; }
+		else if(lp[c] > tMax[c]) { const float dl = lp[c] - tMax[c]; sq += dl * dl; }
+	}
+	return sq > radSq;
+}
+// one lane of the shadow packet (src/scene_trace.cpp:538-558): fromLight = (position - light) / |position - light|, its N.L, and
+// the ray length 0.9999 |..| when N.L > 0 (-inf = masked otherwise).  Lanes without a hit: zeros, masked.
+__device__ __forceinline__ void shadowLane(const Samples &S, int l, const float (&lp)[3], float (&sd)[3], float &distance, float &dotv, float &sdist) {
+	sd[0] = sd[1] = sd[2] = 0.0f;
+	sdist = -__builtin_inff(); distance = 0.0f; dotv = 0.0f;
+	if(S.hit[l]) {
+		float lv[3] = {S.pos[0][l] - lp[0], S.pos[1][l] - lp[1], S.pos[2][l] - lp[2]};
+		if(lv[0] * lv[0] + lv[1] * lv[1] + lv[2] * lv[2] < 0.0001f) { lv[0] = 0.0f; lv[1] = 1.0f; lv[2] = 0.0f; }
+		distance = __builtin_sqrtf(lv[0] * lv[0] + lv[1] * lv[1] + lv[2] * lv[2]);
+		const float inv = 1.0f / distance;
+#pragma unroll
+		for(int c = 0; c < 3; c++) sd[c] = lv[c] * inv;
+		dotv = S.nrm[0][l] * sd[0] + S.nrm[1][l] * sd[1] + S.nrm[2][l] * sd[2];
+		if(dotv > 0.0f) sdist = distance * 0.9999f;
+	}
+}
 
+// ---- one (packet, light): the shadow packet and its walk ----
+// EXACTPASS=false: the main kernel, walks in M_COH / M_FAST; a shadow packet that needs M_EXACT (a non-finite value: practically
+// never) is appended to A.defer untouched -- nothing has been written or counted for it -- and traced by the second, tiny
+// launch (EXACTPASS=true; M_EXACT is valid for any packet).  As in the primary kernel this keeps the select-based walk out
+// of the main kernel's register allocation.
+template <bool DEEP, int SRC, bool EXACTPASS>
+__device__ __forceinline__ void lightPacket(const ShadeArgs &A, const int li, const int n, float *lds) {
+	const int lane = threadIdx.x & 63;
+	const PacketPos P = packetOf(A, li);
+	if(!P.valid) return;
+	const float lp[3] = {A.lights[n][0], A.lights[n][1], A.lights[n][2]};
+	const float radius = A.lights[n][6], radSq = radius * radius;
+	Quad Q;
+	{
+		float d[3][4];
+		Samples S;
+		loadSamples<SRC>(A, P, lane, d, S);
+		float tMin[3], tMax[3];
+		hitBounds(S, tMin, tMax);
+		if(lightCulled(tMin, tMax, lp, radSq)) return;
+#pragma unroll
+		for(int l = 0; l < 4; l++) {
+			float sd[3], distance, dotv;
+			shadowLane(S, l, lp, sd, distance, dotv, Q.dist[l]);
+#pragma unroll
+			for(int c = 0; c < 3; c++) { Q.d[c][l] = sd[c]; Q.id[c][l] = S.hit[l] ? 1.0f / (sd[c] + 0.00000001f) : 0.0f; }
+		}
+	}
+	unsigned rays = 0;
+#pragma unroll
+	for(int l = 0; l < 4; l++) rays += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(Q.dist[l] > 0.0f));
+	float lorg[3][4];
+#pragma unroll
+	for(int c = 0; c < 3; c++)
+#pragma unroll
+		for(int l = 0; l < 4; l++) lorg[c][l] = lp[c];
+	Counters st = {0, 0, 0};
+	int stid[4];
+	float bu[4], bv[4];
+	if(EXACTPASS) walk<true, false, true, M_EXACT, false, DEEP, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st);
+	else {
+		const bool fin = finite4(Q.id) && finite4(Q.d);
+		const int mode = classify(A.fastOK != 0 && originSaneDev(lp), fin, true, Q.id);
+		if(mode == M_EXACT) {
+			if(lane == 0) A.defer[16 + atomicAdd(&A.defer[0], 1)] = n * A.nBlocks + li;
+			return;
+		}
+		if(mode == M_COH) walk<true, false, true, M_COH, false, DEEP, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st);
+		else walk<true, false, true, M_FAST, false, DEEP, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st);
+	}
+	flushStats(A.stats, st, rays, lane);
+	const size_t packets = (size_t)A.pw * A.ph;
+	*(float4 *)(A.sDist + ((size_t)n * packets + P.pidx) * 256 + (size_t)lane * 4) = make_float4(Q.dist[0], Q.dist[1], Q.dist[2], Q.dist[3]);
+}
+
+template <bool DEEP, int SRC>
+__global__ __launch_bounds__(64) void k_light(ShadeArgs A) {
+	__shared__ float lds[LDS_FLOATS_PER_WAVE];
+	lightPacket<DEEP, SRC, false>(A, interleave16((int)blockIdx.x), (int)blockIdx.y, lds);
+}
+template <bool DEEP, int SRC>
+__global__ __launch_bounds__(64) void k_light_exact(ShadeArgs A) {
+	__shared__ float lds[LDS_FLOATS_PER_WAVE];
+	const int cnt = __builtin_amdgcn_readfirstlane(A.defer[0]);
+	for(int i = (int)blockIdx.x; i < cnt; i += (int)gridDim.x) {
+		const int e = __builtin_amdgcn_readfirstlane(A.defer[16 + i]);
+		lightPacket<DEEP, SRC, true>(A, e % A.nBlocks, e / A.nBlocks, lds);
+	}
+	__threadfence();
+	if((threadIdx.x & 63) == 0 && atomicAdd(&A.defer[1], 1) == (int)gridDim.x - 1) { A.defer[0] = 0; A.defer[1] = 0; }
+}
+
+// ---- one packet: samples -> mirrored rays (DST_MIRROR), or samples + the lights' contributions -> colour ----
+template <int SRC, int DST>
+__global__ __launch_bounds__(64) void k_final(ShadeArgs A) {
+	const int lane = threadIdx.x & 63;
+	const PacketPos P = packetOf(A, interleave16((int)blockIdx.x));
+	if(!P.valid) return;
+	const size_t quad = P.pidx * 64 + lane;
+	const float inf = __builtin_inff();
+	float d[3][4];
+	Samples S;
+	loadSamples<SRC>(A, P, lane, d, S);
+
+	if(DST == DST_MIRROR) {
+		// Scene::TraceReflection (src/scene_trace.cpp:603-618): Reflect (src/rtbase_math.h:54-58), origin = position + 0.001 dir,
+		// SafeInv; selector = hit lanes.  Masked lanes: zeros (see include/snail_hip.h), distance -inf.
+		float rd[3][4], ro[3][4], ri[3][4], rdist[4];
+		unsigned sel = 0;
+#pragma unroll
+		for(int l = 0; l < 4; l++) {
+			const float dt = S.nrm[0][l] * d[0][l] + S.nrm[1][l] * d[1][l] + S.nrm[2][l] * d[2][l];
+			const float dt2 = dt + dt;
+#pragma unroll
+			for(int c = 0; c < 3; c++) {
+				const float r = d[c][l] - S.nrm[c][l] * dt2;
+				rd[c][l] = S.hit[l] ? r : 0.0f;
+				ro[c][l] = S.hit[l] ? S.pos[c][l] + r * 0.001f : 0.0f;
+				ri[c][l] = 1.0f / (rd[c][l] + 0.00000001f);
+			}
+			rdist[l] = S.hit[l] ? inf : -inf; // src/scene_trace.cpp:112-115
+			sel |= S.hit[l] ? (1u << l) : 0u;
+		}
+		float4 *po = (float4 *)(A.rOrg + quad * 12), *pd = (float4 *)(A.rDir + quad * 12), *pi = (float4 *)(A.rIDir + quad * 12);
+#pragma unroll
+		for(int c = 0; c < 3; c++) {
+			po[c] = make_float4(ro[c][0], ro[c][1], ro[c][2], ro[c][3]);
+			pd[c] = make_float4(rd[c][0], rd[c][1], rd[c][2], rd[c][3]);
+			pi[c] = make_float4(ri[c][0], ri[c][1], ri[c][2], ri[c][3]);
+		}
+		A.rMask[quad] = (unsigned char)sel;
+		*(float4 *)(A.rDist + quad * 4) = make_float4(rdist[0], rdist[1], rdist[2], rdist[3]);
+		*(int4 *)(A.rObj + quad * 4) = make_int4(0, 0, 0, 0);
+		// stats.TracingRays(CountMaskBits(mask)) of the nested RayTrace (src/scene_trace.cpp:116-117)
+		unsigned cnt = 0;
+#pragma unroll
+		for(int l = 0; l < 4; l++) cnt += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(S.hit[l]));
+		const Counters none = {0, 0, 0};
+		flushStats(A.stats, none, cnt, lane);
+		return;
+	}
+
+	// ---- lights: src/scene_trace.cpp:484-512; per light the tail of Scene::TraceLight (:567-601) ----
 	float lDiff[3][4], lSpec[3][4];
 #pragma unroll
 	for(int c = 0; c < 3; c++)
 #pragma unroll
 		for(int l = 0; l < 4; l++) { lDiff[c][l] = A.ambient[c]; lSpec[c][l] = 0.0f; }
-
-	for(int n = 0; n < A.nLights; n++) {
-		const float lp[3] = {A.lights[n][0], A.lights[n][1], A.lights[n][2]};
-		const float lc[3] = {A.lights[n][3], A.lights[n][4], A.lights[n][5]};
-		const float radius = A.lights[n][6], iRadius = 1.0f / radius, radSq = radius * radius;
-		{ // BoxPointDistanceSq (src/funcs.cpp:8-49), wave-uniform
-			float sq = 0.0f;
+	if(A.nLights) {
+		float tMin[3], tMax[3];
+		hitBounds(S, tMin, tMax);
+		const size_t packets = (size_t)A.pw * A.ph;
+		for(int n = 0; n < A.nLights; n++) {
+			const float lp[3] = {A.lights[n][0], A.lights[n][1], A.lights[n][2]};
+			const float lc[3] = {A.lights[n][3], A.lights[n][4], A.lights[n][5]};
+			const float radius = A.lights[n][6], iRadius = 1.0f / radius, radSq = radius * radius;
+			if(lightCulled(tMin, tMax, lp, radSq)) continue;
+			const float4 sv = *(const float4 *)(A.sDist + ((size_t)n * packets + P.pidx) * 256 + (size_t)lane * 4);
+			const float sdist[4] = {sv.x, sv.y, sv.z, sv.w};
 #pragma unroll
-			for(int c = 0; c < 3; c++) {
-				if(lp[c] < tMin[c]) { const float dl = lp[c] - tMin[c]; sq += dl * dl; }
-				else if(lp[c] > tMax[c]) { const float dl = lp[c] - tMax[c]; sq += dl * dl; }
+			for(int l = 0; l < 4; l++) {
+				float sd[3], distance, dotv, unused;
+				shadowLane(S, l, lp, sd, distance, dotv, unused);
+				if(sdist[l] > 0.0f) {
+					float atten = distance * iRadius;
+					atten = Max<M_EXACT>(0.0f, ((1.0f - atten) * 0.2f + 1.0f / (16.0f * atten * atten)) - 0.0625f);
+					const float diffMul = dotv * atten;
+					float specMul = dotv;
+					specMul *= specMul; specMul *= specMul; specMul *= specMul; specMul *= specMul;
+					specMul *= atten;
+#pragma unroll
+					for(int c = 0; c < 3; c++) { lDiff[c][l] += lc[c] * diffMul; lSpec[c][l] += lc[c] * specMul; }
+				}
 			}
-			if(sq > radSq) continue;
 		}
-		// ---- Scene::TraceLight (src/scene_trace.cpp:523-601) ----
-		Quad S;
-		float distance[4], dotv[4];
-		float lorg[3][4];
-		unsigned cnt = 0;
+	}
+
+	// ---- outColor = diffuse * lDiffuse + specular * lSpecular (src/scene_trace.cpp:504-512) ----
+	float col[3][4];
+#pragma unroll
+	for(int l = 0; l < 4; l++) {
+		float refl[3] = {0.0f, 0.0f, 0.0f};
+		if(DST == DST_FRAME && A.blend) {
+			const float *rc = A.rCol + (quad * 4 + l) * 3;
+			refl[0] = rc[0]; refl[1] = rc[1]; refl[2] = rc[2];
+		}
+#pragma unroll
+		for(int c = 0; c < 3; c++) {
+			const float spec = A.color[c] * S.sdn[l];
+			float diff = spec;
+			if(DST == DST_FRAME && A.blend && S.hit[l]) diff = diff + (refl[c] - diff) * 0.3f; // src/scene_trace.cpp:462-465
+			col[c][l] = A.nLights ? diff * lDiff[c][l] + spec * lSpec[c][l] : diff;
+		}
+	}
+	if(DST == DST_COLOR) {
 #pragma unroll
 		for(int l = 0; l < 4; l++) {
-#pragma unroll
-			for(int c = 0; c < 3; c++) { S.d[c][l] = 0.0f; S.id[c][l] = 0.0f; lorg[c][l] = lp[c]; }
-			S.dist[l] = -inf; distance[l] = 0.0f; dotv[l] = 0.0f;
-			if(hit[l]) {
-				float lv[3] = {pos[0][l] - lp[0], pos[1][l] - lp[1], pos[2][l] - lp[2]};
-				if(lv[0] * lv[0] + lv[1] * lv[1] + lv[2] * lv[2] < 0.0001f) { lv[0] = 0.0f; lv[1] = 1.0f; lv[2] = 0.0f; }
-				distance[l] = __builtin_sqrtf(lv[0] * lv[0] + lv[1] * lv[1] + lv[2] * lv[2]);
-				const float inv = 1.0f / distance[l];
-#pragma unroll
-				for(int c = 0; c < 3; c++) { S.d[c][l] = lv[c] * inv; S.id[c][l] = 1.0f / (S.d[c][l] + 0.00000001f); }
-				dotv[l] = nrm[0][l] * S.d[0][l] + nrm[1][l] * S.d[1][l] + nrm[2][l] * S.d[2][l];
-				if(dotv[l] > 0.0f) S.dist[l] = distance[l] * 0.9999f;
-			}
-			cnt += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(S.dist[l] > 0.0f));
+			float *rc = A.rCol + (quad * 4 + l) * 3;
+			rc[0] = col[0][l]; rc[1] = col[1][l]; rc[2] = col[2][l];
 		}
-		rays += cnt;
-		{
-			bool fin = finite4(S.id) && finite4(S.d);
-			const int mode = classify(A.fastOK != 0 && originSaneDev(lp), fin, true, S.id);
-			int stid[4];
-			if(mode == M_COH) walk<true, false, true, M_COH, false, DEEP, false>(A.nodes, A.tris, 64, lane, lorg, S, 15u, stid, bu, bv, lds, st);
-			else if(mode == M_FAST) walk<true, false, true, M_FAST, false, DEEP, false>(A.nodes, A.tris, 64, lane, lorg, S, 15u, stid, bu, bv, lds, st);
-			else walk<true, false, true, M_EXACT, false, DEEP, false>(A.nodes, A.tris, 64, lane, lorg, S, 15u, stid, bu, bv, lds, st);
-		}
-#pragma unroll
-		for(int l = 0; l < 4; l++)
-			if(S.dist[l] > 0.0f) {
-				float atten = distance[l] * iRadius;
-				atten = Max<M_EXACT>(0.0f, ((1.0f - atten) * 0.2f + 1.0f / (16.0f * atten * atten)) - 0.0625f);
-				const float diffMul = dotv[l] * atten;
-				float specMul = dotv[l];
-				specMul *= specMul; specMul *= specMul; specMul *= specMul; specMul *= specMul;
-				specMul *= atten;
-#pragma unroll
-				for(int c = 0; c < 3; c++) { lDiff[c][l] += lc[c] * diffMul; lSpec[c][l] += lc[c] * specMul; }
-			}
+		return;
 	}
-	flushStats(A.stats, st, rays, lane);
-
-	const int yy = py + ty, xx = px + k4 * 4;
+	const int yy = P.py + (lane >> 2), xx = P.px + (lane & 3) * 4;
 	if(yy < A.resy) {
-		unsigned char *d = A.frame + (size_t)yy * A.pitch + (size_t)xx * 3;
+		unsigned char *dd = A.frame + (size_t)yy * A.pitch + (size_t)xx * 3;
 #pragma unroll
 		for(int l = 0; l < 4; l++)
 			if(xx + l < A.resx) {
-				float col[3];
-#pragma unroll
-				for(int c = 0; c < 3; c++) {
-					const float sd = A.color[c] * sdiff[l];
-					col[c] = A.nLights ? sd * lDiff[c][l] + sd * lSpec[c][l] : sd;
-				}
-				d[l * 3 + 0] = (unsigned char)convChannelW(col[2]); d[l * 3 + 1] = (unsigned char)convChannelW(col[1]); d[l * 3 + 2] = (unsigned char)convChannelW(col[0]);
+				dd[l * 3 + 0] = (unsigned char)convChannelW(col[2][l]); dd[l * 3 + 1] = (unsigned char)convChannelW(col[1][l]);
+				dd[l * 3 + 2] = (unsigned char)convChannelW(col[0][l]);
 			}
 	}
 }
@@ -1094,13 +1286,6 @@ struct RaysArgs {
 	u64 *stats;
 };
 
-__device__ __forceinline__ void loadQuad3(const float *base, size_t quad, float (&v)[3][4]) {
-	const float4 *p = (const float4 *)(base + quad * 12);
-	float4 x = p[0], y = p[1], z = p[2];
-	v[0][0] = x.x; v[0][1] = x.y; v[0][2] = x.z; v[0][3] = x.w;
-	v[1][0] = y.x; v[1][1] = y.y; v[1][2] = y.z; v[1][3] = y.w;
-	v[2][0] = z.x; v[2][1] = z.y; v[2][2] = z.z; v[2][3] = z.w;
-}
 
 template <bool SHARED, bool MASK>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_rays(RaysArgs A) {
@@ -1128,7 +1313,8 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_rays(RaysArgs A) {
 	if(MASK) mask4 = A.mask[q] & 15u;
 	float4 dv = *(const float4 *)(A.distance + q * 4);
 	int4 ov = *(const int4 *)(A.object + q * 4);
-	float4 b0 = *(const float4 *)(A.bary + q * 8), b1 = *(const float4 *)(A.bary + q * 8 + 4);
+	float4 b0 = make_float4(0, 0, 0, 0), b1 = b0;
+	if(A.bary) { b0 = *(const float4 *)(A.bary + q * 8); b1 = *(const float4 *)(A.bary + q * 8 + 4); }
 	Q.dist[0] = dv.x; Q.dist[1] = dv.y; Q.dist[2] = dv.z; Q.dist[3] = dv.w;
 	int tid[4] = {ov.x, ov.y, ov.z, ov.w};
 	float bu[4] = {b0.x, b0.y, b0.z, b0.w}, bv[4] = {b1.x, b1.y, b1.z, b1.w};
@@ -1146,8 +1332,10 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_rays(RaysArgs A) {
 	if(live) {
 		*(float4 *)(A.distance + q * 4) = make_float4(Q.dist[0], Q.dist[1], Q.dist[2], Q.dist[3]);
 		*(int4 *)(A.object + q * 4) = make_int4(tid[0], tid[1], tid[2], tid[3]);
-		*(float4 *)(A.bary + q * 8) = make_float4(bu[0], bu[1], bu[2], bu[3]);
-		*(float4 *)(A.bary + q * 8 + 4) = make_float4(bv[0], bv[1], bv[2], bv[3]);
+		if(A.bary) {
+			*(float4 *)(A.bary + q * 8) = make_float4(bu[0], bu[1], bu[2], bu[3]);
+			*(float4 *)(A.bary + q * 8 + 4) = make_float4(bv[0], bv[1], bv[2], bv[3]);
+		}
 	}
 }
 
@@ -1375,6 +1563,18 @@ struct SnailScene {
 	int *dDefer[kDeferSlots] = {};        // deferred-packet lists, one per launch in flight (round-robin)
 	int deferCap = 0;
 	unsigned launchCount = 0;
+	// intermediate state of snail_render_whitted_dev, one set per launch in flight (round-robin, like dDefer)
+	struct ShadeScratch {
+		size_t packets = 0;
+		bool refl = false;
+		float *hitT = nullptr; int *hitId = nullptr;
+		float *rOrg = nullptr, *rDir = nullptr, *rIDir = nullptr, *rDist = nullptr, *rCol = nullptr;
+		int *rObj = nullptr;
+		unsigned char *rMask = nullptr;
+		int *defer = nullptr;
+		float *sDist = nullptr;
+	} shade[kDeferSlots];
+	unsigned shadeCount = 0;
 };
 
 namespace {
@@ -1423,7 +1623,8 @@ int checkScene(const SnailScene *s, const char *fn) {
 }
 
 int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0, int y0, int w, int h, const int32_t *dPacketXY,
-				  int nPackets, float *t, float *u, float *v, int32_t *id, uint64_t *dStats, hipStream_t stream, unsigned *dCost = nullptr) {
+				  int nPackets, float *t, float *u, float *v, int32_t *id, uint64_t *dStats, hipStream_t stream, unsigned *dCost = nullptr,
+				  bool packetMajor = false) {
 	if(resx <= 0 || resy <= 0) { snail_set_error("snail_trace_primary: bad resolution %dx%d", resx, resy); return 1; }
 	dev::PrimaryArgs A;
 	memset(&A, 0, sizeof(A));
@@ -1434,6 +1635,7 @@ int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0
 	A.t = t; A.u = u; A.v = v; A.id = id;
 	A.stats = (dev::u64 *)dStats;
 	A.cost = dCost;
+	A.packetMajor = packetMajor ? 1 : 0;
 	int blocks;
 	if(dPacketXY) {
 		if(nPackets <= 0) return 0;
@@ -1478,6 +1680,52 @@ int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0
 	}
 	HIP_TRY(hipGetLastError());
 	return 0;
+}
+
+// scratch of one staged frame: ONE allocation, carved (hitT is its base); grown synchronously when a larger frame or the first
+// reflection frame arrives
+int shadeScratch(SnailScene *s, SnailScene::ShadeScratch &W, size_t packets, size_t blocks, bool refl) {
+	if(W.hitT && W.packets >= packets && (W.refl || !refl)) return 0;
+	HIP_TRY(hipDeviceSynchronize());
+	if(W.hitT) (void)hipFree(W.hitT);
+	W = SnailScene::ShadeScratch();
+	const size_t rays = packets * 256, quads = packets * 64;
+	const size_t deferInts = blocks * SNAIL_MAX_LIGHTS + 16;
+	size_t bytes = rays * 8 + deferInts * 4 + rays * 4 * SNAIL_MAX_LIGHTS; // hitT, hitId, defer list, sDist
+	if(refl) bytes += quads * 12 * 4 * 3 + rays * 4 * 2 + rays * 12 + quads; // rOrg, rDir, rIDir; rDist, rObj; rCol; rMask
+	char *base = nullptr;
+	HIP_TRY(hipMalloc((void **)&base, bytes));
+	W.packets = packets; W.refl = refl;
+	W.hitT = (float *)base; base += rays * 4;
+	W.hitId = (int *)base; base += rays * 4;
+	W.defer = (int *)base; base += deferInts * 4;
+	HIP_TRY(hipMemset(W.defer, 0, 16 * sizeof(int)));
+	W.sDist = (float *)base; base += rays * 4 * SNAIL_MAX_LIGHTS;
+	if(refl) {
+		W.rOrg = (float *)base; base += quads * 48;
+		W.rDir = (float *)base; base += quads * 48;
+		W.rIDir = (float *)base; base += quads * 48;
+		W.rDist = (float *)base; base += rays * 4;
+		W.rObj = (int *)base; base += rays * 4;
+		W.rCol = (float *)base; base += rays * 12;
+		W.rMask = (unsigned char *)base;
+	}
+	return 0;
+}
+
+template <int SRC>
+void launchLights(const SnailScene *s, const dev::ShadeArgs &A, hipStream_t stream) {
+	if(A.nLights <= 0) return;
+	const dim3 grid(A.nBlocks, A.nLights);
+	const int total = A.nBlocks * A.nLights;
+	const int exactBlocks = A.fastOK ? (total < 8 ? total : 8) : (total < 2048 ? total : 2048);
+	if(s->depth > 62) {
+		hipLaunchKernelGGL((dev::k_light<true, SRC>), grid, dim3(64), 0, stream, A);
+		hipLaunchKernelGGL((dev::k_light_exact<true, SRC>), dim3(exactBlocks), dim3(64), 0, stream, A);
+	} else {
+		hipLaunchKernelGGL((dev::k_light<false, SRC>), grid, dim3(64), 0, stream, A);
+		hipLaunchKernelGGL((dev::k_light_exact<false, SRC>), dim3(exactBlocks), dim3(64), 0, stream, A);
+	}
 }
 
 } // namespace
@@ -1544,6 +1792,7 @@ void snail_scene_destroy(SnailScene *s) {
 	if(s->dTris) (void)hipFree(s->dTris);
 	if(s->dStats) (void)hipFree(s->dStats);
 	for(int k = 0; k < SnailScene::kDeferSlots; k++) if(s->dDefer[k]) (void)hipFree(s->dDefer[k]);
+	for(int k = 0; k < SnailScene::kDeferSlots; k++) if(s->shade[k].hitT) (void)hipFree(s->shade[k].hitT);
 	delete s;
 }
 
@@ -1623,7 +1872,7 @@ static int launchRays(SnailScene *s, bool shadow, int nPackets, int size, int sh
 					  const float *idir, const uint8_t *mask, float *distance, int32_t *object, float *bary, uint64_t *dStats, hipStream_t stream) {
 	if(nPackets <= 0) return 0;
 	if(size < 1 || size > SNAIL_PACKET_QUADS) { snail_set_error("packet size %d outside 1..%d quads", size, SNAIL_PACKET_QUADS); return 1; }
-	if(!origin || !dir || !idir || !distance || (!shadow && (!object || !bary))) { snail_set_error("null ray array"); return 1; }
+	if(!origin || !dir || !idir || !distance || (!shadow && !object)) { snail_set_error("null ray array"); return 1; }
 	dev::RaysArgs A;
 	memset(&A, 0, sizeof(A));
 	A.nodes = s->dNodes; A.tris = s->dTris;
@@ -1721,14 +1970,16 @@ int snail_trace_shadow(SnailScene *s, int nPackets, int size, const float *origi
 }
 
 int snail_render_whitted_dev(SnailScene *s, const float cam[13], int resx, int resy, const float *lights7, int nLights, const float ambient[3],
-							 const float color[3], uint8_t *frame, int pitch, uint64_t *dStats, void *stream) {
+							 const float color[3], int flags, uint8_t *frame, int pitch, uint64_t *dStats, void *stream) {
 	if(int rc = checkScene(s, "snail_render_whitted_dev")) return rc;
-	if(resx <= 0 || resy <= 0 || !frame || pitch < resx * 3 || nLights < 0 || nLights > SNAIL_MAX_LIGHTS || (nLights && !lights7) || !ambient || !color) {
-		snail_set_error("snail_render_whitted_dev: bad arguments (at most %d lights)", SNAIL_MAX_LIGHTS);
+	if(resx <= 0 || resy <= 0 || !frame || pitch < resx * 3 || nLights < 0 || nLights > SNAIL_MAX_LIGHTS || (nLights && !lights7) || !ambient || !color ||
+	   (flags & ~SNAIL_WHITTED_REFLECTIONS)) {
+		snail_set_error("snail_render_whitted_dev: bad arguments (at most %d lights; flags = SNAIL_WHITTED_REFLECTIONS or 0)", SNAIL_MAX_LIGHTS);
 		return 1;
 	}
 	DeviceGuard guard(s->device);
-	dev::WhittedArgs A;
+	const bool refl = (flags & SNAIL_WHITTED_REFLECTIONS) != 0;
+	dev::ShadeArgs A;
 	memset(&A, 0, sizeof(A));
 	A.nodes = s->dNodes; A.tris = s->dTris;
 	A.g = makeGen(cam, resx, resy);
@@ -1738,10 +1989,31 @@ int snail_render_whitted_dev(SnailScene *s, const float cam[13], int resx, int r
 	for(int n = 0; n < nLights; n++) for(int k = 0; k < 7; k++) A.lights[n][k] = lights7[n * 7 + k];
 	for(int c = 0; c < 3; c++) { A.ambient[c] = ambient[c]; A.color[c] = color[c]; }
 	A.frame = frame; A.pitch = pitch; A.stats = (dev::u64 *)dStats;
+	const int packets = A.pw * A.ph;
 	const int nRegions = ((A.pw + 3) / 4) * ((A.ph + 3) / 4);
 	const int blocks = ((nRegions + 7) / 8) * 8 * 16;
-	if(s->depth > 62) hipLaunchKernelGGL(dev::k_whitted<true>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, A);
-	else hipLaunchKernelGGL(dev::k_whitted<false>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, A);
+	A.nBlocks = blocks;
+	SnailScene::ShadeScratch &W = s->shade[s->shadeCount++ % SnailScene::kDeferSlots];
+	if(int rc = shadeScratch(s, W, (size_t)packets, (size_t)blocks, refl)) return rc;
+	A.hitT = W.hitT; A.hitId = W.hitId;
+	A.rOrg = W.rOrg; A.rDir = W.rDir; A.rIDir = W.rIDir; A.rMask = W.rMask; A.rDist = W.rDist; A.rObj = W.rObj; A.rCol = W.rCol;
+	A.sDist = W.sDist;
+	A.blend = refl ? 1 : 0;
+	A.defer = W.defer;
+	const hipStream_t st = (hipStream_t)stream;
+	const dim3 grid(blocks), wave(64);
+	// the primary packets (the bench kernel), hit records packet-major in grid order
+	if(int rc = launchPrimary(s, cam, resx, resy, 0, 0, resx, resy, nullptr, 0, W.hitT, nullptr, nullptr, W.hitId, dStats, st, nullptr, true)) return rc;
+	if(refl) { // the nested RayTrace of the mirrored packets
+		hipLaunchKernelGGL((dev::k_final<dev::SRC_PRIMARY, dev::DST_MIRROR>), grid, wave, 0, st, A);
+		HIP_TRY(hipGetLastError());
+		if(int rc = launchRays(s, false, packets, 64, 0, W.rOrg, W.rDir, W.rIDir, W.rMask, W.rDist, W.rObj, nullptr, dStats, st)) return rc;
+		launchLights<dev::SRC_MIRROR>(s, A, st);
+		hipLaunchKernelGGL((dev::k_final<dev::SRC_MIRROR, dev::DST_COLOR>), grid, wave, 0, st, A);
+		HIP_TRY(hipGetLastError());
+	}
+	launchLights<dev::SRC_PRIMARY>(s, A, st);
+	hipLaunchKernelGGL((dev::k_final<dev::SRC_PRIMARY, dev::DST_FRAME>), grid, wave, 0, st, A);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }

@@ -216,10 +216,11 @@ class Scene:
         return frame_rgb8
 
     def render_whitted(self, cam: Camera, resx: int, resy: int, lights7, ambient=(0.1, 0.1, 0.1), color=(1.0, 1.0, 1.0), out=None, stats=None,
-                       stream=None):
-        """Scene::RayTrace in the reference's simple-shading configuration (primary + one shadow packet per point light),
-        fused on the device; returns the interleaved [resy,resx,3] uint8 (B,G,R) frame.  lights7 = n x {pos, color, radius}
-        (class Light, src/light.h:5-16); defaults = Scene::ambientLight / defaultMat (src/scene.cpp:6-10)."""
+                       stream=None, reflections: bool = False):
+        """Scene::RayTrace in the reference's simple-shading configuration (primary + one shadow packet per point light;
+        reflections=True = gVals[7], one mirrored bounce shaded the same way), staged on the device; returns the interleaved
+        [resy,resx,3] uint8 (B,G,R) frame.  lights7 = n x {pos, color, radius} (class Light, src/light.h:5-16); defaults =
+        Scene::ambientLight / defaultMat (src/scene.cpp:6-10)."""
         torch = _torch()
         if out is None:
             out = torch.zeros((resy, resx, 3), dtype=torch.uint8, device=self._dev())
@@ -227,7 +228,7 @@ class Scene:
         cam13 = np.ascontiguousarray(cam.as_array13(), dtype=np.float32)
         amb = np.ascontiguousarray(ambient, dtype=np.float32); col = np.ascontiguousarray(color, dtype=np.float32)
         rc = _lib.lib().snail_render_whitted_dev(self._h, _lib.ptr(cam13), resx, resy, _lib.ptr(lights), len(lights), _lib.ptr(amb), _lib.ptr(col),
-                                                 _lib.ptr(out), resx * 3, _lib.ptr(stats), _stream_ptr(stream))
+                                                 1 if reflections else 0, _lib.ptr(out), resx * 3, _lib.ptr(stats), _stream_ptr(stream))
         _lib.check(rc, "snail_render_whitted_dev")
         return out
 

@@ -48,7 +48,7 @@ def lib():
         L.orc_shade_depth.argtypes = [vp, i32, vp, i32]
         L.orc_planar_encode_tile.argtypes = [vp, i32, i32, i32, i32, i32, vp]
         L.orc_planar_decode_tile.argtypes = [vp, i32, i32, i32, i32, vp, i32]
-        L.orc_render_whitted.argtypes = [vp, vp, vp, i32, i32, vp, i32, vp, vp, vp, i32, u64p, i32, i32]
+        L.orc_render_whitted.argtypes = [vp, vp, vp, i32, i32, vp, i32, vp, vp, i32, vp, i32, u64p, i32, i32]
         for f in (L.orc_inv, L.orc_rsqrt):
             f.argtypes = [C.c_float, i32]
             f.restype = C.c_float
@@ -108,13 +108,13 @@ class OracleScene:
         lib().orc_account_primary(_p(self.nodes), _p(self.tris), _p(cam), resx, resy, x0, y0, w, h, _p(out), mode, threads)
         return out
 
-    def render_whitted(self, cam13, resx, resy, lights7, ambient=(0.1, 0.1, 0.1), color=(1.0, 1.0, 1.0), mode=MODE_IEEE, threads=8):
+    def render_whitted(self, cam13, resx, resy, lights7, ambient=(0.1, 0.1, 0.1), color=(1.0, 1.0, 1.0), mode=MODE_IEEE, threads=8, reflections=False):
         cam = np.ascontiguousarray(cam13, dtype=np.float32)
         lights = np.ascontiguousarray(lights7, dtype=np.float32).reshape(-1, 7)
         amb = np.asarray(ambient, dtype=np.float32); col = np.asarray(color, dtype=np.float32)
         frame = np.zeros((resy, resx, 3), dtype=np.uint8)
         stats = np.zeros(4, dtype=np.uint64)
-        lib().orc_render_whitted(_p(self.nodes), _p(self.tris), _p(cam), resx, resy, _p(lights), len(lights), _p(amb), _p(col), _p(frame), resx * 3,
+        lib().orc_render_whitted(_p(self.nodes), _p(self.tris), _p(cam), resx, resy, _p(lights), len(lights), _p(amb), _p(col), 1 if reflections else 0, _p(frame), resx * 3,
                                  _p(stats), mode, threads)
         return frame, stats
 

@@ -411,12 +411,15 @@ def test_two_rank_bench_rehearsal(torch_mod):
     assert d["config"]["hit_fraction"] > 0.5
 
 
-@pytest.mark.parametrize("name,resx,resy,nl", [("atrium:0.05", 640, 368, 2), ("atrium:0.05", 250, 130, 1), ("box", 256, 256, 1), ("stress:0.05", 320, 192, 3),
-                                                ("atrium:0.05", 320, 192, 0)])
-def test_whitted_primary_plus_shadow_bit_exact(torch_mod, name, resx, resy, nl):
-    """BASELINE config 3 (primary + one shadow packet per point light), fused on the device: the rgb8 frame and the
-    TreeStats counters (incl. the traced-ray count = primary + shadow lanes with N.L > 0) equal the oracle's
-    Scene::RayTrace restatement byte for byte."""
+@pytest.mark.parametrize("name,resx,resy,nl,refl", [("atrium:0.05", 640, 368, 2, False), ("atrium:0.05", 250, 130, 1, False), ("box", 256, 256, 1, False),
+                                                     ("stress:0.05", 320, 192, 3, False), ("atrium:0.05", 320, 192, 0, False),
+                                                     ("atrium:0.05", 640, 368, 2, True), ("atrium:0.05", 250, 130, 0, True), ("box", 256, 256, 1, True),
+                                                     ("stress:0.05", 320, 192, 3, True), ("chain", 128, 96, 1, True)])
+def test_whitted_primary_plus_shadow_bit_exact(torch_mod, name, resx, resy, nl, refl):
+    """BASELINE config 3 (primary + one shadow packet per point light), staged on the device, without and with the
+    reference's one-bounce reflections (gVals[7]: mirrored packets with per-ray origins and lane masks, shaded and lit like
+    the primaries): the rgb8 frame and the TreeStats counters (incl. the traced-ray count = primary + mirrored lanes +
+    shadow lanes with N.L > 0) equal the oracle's Scene::RayTrace restatement byte for byte."""
     tv, sc, osc = gpu_scene(name)
     cam = util.camera_for(name, tv)
     bmin, bmax = osc.nodes[0]["bmin"], osc.nodes[0]["bmax"]
@@ -424,15 +427,18 @@ def test_whitted_primary_plus_shadow_bit_exact(torch_mod, name, resx, resy, nl):
     lights = np.array([[c[0], c[1] + 0.35 * e[1], c[2], 1.0, 0.9, 0.8, 2.0 * float(e.max())],
                        [c[0] - 0.3 * e[0], c[1] + 0.1 * e[1], c[2] + 0.2 * e[2], 0.3, 0.5, 1.0, 0.6 * float(e.max())],
                        [cam.pos[0], cam.pos[1], cam.pos[2], 0.6, 0.6, 0.6, 0.25 * float(e.max())]], dtype=np.float32)[:nl]
-    want, wst = osc.render_whitted(cam.as_array13(), resx, resy, lights, mode=O.MODE_IEEE)
+    want, wst = osc.render_whitted(cam.as_array13(), resx, resy, lights, mode=O.MODE_IEEE, reflections=refl)
     stats = sc.new_stats()
-    got = sc.render_whitted(cam, resx, resy, lights, stats=stats)
+    got = sc.render_whitted(cam, resx, resy, lights, stats=stats, reflections=refl)
     torch_mod.cuda.synchronize()
     g = got.cpu().numpy()
     assert np.array_equal(g, want), (int((g != want).sum()), g.shape)
     assert np.array_equal(stats.cpu().numpy().astype(np.uint64), wst), (stats.cpu().numpy(), wst)
     assert want.max() > 0
-    if nl and name != "box":                          # (the box's lights sit inside the cube: no lane has N.L > 0)
+    if refl:                                          # the bounce changes the picture and traces more rays
+        plain, pst = osc.render_whitted(cam.as_array13(), resx, resy, lights, mode=O.MODE_IEEE)
+        assert (plain != want).any() and wst[2] > pst[2]
+    if nl and name != "box" and not name.startswith("chain"):                          # (the box's lights sit inside the cube: no lane has N.L > 0)
         assert wst[2] > ((resx + 15) // 16) * ((resy + 15) // 16) * 256        # shadow rays were traced
     sc.close()
 

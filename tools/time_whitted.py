@@ -1,4 +1,5 @@
-"""Timing of BASELINE config 3 (primary + shadow packets, fused on the device) -- development aid."""
+"""Timing of BASELINE config 3 (primary + shadow packets, staged on the device; optional third argument `refl` = one mirrored
+bounce) -- development aid."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -6,6 +7,7 @@ from snail_amd import HostBVH, scenes, FPSCamera
 from snail_amd.scene import Scene
 name = sys.argv[1] if len(sys.argv) > 1 else "atrium"
 nl = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+refl = len(sys.argv) > 3 and sys.argv[3] == "refl"
 resx, resy = 1920, 1080
 tv = scenes.scene_by_name(name); h = HostBVH.build(tv)
 pos, ang, pitch = scenes.atrium_camera() if name.startswith("atrium") else scenes.stress_camera()
@@ -15,9 +17,9 @@ bmin, bmax = h.bbox(); c, e = (bmin + bmax) * 0.5, (bmax - bmin)
 lights = np.array([[c[0], c[1] + 0.35 * e[1], c[2], 1.0, 0.9, 0.8, 2.0 * float(e.max())],
                    [c[0] - 0.3 * e[0], c[1] + 0.1 * e[1], c[2] + 0.2 * e[2], 0.3, 0.5, 1.0, 0.6 * float(e.max())]], dtype=np.float32)[:nl]
 st = sc.new_stats()
-out = sc.render_whitted(cam, resx, resy, lights, stats=st); torch.cuda.synchronize()
+out = sc.render_whitted(cam, resx, resy, lights, stats=st, reflections=refl); torch.cuda.synchronize()
 s = st.cpu().numpy()
-print("rays traced per frame:", int(s[2]), "(primary 2088960 + shadow %d)" % (int(s[2]) - 2088960), "skips", int(s[3]))
+print("rays traced per frame:", int(s[2]), "(primary 2088960 + %s %d)" % ("mirrored+shadow" if refl else "shadow", int(s[2]) - 2088960), "skips", int(s[3]))
 streams = [torch.cuda.Stream() for _ in range(3)]
 outs = [torch.zeros_like(out) for _ in range(3)]
 for ns in (1, 3):
@@ -29,7 +31,7 @@ for ns in (1, 3):
         s_ = streams[i % ns]
         s_.wait_event(e0) if i < ns else None
         with torch.cuda.stream(s_):
-            sc.render_whitted(cam, resx, resy, lights, out=outs[i % ns], stream=s_)
+            sc.render_whitted(cam, resx, resy, lights, out=outs[i % ns], stream=s_, reflections=refl)
     for s_ in streams[:ns]:
         torch.cuda.current_stream().wait_stream(s_)
     e1.record(); torch.cuda.synchronize()
