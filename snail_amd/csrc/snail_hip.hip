@@ -1561,6 +1561,10 @@ struct SnailScene {
 	unsigned long long *dStats = nullptr; // 4 x u64 scratch for the host-pointer entry points
 	enum { kDeferSlots = 8 };
 	int *dDefer[kDeferSlots] = {};        // deferred-packet lists, one per launch in flight (round-robin)
+	// a slot's buffers are reused by the 8th launch after it, possibly on another stream and possibly while the host runs far
+	// ahead of the device: each slot carries an event recorded after its last kernel, and the next user's stream waits for it
+	hipEvent_t deferDone[kDeferSlots] = {};
+	bool deferUsed[kDeferSlots] = {};
 	int deferCap = 0;
 	unsigned launchCount = 0;
 	// intermediate state of snail_render_whitted_dev, one set per launch in flight (round-robin, like dDefer)
@@ -1573,6 +1577,8 @@ struct SnailScene {
 		unsigned char *rMask = nullptr;
 		int *defer = nullptr;
 		float *sDist = nullptr;
+		hipEvent_t done = nullptr;
+		bool used = false;
 	} shade[kDeferSlots];
 	unsigned shadeCount = 0;
 };
@@ -1666,7 +1672,10 @@ int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0
 		}
 		s->deferCap = blocks + 2;
 	}
-	A.defer = s->dDefer[s->launchCount++ % SnailScene::kDeferSlots];
+	const int slot = (int)(s->launchCount++ % SnailScene::kDeferSlots);
+	A.defer = s->dDefer[slot];
+	if(!s->deferDone[slot]) HIP_TRY(hipEventCreateWithFlags(&s->deferDone[slot], hipEventDisableTiming));
+	if(s->deferUsed[slot]) HIP_TRY(hipStreamWaitEvent(stream, s->deferDone[slot], 0));
 	// SNAIL_DEBUG_DYNLDS=<bytes>: occupancy experiments only (unused dynamic LDS limits waves per CU)
 	static const int dynLds = getenv("SNAIL_DEBUG_DYNLDS") ? atoi(getenv("SNAIL_DEBUG_DYNLDS")) : 0;
 	// a scene with sane records defers (practically) nothing: a handful of blocks suffices; an unsafe scene defers every packet
@@ -1679,6 +1688,8 @@ int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0
 		hipLaunchKernelGGL(dev::k_primary_exact<false>, dim3(exactBlocks), dim3(64), 0, stream, A);
 	}
 	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(s->deferDone[slot], stream));
+	s->deferUsed[slot] = true;
 	return 0;
 }
 
@@ -1688,7 +1699,9 @@ int shadeScratch(SnailScene *s, SnailScene::ShadeScratch &W, size_t packets, siz
 	if(W.hitT && W.packets >= packets && (W.refl || !refl)) return 0;
 	HIP_TRY(hipDeviceSynchronize());
 	if(W.hitT) (void)hipFree(W.hitT);
+	const hipEvent_t keep = W.done;
 	W = SnailScene::ShadeScratch();
+	W.done = keep;
 	const size_t rays = packets * 256, quads = packets * 64;
 	const size_t deferInts = blocks * SNAIL_MAX_LIGHTS + 16;
 	size_t bytes = rays * 8 + deferInts * 4 + rays * 4 * SNAIL_MAX_LIGHTS; // hitT, hitId, defer list, sDist
@@ -1793,6 +1806,10 @@ void snail_scene_destroy(SnailScene *s) {
 	if(s->dStats) (void)hipFree(s->dStats);
 	for(int k = 0; k < SnailScene::kDeferSlots; k++) if(s->dDefer[k]) (void)hipFree(s->dDefer[k]);
 	for(int k = 0; k < SnailScene::kDeferSlots; k++) if(s->shade[k].hitT) (void)hipFree(s->shade[k].hitT);
+	for(int k = 0; k < SnailScene::kDeferSlots; k++) {
+		if(s->deferDone[k]) (void)hipEventDestroy(s->deferDone[k]);
+		if(s->shade[k].done) (void)hipEventDestroy(s->shade[k].done);
+	}
 	delete s;
 }
 
@@ -1995,6 +2012,8 @@ int snail_render_whitted_dev(SnailScene *s, const float cam[13], int resx, int r
 	A.nBlocks = blocks;
 	SnailScene::ShadeScratch &W = s->shade[s->shadeCount++ % SnailScene::kDeferSlots];
 	if(int rc = shadeScratch(s, W, (size_t)packets, (size_t)blocks, refl)) return rc;
+	if(!W.done) HIP_TRY(hipEventCreateWithFlags(&W.done, hipEventDisableTiming));
+	if(W.used) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, W.done, 0));
 	A.hitT = W.hitT; A.hitId = W.hitId;
 	A.rOrg = W.rOrg; A.rDir = W.rDir; A.rIDir = W.rIDir; A.rMask = W.rMask; A.rDist = W.rDist; A.rObj = W.rObj; A.rCol = W.rCol;
 	A.sDist = W.sDist;
@@ -2015,6 +2034,8 @@ int snail_render_whitted_dev(SnailScene *s, const float cam[13], int resx, int r
 	launchLights<dev::SRC_PRIMARY>(s, A, st);
 	hipLaunchKernelGGL((dev::k_final<dev::SRC_PRIMARY, dev::DST_FRAME>), grid, wave, 0, st, A);
 	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(W.done, st));
+	W.used = true;
 	return 0;
 }
 

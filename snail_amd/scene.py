@@ -31,8 +31,14 @@ def _torch():
 
 def _stream_ptr(stream=None):
     torch = _torch()
-    s = stream if stream is not None else torch.cuda.current_stream()
-    return C.c_void_p(s.cuda_stream)
+    if stream is not None:
+        return C.c_void_p(stream.cuda_stream)
+    # torch.cuda.current_stream() without a device walks through is_available() (~150 us per call on this stack); the raw
+    # accessors are two C calls
+    try:
+        return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    except AttributeError:      # another torch build: the documented path
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 @dataclass

@@ -19,14 +19,16 @@ lights = np.array([[c[0], c[1] + 0.35 * e[1], c[2], 1.0, 0.9, 0.8, 2.0 * float(e
 st = sc.new_stats()
 out = sc.render_whitted(cam, resx, resy, lights, stats=st, reflections=refl); torch.cuda.synchronize()
 s = st.cpu().numpy()
-print("rays traced per frame:", int(s[2]), "(primary 2088960 + %s %d)" % ("mirrored+shadow" if refl else "shadow", int(s[2]) - 2088960), "skips", int(s[3]))
+print("stats {intersects, iters, rays, skips}:", s.tolist()); print("rays traced per frame:", int(s[2]), "(primary 2088960 + %s %d)" % ("mirrored+shadow" if refl else "shadow", int(s[2]) - 2088960), "skips", int(s[3]))
+for i in range(24): sc.render_whitted(cam, resx, resy, lights, reflections=refl)   # every scratch slot of the scene handle allocated
+torch.cuda.synchronize()
 streams = [torch.cuda.Stream() for _ in range(3)]
 outs = [torch.zeros_like(out) for _ in range(3)]
-for ns in (1, 3):
+for ns in (1, 1, 1, 3, 3, 3):   # the first round after a change of concurrency is a transient (queues, clocks)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    K = 60
+    K = 90
     for i in range(K):
         s_ = streams[i % ns]
         s_.wait_event(e0) if i < ns else None
@@ -37,3 +39,9 @@ for ns in (1, 3):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / K
     print("frames in flight %d: %.3f ms/frame, %.1f Mrays/s (primary+shadow)" % (ns, ms, s[2] / ms / 1e3))
+# host-side cost of one call (launches only; the queue is drained first and after)
+import time
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(200): sc.render_whitted(cam, resx, resy, lights, out=outs[0], reflections=refl)
+t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+print("host time per call %.1f us (queue drained after another %.1f us per call)" % ((t1 - t0) / 200 * 1e6, (t2 - t1) / 200 * 1e6))
