@@ -390,7 +390,7 @@ __device__ __forceinline__ bool leafShared(const uint4 *__restrict__ tris, int c
 template <bool SHARED, bool MASK, bool SHADOW, int M, bool BARY, bool DEEP, bool DISTPOS, int OCT = -1>
 __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint4 *__restrict__ tris, int size, int lane,
 									 const float (&org)[3][4] /* SHARED: [c][0] uniform */, Quad &Q, unsigned mask4, int (&tid)[4],
-									 float (&bu)[4], float (&bv)[4], float *lds, Counters &st) {
+									 float (&bu)[4], float (&bv)[4], float *lds, Counters &st, const int oct = 0 /* M_COH with OCT < 0: classify()'s octant */) {
 	constexpr bool EXACT = M == M_EXACT;
 	Interval iv;
 	{ // RayInterval ctor (src/ray_group.h:296-333)
@@ -415,10 +415,8 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 
 	// child order from lane 0 of quad 0 (src/bvh/traverse.cpp:21)
 	const int signBits = __builtin_amdgcn_readfirstlane((Q.d[0][0] < 0.0f ? 1 : 0) | (Q.d[1][0] < 0.0f ? 2 : 0) | (Q.d[2][0] < 0.0f ? 4 : 0));
-	// M_COH: the (packet-uniform) sign of idir per axis picks the near/far slab plane
-	// (sign BIT, so that the selects stay on the scalar unit; -0 behaves like any negative: both slab products are 0)
-	const int octMask[3] = {__builtin_amdgcn_readfirstlane(__float_as_int(Q.id[0][0]) >> 31), __builtin_amdgcn_readfirstlane(__float_as_int(Q.id[1][0]) >> 31),
-							__builtin_amdgcn_readfirstlane(__float_as_int(Q.id[2][0]) >> 31)}; // 0 or -1 per axis
+	// M_COH: the packet's sign octant picks the near/far slab plane per axis (0 or -1 per axis, for the scalar XOR-swap below)
+	const int octMask[3] = {-(oct & 1), -((oct >> 1) & 1), -((oct >> 2) & 1)};
 
 	int stkNode = 0, stkFL = 0, stkNode2 = 0, stkFL2 = 0;
 	int sp = 0;
@@ -520,9 +518,13 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				const float slack = vmax3(tf[0] - tn[0], tf[1] - tn[1], vmax(tf[2] - tn[2], tf[3] - tn[3]));
 				passMask = __builtin_amdgcn_ballot_w64(slack >= 0.0f);
 			} else {
+				// any distance (masked lanes: -inf): lmax>=0 && lmin<=lmax && lmin<=dist  <=>  min(min(lmax,dist) - lmin, lmax) >= 0
+				// (lmin, lmax finite; min(lmax,dist) finite or -inf, so the difference is exact in sign or -inf)
+				float sl[4];
 #pragma unroll
-				for(int l = 0; l < 4; l++)
-					passMask |= __builtin_amdgcn_ballot_w64(tf[l] >= 0.0f) & __builtin_amdgcn_ballot_w64(tn[l] <= tf[l]) & __builtin_amdgcn_ballot_w64(tn[l] <= Q.dist[l]);
+				for(int l = 0; l < 4; l++) sl[l] = vmin(vmin(tf[l], Q.dist[l]) - tn[l], tf[l]);
+				const float slack = vmax3(sl[0], sl[1], vmax(sl[2], sl[3]));
+				passMask = __builtin_amdgcn_ballot_w64(slack >= 0.0f);
 			}
 		}
 		// clip to the quad range [first,last]: (lane - first) <= (last - first) as ONE unsigned VALU compare -- the scalar unit
@@ -712,18 +714,27 @@ __device__ __forceinline__ void finalBarycentrics(const uint4 *__restrict__ tris
 	}
 }
 
-// packet classification (wave-uniform): M_EXACT unless everything is finite; M_COH if additionally every
-// ray of the packet (lanes < size) has the same idir sign on each axis
-__device__ __forceinline__ int classify(bool fastOK, bool laneFinite, bool live, const float (&id)[3][4]) {
+// packet classification (wave-uniform): M_EXACT unless everything is finite; M_COH if additionally every ray THAT MATTERS has
+// the same idir sign on each axis -- `oct` then holds those signs (bit k = negative on axis k).  A ray whose distance is -inf on
+// entry (a masked lane as Scene::RayTrace / TraceLight set it up, src/scene_trace.cpp:112-115,:551-557) fails every slab test
+// whatever planes it is given, so its signs are ignored: mirrored and shadow packets stay coherent although their masked lanes
+// carry placeholder directions.
+__device__ __forceinline__ int classify(bool fastOK, bool laneFinite, bool live, const float (&id)[3][4], const float (&dist)[4], int &oct) {
+	oct = 0;
 	if(!(fastOK && __all(laneFinite || !live))) return M_EXACT;
 	bool coh = true;
 #pragma unroll
 	for(int k = 0; k < 3; k++) {
 		bool anyNeg = false, anyPos = false;
 #pragma unroll
-		for(int l = 0; l < 4; l++) { anyNeg |= __float_as_int(id[k][l]) < 0; anyPos |= __float_as_int(id[k][l]) >= 0; }
+		for(int l = 0; l < 4; l++) {
+			const bool matters = dist[l] > -__builtin_inff();
+			anyNeg |= matters && __float_as_int(id[k][l]) < 0;
+			anyPos |= matters && __float_as_int(id[k][l]) >= 0;
+		}
 		const bool n = __any(anyNeg && live), p = __any(anyPos && live);
 		coh = coh && !(n && p);
+		oct |= n ? (1 << k) : 0;
 	}
 	return coh ? M_COH : M_FAST;
 }
@@ -838,16 +849,16 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 		for(int l = 0; l < 4; l++) org[c][l] = A.g.org[c];
 
 	Counters st = {0, 0, 0};
-	const int mode = classify(A.fastOK != 0, finite4(Q.id) && finite4(Q.d), true, Q.id);
+	int oct;
+	const int mode = classify(A.fastOK != 0, finite4(Q.id) && finite4(Q.d), true, Q.id, Q.dist, oct);
 	if(EXACTPASS) walk<true, false, false, M_EXACT, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st);
 	else if(mode == M_EXACT) {
 		if(lane == 0) A.defer[2 + atomicAdd(&A.defer[0], 1)] = li;
 		return;
 	} else if(mode == M_COH) {
-		const int oct = __builtin_amdgcn_readfirstlane(((__float_as_int(Q.id[0][0]) >> 31) & 1) | ((__float_as_int(Q.id[1][0]) >> 31) & 2) | ((__float_as_int(Q.id[2][0]) >> 31) & 4));
 #define SNAIL_WALK_OCT(O)                                                                                                                  \
 	do {                                                                                                                                   \
-		if(DEEP) walk<true, false, false, M_COH, false, DEEP, true, O>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st);        \
+		if(DEEP) walk<true, false, false, M_COH, false, DEEP, true, O>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, O);     \
 		else walkPrimaryCoh<O>(A.nodes, A.tris, lane, org, Q, tid, lds, st);                                                               \
 	} while(0)
 		switch(oct) { // one specialised walk per sign octant, chosen once per packet
@@ -1122,12 +1133,13 @@ __device__ __forceinline__ void lightPacket(const ShadeArgs &A, const int li, co
 	if(EXACTPASS) walk<true, false, true, M_EXACT, false, DEEP, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st);
 	else {
 		const bool fin = finite4(Q.id) && finite4(Q.d);
-		const int mode = classify(A.fastOK != 0 && originSaneDev(lp), fin, true, Q.id);
+		int oct;
+		const int mode = classify(A.fastOK != 0 && originSaneDev(lp), fin, true, Q.id, Q.dist, oct);
 		if(mode == M_EXACT) {
 			if(lane == 0) A.defer[16 + atomicAdd(&A.defer[0], 1)] = n * A.nBlocks + li;
 			return;
 		}
-		if(mode == M_COH) walk<true, false, true, M_COH, false, DEEP, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st);
+		if(mode == M_COH) walk<true, false, true, M_COH, false, DEEP, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st, oct);
 		else walk<true, false, true, M_FAST, false, DEEP, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st);
 	}
 	flushStats(A.stats, st, rays, lane);
@@ -1284,15 +1296,16 @@ struct RaysArgs {
 	int *object;
 	float *bary;
 	u64 *stats;
+	int *defer; // k_rays: [0] = count, [1] = finished blocks of the M_EXACT pass, [16..] = deferred packet indices
 };
 
 
-template <bool SHARED, bool MASK>
-__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_rays(RaysArgs A) {
-	__shared__ float ldsAll[WAVES_PER_BLOCK][LDS_FLOATS_PER_WAVE];
+// One wave per block (packet costs are heavy-tailed, see k_primary), blocks dealt to the XCDs 16 consecutive packets at a time.
+// EXACTPASS as in the primary kernel: the main launch walks in M_COH / M_FAST and appends a packet that needs M_EXACT to A.defer
+// untouched (its distances / objects in memory are still the caller's); the second, small launch walks those in M_EXACT.
+template <bool SHARED, bool MASK, bool DEEP, bool BARY, bool EXACTPASS>
+__device__ __forceinline__ void raysPacket(const RaysArgs &A, const int p, float *lds) {
 	const int lane = threadIdx.x & 63;
-	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	const int p = (int)blockIdx.x * WAVES_PER_BLOCK + wave;
 	if(p >= A.nPackets) return;
 	const int size = A.size;
 	const size_t q0 = (size_t)p * size;
@@ -1314,29 +1327,49 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_rays(RaysArgs A) {
 	float4 dv = *(const float4 *)(A.distance + q * 4);
 	int4 ov = *(const int4 *)(A.object + q * 4);
 	float4 b0 = make_float4(0, 0, 0, 0), b1 = b0;
-	if(A.bary) { b0 = *(const float4 *)(A.bary + q * 8); b1 = *(const float4 *)(A.bary + q * 8 + 4); }
+	if(BARY) { b0 = *(const float4 *)(A.bary + q * 8); b1 = *(const float4 *)(A.bary + q * 8 + 4); }
 	Q.dist[0] = dv.x; Q.dist[1] = dv.y; Q.dist[2] = dv.z; Q.dist[3] = dv.w;
 	int tid[4] = {ov.x, ov.y, ov.z, ov.w};
 	float bu[4] = {b0.x, b0.y, b0.z, b0.w}, bv[4] = {b1.x, b1.y, b1.z, b1.w};
 
 	Counters st = {0, 0, 0};
-	bool fin = finite4(Q.id) && finite4(Q.d) && finite4(org);
+	if(EXACTPASS) walk<SHARED, MASK, false, M_EXACT, BARY, DEEP, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, lds, st);
+	else {
+		bool fin = finite4(Q.id) && finite4(Q.d) && finite4(org);
 #pragma unroll
-	for(int l = 0; l < 4; l++) fin = fin && !(Q.dist[l] != Q.dist[l]);
-	const int mode = classify(A.fastOK != 0, fin, live, Q.id);
-	if(mode == M_COH) walk<SHARED, MASK, false, M_COH, true, true, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, ldsAll[wave], st);
-	else if(mode == M_FAST) walk<SHARED, MASK, false, M_FAST, true, true, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, ldsAll[wave], st);
-	else walk<SHARED, MASK, false, M_EXACT, true, true, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, ldsAll[wave], st);
+		for(int l = 0; l < 4; l++) fin = fin && !(Q.dist[l] != Q.dist[l]);
+		int oct;
+		const int mode = classify(A.fastOK != 0, fin, live, Q.id, Q.dist, oct);
+		if(mode == M_EXACT) {
+			if(lane == 0) A.defer[16 + atomicAdd(&A.defer[0], 1)] = p;
+			return;
+		}
+		if(mode == M_COH) walk<SHARED, MASK, false, M_COH, BARY, DEEP, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, lds, st, oct);
+		else walk<SHARED, MASK, false, M_FAST, BARY, DEEP, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, lds, st);
+	}
 	flushStats(A.stats, st, 0u, lane);
 
 	if(live) {
 		*(float4 *)(A.distance + q * 4) = make_float4(Q.dist[0], Q.dist[1], Q.dist[2], Q.dist[3]);
 		*(int4 *)(A.object + q * 4) = make_int4(tid[0], tid[1], tid[2], tid[3]);
-		if(A.bary) {
+		if(BARY) {
 			*(float4 *)(A.bary + q * 8) = make_float4(bu[0], bu[1], bu[2], bu[3]);
 			*(float4 *)(A.bary + q * 8 + 4) = make_float4(bv[0], bv[1], bv[2], bv[3]);
 		}
 	}
+}
+template <bool SHARED, bool MASK, bool DEEP, bool BARY>
+__global__ __launch_bounds__(64) void k_rays(RaysArgs A) {
+	__shared__ float lds[LDS_FLOATS_PER_WAVE];
+	raysPacket<SHARED, MASK, DEEP, BARY, false>(A, interleave16((int)blockIdx.x), lds);
+}
+template <bool SHARED, bool MASK, bool DEEP, bool BARY>
+__global__ __launch_bounds__(64) void k_rays_exact(RaysArgs A) {
+	__shared__ float lds[LDS_FLOATS_PER_WAVE];
+	const int n = __builtin_amdgcn_readfirstlane(A.defer[0]);
+	for(int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) raysPacket<SHARED, MASK, DEEP, BARY, true>(A, __builtin_amdgcn_readfirstlane(A.defer[16 + i]), lds);
+	__threadfence();
+	if((threadIdx.x & 63) == 0 && atomicAdd(&A.defer[1], 1) == (int)gridDim.x - 1) { A.defer[0] = 0; A.defer[1] = 0; }
 }
 
 // ---- shadow packets: TraverseShadow(ShadowContext&) -----------------------------------------------
@@ -1369,8 +1402,9 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_shadow(RaysArgs A) {
 	bool fin = finite4(Q.id) && finite4(Q.d) && finite4(org);
 #pragma unroll
 	for(int l = 0; l < 4; l++) fin = fin && !(Q.dist[l] != Q.dist[l]);
-	const int mode = classify(A.fastOK != 0, fin, live, Q.id);
-	if(mode == M_COH) walk<true, false, true, M_COH, false, true, false>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
+	int oct;
+	const int mode = classify(A.fastOK != 0, fin, live, Q.id, Q.dist, oct);
+	if(mode == M_COH) walk<true, false, true, M_COH, false, true, false>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st, oct);
 	else if(mode == M_FAST) walk<true, false, true, M_FAST, false, true, false>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
 	else walk<true, false, true, M_EXACT, false, true, false>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
 	flushStats(A.stats, st, 0u, lane);
@@ -1581,6 +1615,9 @@ struct SnailScene {
 		bool used = false;
 	} shade[kDeferSlots];
 	unsigned shadeCount = 0;
+	// deferred-packet lists of snail_trace_rays*, same slot discipline
+	struct RayDefer { int *p = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool used = false; } rayDefer[kDeferSlots];
+	unsigned rayCount = 0;
 };
 
 namespace {
@@ -1726,6 +1763,63 @@ int shadeScratch(SnailScene *s, SnailScene::ShadeScratch &W, size_t packets, siz
 	return 0;
 }
 
+template <bool SHARED, bool MASK>
+void launchRaysKernels(const SnailScene *s, const dev::RaysArgs &A, int blocks, int exactBlocks, hipStream_t stream) {
+	const bool deep = s->depth > 62, bary = A.bary != nullptr;
+#define SNAIL_RAYS_LAUNCH(D, B)                                                                                                            \
+	do {                                                                                                                                   \
+		hipLaunchKernelGGL((dev::k_rays<SHARED, MASK, D, B>), dim3(blocks), dim3(64), 0, stream, A);                                        \
+		hipLaunchKernelGGL((dev::k_rays_exact<SHARED, MASK, D, B>), dim3(exactBlocks), dim3(64), 0, stream, A);                             \
+	} while(0)
+	if(deep && bary) SNAIL_RAYS_LAUNCH(true, true);
+	else if(deep) SNAIL_RAYS_LAUNCH(true, false);
+	else if(bary) SNAIL_RAYS_LAUNCH(false, true);
+	else SNAIL_RAYS_LAUNCH(false, false);
+#undef SNAIL_RAYS_LAUNCH
+}
+
+int launchRays(SnailScene *s, bool shadow, int nPackets, int size, int sharedOrigin, const float *origin, const float *dir,
+					  const float *idir, const uint8_t *mask, float *distance, int32_t *object, float *bary, uint64_t *dStats, hipStream_t stream) {
+	if(nPackets <= 0) return 0;
+	if(size < 1 || size > SNAIL_PACKET_QUADS) { snail_set_error("packet size %d outside 1..%d quads", size, SNAIL_PACKET_QUADS); return 1; }
+	if(!origin || !dir || !idir || !distance || (!shadow && !object)) { snail_set_error("null ray array"); return 1; }
+	dev::RaysArgs A;
+	memset(&A, 0, sizeof(A));
+	A.nodes = s->dNodes; A.tris = s->dTris;
+	A.nPackets = nPackets; A.size = size; A.fastOK = s->fastOK;
+	A.origin = origin; A.dir = dir; A.idir = idir; A.mask = mask;
+	A.distance = distance; A.object = object; A.bary = bary;
+	A.stats = (dev::u64 *)dStats;
+	if(shadow) {
+		const int blocks = (nPackets + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+		hipLaunchKernelGGL(dev::k_shadow, dim3(blocks), dim3(WAVES_PER_BLOCK * 64), 0, stream, A);
+		HIP_TRY(hipGetLastError());
+		return 0;
+	}
+	const int blocks = ((nPackets + 127) / 128) * 128;
+	SnailScene::RayDefer &R = s->rayDefer[s->rayCount++ % SnailScene::kDeferSlots];
+	if((size_t)nPackets + 16 > R.cap) { // grown synchronously when a larger batch than ever before arrives
+		HIP_TRY(hipDeviceSynchronize());
+		if(R.p) (void)hipFree(R.p);
+		R.p = nullptr; R.cap = 0;
+		HIP_TRY(hipMalloc((void **)&R.p, ((size_t)nPackets + 16) * sizeof(int)));
+		HIP_TRY(hipMemset(R.p, 0, 16 * sizeof(int)));
+		R.cap = (size_t)nPackets + 16;
+	}
+	if(!R.done) HIP_TRY(hipEventCreateWithFlags(&R.done, hipEventDisableTiming));
+	if(R.used) HIP_TRY(hipStreamWaitEvent(stream, R.done, 0));
+	A.defer = R.p;
+	const int exactBlocks = A.fastOK ? (blocks < 8 ? blocks : 8) : (blocks < 2048 ? blocks : 2048);
+	if(sharedOrigin && mask) launchRaysKernels<true, true>(s, A, blocks, exactBlocks, stream);
+	else if(sharedOrigin) launchRaysKernels<true, false>(s, A, blocks, exactBlocks, stream);
+	else if(mask) launchRaysKernels<false, true>(s, A, blocks, exactBlocks, stream);
+	else launchRaysKernels<false, false>(s, A, blocks, exactBlocks, stream);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(R.done, stream));
+	R.used = true;
+	return 0;
+}
+
 template <int SRC>
 void launchLights(const SnailScene *s, const dev::ShadeArgs &A, hipStream_t stream) {
 	if(A.nLights <= 0) return;
@@ -1807,6 +1901,8 @@ void snail_scene_destroy(SnailScene *s) {
 	for(int k = 0; k < SnailScene::kDeferSlots; k++) if(s->dDefer[k]) (void)hipFree(s->dDefer[k]);
 	for(int k = 0; k < SnailScene::kDeferSlots; k++) if(s->shade[k].hitT) (void)hipFree(s->shade[k].hitT);
 	for(int k = 0; k < SnailScene::kDeferSlots; k++) {
+		if(s->rayDefer[k].p) (void)hipFree(s->rayDefer[k].p);
+		if(s->rayDefer[k].done) (void)hipEventDestroy(s->rayDefer[k].done);
 		if(s->deferDone[k]) (void)hipEventDestroy(s->deferDone[k]);
 		if(s->shade[k].done) (void)hipEventDestroy(s->shade[k].done);
 	}
@@ -1885,28 +1981,6 @@ int snail_trace_primary(SnailScene *s, const float cam[13], int resx, int resy, 
 	return 0;
 }
 
-static int launchRays(SnailScene *s, bool shadow, int nPackets, int size, int sharedOrigin, const float *origin, const float *dir,
-					  const float *idir, const uint8_t *mask, float *distance, int32_t *object, float *bary, uint64_t *dStats, hipStream_t stream) {
-	if(nPackets <= 0) return 0;
-	if(size < 1 || size > SNAIL_PACKET_QUADS) { snail_set_error("packet size %d outside 1..%d quads", size, SNAIL_PACKET_QUADS); return 1; }
-	if(!origin || !dir || !idir || !distance || (!shadow && !object)) { snail_set_error("null ray array"); return 1; }
-	dev::RaysArgs A;
-	memset(&A, 0, sizeof(A));
-	A.nodes = s->dNodes; A.tris = s->dTris;
-	A.nPackets = nPackets; A.size = size; A.fastOK = s->fastOK;
-	A.origin = origin; A.dir = dir; A.idir = idir; A.mask = mask;
-	A.distance = distance; A.object = object; A.bary = bary;
-	A.stats = (dev::u64 *)dStats;
-	const int blocks = (nPackets + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-	const dim3 g(blocks), b(WAVES_PER_BLOCK * 64);
-	if(shadow) hipLaunchKernelGGL(dev::k_shadow, g, b, 0, stream, A);
-	else if(sharedOrigin && mask) hipLaunchKernelGGL((dev::k_rays<true, true>), g, b, 0, stream, A);
-	else if(sharedOrigin) hipLaunchKernelGGL((dev::k_rays<true, false>), g, b, 0, stream, A);
-	else if(mask) hipLaunchKernelGGL((dev::k_rays<false, true>), g, b, 0, stream, A);
-	else hipLaunchKernelGGL((dev::k_rays<false, false>), g, b, 0, stream, A);
-	HIP_TRY(hipGetLastError());
-	return 0;
-}
 
 int snail_trace_rays_dev(SnailScene *s, int nPackets, int size, int sharedOrigin, const float *origin, const float *dir, const float *idir,
 						 const uint8_t *mask, float *distance, int32_t *object, float *bary, uint64_t *dStats, void *stream) {
