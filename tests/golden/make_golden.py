@@ -133,6 +133,11 @@ def oracle_whitted():
                "mean_bgr": [float(x) for x in frame.reshape(-1, 3).mean(axis=0)]}, open(os.path.join(HERE, "oracle_whitted.json"), "w"), indent=1)
     np.savez_compressed(os.path.join(HERE, "oracle_whitted_samples.npz"), bgr=frame[::8, ::8])
     print("oracle_whitted.json written")
+    # the same frame with the one-bounce reflections of gVals[7] (mirrored packets: per-ray origins, lane masks)
+    frame, st = osc.render_whitted(cam.as_array13(), resx, resy, lights, mode=O.MODE_IEEE, reflections=True)
+    json.dump({"scene": name, "res": [resx, resy], "lights": lights.tolist(), "sha_bgr": sha(frame), "stats": [int(x) for x in st],
+               "mean_bgr": [float(x) for x in frame.reshape(-1, 3).mean(axis=0)]}, open(os.path.join(HERE, "oracle_whitted_refl.json"), "w"), indent=1)
+    print("oracle_whitted_refl.json written")
 
 
 if __name__ == "__main__":

@@ -443,15 +443,16 @@ def test_whitted_primary_plus_shadow_bit_exact(torch_mod, name, resx, resy, nl, 
     sc.close()
 
 
-def test_whitted_against_committed_fixture(torch_mod):
+@pytest.mark.parametrize("fixture,refl", [("oracle_whitted.json", False), ("oracle_whitted_refl.json", True)])
+def test_whitted_against_committed_fixture(torch_mod, fixture, refl):
     import hashlib
     import json
     import os
-    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_whitted.json")))
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture)))
     tv, sc, osc = gpu_scene(g["scene"])
     cam = util.camera_for(g["scene"], tv)
     stats = sc.new_stats()
-    fr = sc.render_whitted(cam, g["res"][0], g["res"][1], np.asarray(g["lights"], dtype=np.float32), stats=stats)
+    fr = sc.render_whitted(cam, g["res"][0], g["res"][1], np.asarray(g["lights"], dtype=np.float32), stats=stats, reflections=refl)
     torch_mod.cuda.synchronize()
     assert hashlib.sha256(fr.cpu().numpy().tobytes()).hexdigest() == g["sha_bgr"]
     assert stats.cpu().numpy().tolist() == g["stats"]
