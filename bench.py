@@ -193,11 +193,13 @@ def main():
             "config": {"workload": "%s (%d tris, sponza.obj stand-in) %dx%d primary rays, hit records (t,u,v,triId)" % (args.scene, hbvh.n_tris, resx, resy),
                        "rays_per_step": total_rays, "packets": "16x16 px = 1 wavefront", "bvh_nodes": hbvh.n_nodes, "bvh_depth": hbvh.depth,
                        "bvh_build_s": round(build_s, 3), "hit_fraction": round(hit_frac, 5), "frames_in_flight": rnd.nslots,
+                       "traversal_stack": "VGPR pair per wave (lane i = slot i), at most bvh_depth+1 = %d slots; LDS 0 B/wave in the main kernel (3328 B/wave only in the deferred M_EXACT pass)" % (hbvh.depth + 1),
                        "parallelism": "tiles16x64-roundrobin-x%d + depth-shade + async RCCL gather of rgb8 tiles to rank 0" % world if world > 1 else "single-gpu"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_bytes_per_launch": tr["bytes_per_launch"] if tr else None,
                          "traffic_source": tr["source"] if tr else None, "kernel": "dev::k_primary", "kernel_ms": round(kern_ms, 5),
                          "alg_bytes_per_ray": round(b_alg, 1), "rays_per_launch": launch_rays,
+                         "compulsory_bytes_per_ray": round((32.0 * hbvh.n_nodes + 64.0 * hbvh.n_tris) / launch_rays + 16.0, 2),
                          "note": "achieved = single-ray algorithmic bytes (32*V_n+64*V_t+16 per ray) / kernel time; the packet kernel fetches a node once per 256 rays, so this can exceed the HBM peak"},
         }
         if world == 1 and not args.no_cpu_baseline:
