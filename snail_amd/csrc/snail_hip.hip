@@ -609,25 +609,35 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 #ifndef SNAIL_EXP_PAD
 #define SNAIL_EXP_PAD "" // experiment hook: extra instructions per node visit (tools/exp_pad.sh)
 #endif
-#define SNAIL_RAY_SLAB(L, S)                                                                                                               \
+// slab products of ray L -> tn in t0, tf in t3.  COH: near/far planes known (pn*, pf*); FAST: planes bmin-o / bmax-o, min/max per axis
+#define SNAIL_SLAB_COH(L)                                                                                                                  \
 	"v_mul_f32 %[t0], %[ix" L "], %[pnx]\n v_mul_f32 %[t1], %[iy" L "], %[pny]\n v_mul_f32 %[t2], %[iz" L "], %[pnz]\n"                    \
 	"v_mul_f32 %[t3], %[ix" L "], %[pfx]\n v_mul_f32 %[t4], %[iy" L "], %[pfy]\n v_mul_f32 %[t5], %[iz" L "], %[pfz]\n"                    \
-	"v_max3_f32 %[t0], %[t0], %[t1], %[t2]\n v_min3_f32 %[t3], %[t3], %[t4], %[t5]\n"                                                      \
-	"v_max_f32 %[t0], 0, %[t0]\n v_min_f32 %[t3], %[t3], %[d" L "]\n v_sub_f32 %[" S "], %[t3], %[t0]\n"
-#define SNAIL_DESCEND_ASM(NX, FX, NY, FY, NZ, FZ)                                                                                          \
+	"v_max3_f32 %[t0], %[t0], %[t1], %[t2]\n v_min3_f32 %[t3], %[t3], %[t4], %[t5]\n"
+#define SNAIL_SLAB_FAST(L)                                                                                                                 \
+	"v_mul_f32 %[t0], %[ix" L "], %[pnx]\n v_mul_f32 %[t3], %[ix" L "], %[pfx]\n v_min_f32 %[u0], %[t0], %[t3]\n v_max_f32 %[t3], %[t0], %[t3]\n" \
+	"v_mul_f32 %[t1], %[iy" L "], %[pny]\n v_mul_f32 %[t4], %[iy" L "], %[pfy]\n v_min_f32 %[t0], %[t1], %[t4]\n v_max_f32 %[t4], %[t1], %[t4]\n" \
+	"v_mul_f32 %[t2], %[iz" L "], %[pnz]\n v_mul_f32 %[t5], %[iz" L "], %[pfz]\n v_min_f32 %[t1], %[t2], %[t5]\n v_max_f32 %[t5], %[t2], %[t5]\n" \
+	"v_max3_f32 %[t0], %[u0], %[t0], %[t1]\n v_min3_f32 %[t3], %[t3], %[t4], %[t5]\n"
+// the ray's slack -> S.  POS: distances >= 0 (primary): min(tf,dist) - max(tn,0);  ANY: any distance, -inf = masked (shadow):
+// min(min(tf,dist) - tn, tf)
+#define SNAIL_TAIL_POS(L, S) "v_max_f32 %[t0], 0, %[t0]\n v_min_f32 %[t3], %[t3], %[d" L "]\n v_sub_f32 %[" S "], %[t3], %[t0]\n"
+#define SNAIL_TAIL_ANY(L, S) "v_min_f32 %[t4], %[t3], %[d" L "]\n v_sub_f32 %[t4], %[t4], %[t0]\n v_min_f32 %[" S "], %[t4], %[t3]\n"
+#define SNAIL_COUNT " s_add_u32 %[cnt], %[cnt], 1\n"
+#define SNAIL_DESCEND_ASM(SLAB, TAIL, CNTPOP, CNTVISIT, NX, FX, NY, FY, NZ, FZ)                                                            \
 	asm volatile("L_pop_%=:\n"                                                                                                             \
 				 " s_cmp_eq_u32 %[sp], 0\n s_cbranch_scc1 L_done_%=\n"                                                                     \
-				 " s_sub_u32 %[sp], %[sp], 1\n s_add_u32 %[pops], %[pops], 1\n"                                                            \
+				 " s_sub_u32 %[sp], %[sp], 1\n" CNTPOP                                                                                     \
 				 " v_readlane_b32 %[cur], %[stkN], %[sp]\n v_readlane_b32 %[fl], %[stkF], %[sp]\n"                                         \
 				 " s_lshl_b32 %[off], %[cur], 5\n s_load_dwordx8 s[84:91], %[base], %[off]\n"                                              \
 				 " s_and_b32 %[first], %[fl], 0xff\n s_lshr_b32 %[last], %[fl], 8\n s_sub_u32 %[width], %[last], %[first]\n"               \
 				 " s_waitcnt lgkmcnt(0)\n"                                                                                                 \
-				 "L_visit_%=:\n"                                                                                                           \
+				 "L_visit_%=:\n" CNTVISIT                                                                                                  \
 				 " v_sub_f32 %[pnx], " NX ", %[ox]\n v_sub_f32 %[pny], " NY ", %[oy]\n v_sub_f32 %[pnz], " NZ ", %[oz]\n"                  \
 				 " v_sub_f32 %[pfx], " FX ", %[ox]\n v_sub_f32 %[pfy], " FY ", %[oy]\n v_sub_f32 %[pfz], " FZ ", %[oz]\n"                  \
-				 SNAIL_RAY_SLAB("0", "s0") SNAIL_RAY_SLAB("1", "s1") SNAIL_RAY_SLAB("2", "s2") SNAIL_RAY_SLAB("3", "s3")                   \
+				 SLAB("0") TAIL("0", "s0") SLAB("1") TAIL("1", "s1") SLAB("2") TAIL("2", "s2") SLAB("3") TAIL("3", "s3")                   \
 				 " v_max_f32 %[s2], %[s2], %[s3]\n v_max3_f32 %[s0], %[s0], %[s1], %[s2]\n"                                                \
-				 SNAIL_EXP_PAD                                                                                                                            \
+				 SNAIL_EXP_PAD                                                                                                             \
 				 " v_cmp_le_f32 vcc, 0, %[s0]\n"                                                                                           \
 				 " v_subrev_u32 %[t0], %[first], %[lane]\n v_cmp_ge_u32 %[rng], %[width], %[t0]\n"                                         \
 				 " s_and_b64 %[alive], vcc, %[rng]\n s_cbranch_scc0 L_pop_%=\n"                                                            \
@@ -645,24 +655,51 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 "L_leaf_%=:\n s_mov_b32 %[leafSub], s90\n s_mov_b32 %[leafAux], s91\n s_branch L_end_%=\n"                                \
 				 "L_done_%=:\n s_mov_b32 %[leafSub], 0\n s_mov_b32 %[leafAux], 0\n"                                                        \
 				 "L_end_%=:\n"                                                                                                             \
-				 : [sp] "+s"(sp), [first] "+s"(first), [last] "+s"(last), [pops] "+s"(pops), [stkN] "+v"(stkN), [stkF] "+v"(stkF),         \
+				 : [sp] "+s"(sp), [first] "+s"(first), [last] "+s"(last), [cnt] "+s"(cnt), [stkN] "+v"(stkN), [stkF] "+v"(stkF),           \
 				   [leafSub] "=&s"(leafSub), [leafAux] "=&s"(leafAux), [cur] "=&s"(sCur), [fl] "=&s"(sFl), [off] "=&s"(sOff),              \
 				   [width] "=&s"(sWidth), [rng] "=&s"(sRng), [alive] "=&s"(sAlive), [pnx] "=&v"(vt[0]), [pny] "=&v"(vt[1]),                \
 				   [pnz] "=&v"(vt[2]), [pfx] "=&v"(vt[3]), [pfy] "=&v"(vt[4]), [pfz] "=&v"(vt[5]), [t0] "=&v"(vt[6]), [t1] "=&v"(vt[7]),   \
 				   [t2] "=&v"(vt[8]), [t3] "=&v"(vt[9]), [t4] "=&v"(vt[10]), [t5] "=&v"(vt[11]), [s0] "=&v"(vt[12]), [s1] "=&v"(vt[13]),   \
-				   [s2] "=&v"(vt[14]), [s3] "=&v"(vt[15])                                                                                  \
+				   [s2] "=&v"(vt[14]), [s3] "=&v"(vt[15]), [u0] "=&v"(vt[16])                                                              \
 				 : [base] "s"(nodeBase), [sign16] "s"(sign16), [lane] "v"(lane), [ox] "v"(org[0][0]), [oy] "v"(org[1][0]),                 \
 				   [oz] "v"(org[2][0]), [ix0] "v"(Q.id[0][0]), [ix1] "v"(Q.id[0][1]), [ix2] "v"(Q.id[0][2]), [ix3] "v"(Q.id[0][3]),        \
 				   [iy0] "v"(Q.id[1][0]), [iy1] "v"(Q.id[1][1]), [iy2] "v"(Q.id[1][2]), [iy3] "v"(Q.id[1][3]), [iz0] "v"(Q.id[2][0]),      \
 				   [iz1] "v"(Q.id[2][1]), [iz2] "v"(Q.id[2][2]), [iz3] "v"(Q.id[2][3]), [d0] "v"(Q.dist[0]), [d1] "v"(Q.dist[1]),          \
 				   [d2] "v"(Q.dist[2]), [d3] "v"(Q.dist[3])                                                                                \
-				 : "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "vcc", "scc", "m0")
+				 : "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "vcc", "scc", "m0");                                            \
+	/* every result is consumed HERE, in the block of the asm statement (no code is emitted for this): LLVM classes the whole result     \
+	   tuple of an asm with mixed SGPR/VGPR outputs as scalar once the tuple itself is live across a block boundary                      \
+	   (SITargetLowering::requiresUniformRegister), i.e. once the optimiser sinks one of the extractions into a successor */              \
+	asm volatile("" ::"s"(sp), "s"(first), "s"(last), "s"(cnt), "v"(stkN), "v"(stkF), "s"(leafSub), "s"(leafAux), "s"(sCur), "s"(sFl), "s"(sOff),    \
+				 "s"(sWidth), "s"(sRng), "s"(sAlive), "v"(vt[0]), "v"(vt[1]), "v"(vt[2]), "v"(vt[3]), "v"(vt[4]), "v"(vt[5]), "v"(vt[6]), "v"(vt[7]), \
+				 "v"(vt[8]), "v"(vt[9]), "v"(vt[10]), "v"(vt[11]), "v"(vt[12]), "v"(vt[13]), "v"(vt[14]), "v"(vt[15]), "v"(vt[16]))
+// near/far plane registers by sign octant (bit k set = idir negative on axis k: near plane = bmax[k]); s[84:86] = bmin, s[87:89] = bmax
+#define SNAIL_DESCEND_OCT(SLAB, TAIL, CNTPOP, CNTVISIT, OCT)                                                                               \
+	switch(OCT) {                                                                                                                          \
+	case 0: SNAIL_DESCEND_ASM(SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s85", "s88", "s86", "s89"); break;                              \
+	case 1: SNAIL_DESCEND_ASM(SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s85", "s88", "s86", "s89"); break;                              \
+	case 2: SNAIL_DESCEND_ASM(SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s88", "s85", "s86", "s89"); break;                              \
+	case 3: SNAIL_DESCEND_ASM(SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s88", "s85", "s86", "s89"); break;                              \
+	case 4: SNAIL_DESCEND_ASM(SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s85", "s88", "s89", "s86"); break;                              \
+	case 5: SNAIL_DESCEND_ASM(SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s85", "s88", "s89", "s86"); break;                              \
+	case 6: SNAIL_DESCEND_ASM(SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s88", "s85", "s89", "s86"); break;                              \
+	default: SNAIL_DESCEND_ASM(SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s88", "s85", "s89", "s86"); break;                             \
+	}
 
-template <int OCT>
-__device__ __forceinline__ void walkPrimaryCoh(const uint4 *__restrict__ nodes, const uint4 *__restrict__ tris, int lane, const float (&org)[3][4],
-											   Quad &Q, int (&tid)[4], float *lds, Counters &st) {
+// SHADOW=false: closest hit of a primary packet (distances >= 0; visits = 2 * pops - 1: every chain of visits starts with a pop,
+// the root is pushed here, and every push is popped).  SHADOW=true: any hit of a shadow packet (masked lanes -inf; the walk ends
+// when a triangle occludes the whole packet, so every visit is counted).  COH: one asm statement per sign octant, picked by a
+// wave-uniform switch at every (re-)entry, i.e. once per leaf; the leaf code exists once.
+template <bool SHADOW, bool COH>
+__device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes, const uint4 *__restrict__ tris, int lane, const float (&org)[3][4],
+											  Quad &Q, int (&tid)[4], float *lds, Counters &st, const int oct) {
 	Interval iv;
-	computeMinMax<false, false>(Q.d, 15u, 64, lane, lds, iv.minDir, iv.maxDir);
+	if(SHADOW) {
+		unsigned act4 = 0;
+#pragma unroll
+		for(int l = 0; l < 4; l++) act4 |= (Q.dist[l] >= 0.0f ? 1u : 0u) << l;
+		computeMinMax<false, true>(Q.d, act4, 64, lane, lds, iv.minDir, iv.maxDir);
+	} else computeMinMax<false, false>(Q.d, 15u, 64, lane, lds, iv.minDir, iv.maxDir);
 #pragma unroll
 	for(int k = 0; k < 3; k++) { iv.minIDir[k] = iv.maxIDir[k] = 0.0f; iv.minOrg[k] = iv.maxOrg[k] = org[k][0]; }
 	const int signBits = __builtin_amdgcn_readfirstlane((Q.d[0][0] < 0.0f ? 1 : 0) | (Q.d[1][0] < 0.0f ? 2 : 0) | (Q.d[2][0] < 0.0f ? 4 : 0));
@@ -670,29 +707,24 @@ __device__ __forceinline__ void walkPrimaryCoh(const uint4 *__restrict__ nodes, 
 	const u64 nodeBase = (u64)nodes;
 	float bu[4], bv[4]; // not maintained here (finalBarycentrics)
 	int stkN = 0, stkF = 63 << 8; // slot 0 = the root with the full quad range
-	int sp = 1, first = 0, last = 63, pops = 0;
+	int sp = 1, first = 0, last = 63, cnt = 0;
 	for(;;) {
 		int leafSub, leafAux, sCur, sFl, sOff, sWidth;
 		u64 sRng, sAlive;
-		float vt[16];
-		if(OCT == 0) SNAIL_DESCEND_ASM("s84", "s87", "s85", "s88", "s86", "s89");
-		else if(OCT == 1) SNAIL_DESCEND_ASM("s87", "s84", "s85", "s88", "s86", "s89");
-		else if(OCT == 2) SNAIL_DESCEND_ASM("s84", "s87", "s88", "s85", "s86", "s89");
-		else if(OCT == 3) SNAIL_DESCEND_ASM("s87", "s84", "s88", "s85", "s86", "s89");
-		else if(OCT == 4) SNAIL_DESCEND_ASM("s84", "s87", "s85", "s88", "s89", "s86");
-		else if(OCT == 5) SNAIL_DESCEND_ASM("s87", "s84", "s85", "s88", "s89", "s86");
-		else if(OCT == 6) SNAIL_DESCEND_ASM("s84", "s87", "s88", "s85", "s89", "s86");
-		else SNAIL_DESCEND_ASM("s87", "s84", "s88", "s85", "s89", "s86");
-		// every result is consumed HERE, in the block of the asm statement (no code is emitted for this): LLVM classes the whole
-		// result tuple of an asm with mixed SGPR/VGPR outputs as scalar once the tuple itself is live across a block boundary
-		// (SITargetLowering::requiresUniformRegister), i.e. once the optimiser sinks one of the extractions into a successor
-		asm volatile("" ::"s"(sp), "s"(first), "s"(last), "s"(pops), "v"(stkN), "v"(stkF), "s"(leafSub), "s"(leafAux), "s"(sCur), "s"(sFl), "s"(sOff),
-					 "s"(sWidth), "s"(sRng), "s"(sAlive), "v"(vt[0]), "v"(vt[1]), "v"(vt[2]), "v"(vt[3]), "v"(vt[4]), "v"(vt[5]), "v"(vt[6]), "v"(vt[7]),
-					 "v"(vt[8]), "v"(vt[9]), "v"(vt[10]), "v"(vt[11]), "v"(vt[12]), "v"(vt[13]), "v"(vt[14]), "v"(vt[15]));
+		float vt[17];
+		if(COH) {
+			if(SHADOW) { SNAIL_DESCEND_OCT(SNAIL_SLAB_COH, SNAIL_TAIL_ANY, "", SNAIL_COUNT, oct) }
+			else { SNAIL_DESCEND_OCT(SNAIL_SLAB_COH, SNAIL_TAIL_POS, SNAIL_COUNT, "", oct) }
+		} else {
+			if(SHADOW) { SNAIL_DESCEND_ASM(SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, "", SNAIL_COUNT, "s84", "s87", "s85", "s88", "s86", "s89"); }
+			else { SNAIL_DESCEND_ASM(SNAIL_SLAB_FAST, SNAIL_TAIL_POS, SNAIL_COUNT, "", "s84", "s87", "s85", "s88", "s86", "s89"); }
+		}
 		if(leafSub == 0) break;
-		leafShared<false, false, M_COH, false>(tris, leafAux, (int)((unsigned)leafSub & 0x7fffffffu), 64, lane, first, last, org, Q, 15u, tid, bu, bv, iv, st);
+		if(leafShared<false, SHADOW, COH ? M_COH : M_FAST, false>(tris, leafAux, (int)((unsigned)leafSub & 0x7fffffffu), 64, lane, first, last, org, Q, 15u,
+																   tid, bu, bv, iv, st))
+			break;
 	}
-	st.iters += 2u * (unsigned)pops - 1u;
+	st.iters += SHADOW ? (unsigned)cnt : 2u * (unsigned)cnt - 1u;
 }
 
 // barycentrics of the final hits, derived after the walk (primary kernel): the same operations on the same
@@ -855,18 +887,11 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 	else if(mode == M_EXACT) {
 		if(lane == 0) A.defer[2 + atomicAdd(&A.defer[0], 1)] = li;
 		return;
-	} else if(mode == M_COH) {
-#define SNAIL_WALK_OCT(O)                                                                                                                  \
-	do {                                                                                                                                   \
-		if(DEEP) walk<true, false, false, M_COH, false, DEEP, true, O>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, O);     \
-		else walkPrimaryCoh<O>(A.nodes, A.tris, lane, org, Q, tid, lds, st);                                                               \
-	} while(0)
-		switch(oct) { // one specialised walk per sign octant, chosen once per packet
-		case 0: SNAIL_WALK_OCT(0); break; case 1: SNAIL_WALK_OCT(1); break; case 2: SNAIL_WALK_OCT(2); break; case 3: SNAIL_WALK_OCT(3); break;
-		case 4: SNAIL_WALK_OCT(4); break; case 5: SNAIL_WALK_OCT(5); break; case 6: SNAIL_WALK_OCT(6); break; default: SNAIL_WALK_OCT(7); break;
-		}
-#undef SNAIL_WALK_OCT
-	} else walk<true, false, false, M_FAST, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st);
+	} else if(DEEP) { // depth > 62: the C++ walk with its second stack register pair
+		if(mode == M_COH) walk<true, false, false, M_COH, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, oct);
+		else walk<true, false, false, M_FAST, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st);
+	} else if(mode == M_COH) walkSharedAsm<false, true>(A.nodes, A.tris, lane, org, Q, tid, lds, st, oct);
+	else walkSharedAsm<false, false>(A.nodes, A.tris, lane, org, Q, tid, lds, st, 0);
 	finalBarycentrics(A.tris, org, Q, tid, bu, bv);
 
 	flushStats(A.stats, st, 256u, lane);
@@ -1049,19 +1074,20 @@ __device__ __forceinline__ void loadSamples(const ShadeArgs &A, const PacketPos 
 // bbox of the packet's hit points: per SSE slot over the quads, then Minimize / Maximize (src/scene_trace.cpp:375-376,
 // src/rtbase_math.h:63-64)
 __device__ __forceinline__ void hitBounds(const Samples &S, float (&tMin)[3], float (&tMax)[3]) {
+	// min / max of finite values (+-inf for lanes without a hit) are exact and order-independent up to the sign of a zero, which
+	// neither the comparisons nor the squared differences of BoxPointDistanceSq observe: fold the 4 SSE slots first, then ONE
+	// wave reduction per component instead of four
 	const float inf = __builtin_inff();
-	float mnP[3][4], mxP[3][4];
-#pragma unroll
-	for(int l = 0; l < 4; l++)
-#pragma unroll
-		for(int c = 0; c < 3; c++) {
-			mnP[c][l] = waveMin(S.hit[l] ? S.pos[c][l] : inf);
-			mxP[c][l] = waveMax(S.hit[l] ? S.pos[c][l] : -inf);
-		}
 #pragma unroll
 	for(int c = 0; c < 3; c++) {
-		tMin[c] = Min<M_EXACT>(Min<M_EXACT>(mnP[c][0], mnP[c][1]), Min<M_EXACT>(mnP[c][2], mnP[c][3]));
-		tMax[c] = Max<M_EXACT>(Max<M_EXACT>(mxP[c][0], mxP[c][1]), Max<M_EXACT>(mxP[c][2], mxP[c][3]));
+		float mn = inf, mx = -inf;
+#pragma unroll
+		for(int l = 0; l < 4; l++) {
+			mn = vmin(mn, S.hit[l] ? S.pos[c][l] : inf);
+			mx = vmax(mx, S.hit[l] ? S.pos[c][l] : -inf);
+		}
+		tMin[c] = waveMin(mn);
+		tMax[c] = waveMax(mx);
 	}
 }
 // the packet-level light cull: BoxPointDistanceSq(bbox, light) > radSq (src/scene_trace.cpp:494-501, src/funcs.cpp:8-49); wave-uniform
@@ -1139,8 +1165,11 @@ __device__ __forceinline__ void lightPacket(const ShadeArgs &A, const int li, co
 			if(lane == 0) A.defer[16 + atomicAdd(&A.defer[0], 1)] = n * A.nBlocks + li;
 			return;
 		}
-		if(mode == M_COH) walk<true, false, true, M_COH, false, DEEP, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st, oct);
-		else walk<true, false, true, M_FAST, false, DEEP, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st);
+		if(DEEP) {
+			if(mode == M_COH) walk<true, false, true, M_COH, false, DEEP, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st, oct);
+			else walk<true, false, true, M_FAST, false, DEEP, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st);
+		} else if(mode == M_COH) walkSharedAsm<true, true>(A.nodes, A.tris, lane, lorg, Q, stid, lds, st, oct);
+		else walkSharedAsm<true, false>(A.nodes, A.tris, lane, lorg, Q, stid, lds, st, 0);
 	}
 	flushStats(A.stats, st, rays, lane);
 	const size_t packets = (size_t)A.pw * A.ph;
