@@ -1177,7 +1177,7 @@ __device__ __forceinline__ void lightPacket(const ShadeArgs &A, const int li, co
 }
 
 template <bool DEEP, int SRC>
-__global__ __launch_bounds__(64) void k_light(ShadeArgs A) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_light(ShadeArgs A) {
 	__shared__ float lds[LDS_FLOATS_PER_WAVE];
 	lightPacket<DEEP, SRC, false>(A, interleave16((int)blockIdx.x), (int)blockIdx.y, lds);
 }
