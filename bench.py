@@ -200,6 +200,9 @@ def main():
                          "traffic_source": tr["source"] if tr else None, "kernel": "dev::k_primary", "kernel_ms": round(kern_ms, 5),
                          "alg_bytes_per_ray": round(b_alg, 1), "rays_per_launch": launch_rays,
                          "compulsory_bytes_per_ray": round((32.0 * hbvh.n_nodes + 64.0 * hbvh.n_tris) / launch_rays + 16.0, 2),
+                         # what actually bounds this kernel (profiles/README.md): the SIMDs' VALU pipes.  One wave64 VALU instruction per
+                         # 2 cycles per SIMD, 1024 SIMDs, 2.4 GHz; instruction count per launch from the committed PMC pass
+                         "valu_pipe_frac": round(tr["valu_insts_per_launch"] * 2.0 / (1024 * ms_per_step * 1e-3 * 2.4e9), 4) if tr and world == 1 and "valu_insts_per_launch" in tr else None,
                          "note": "achieved = single-ray algorithmic bytes (32*V_n+64*V_t+16 per ray) / kernel time; the packet kernel fetches a node once per 256 rays, so this can exceed the HBM peak"},
         }
         if world == 1 and not args.no_cpu_baseline:
