@@ -892,7 +892,7 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 		else walk<true, false, false, M_FAST, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st);
 	} else if(mode == M_COH) walkSharedAsm<false, true>(A.nodes, A.tris, lane, org, Q, tid, lds, st, oct);
 	else walkSharedAsm<false, false>(A.nodes, A.tris, lane, org, Q, tid, lds, st, 0);
-	finalBarycentrics(A.tris, org, Q, tid, bu, bv);
+	if(A.u || A.v) finalBarycentrics(A.tris, org, Q, tid, bu, bv); // (the staged shading pipeline asks for t and triId only)
 
 	flushStats(A.stats, st, 256u, lane);
 	if(A.cost && lane == 0) {
@@ -1306,12 +1306,20 @@ __global__ __launch_bounds__(64) void k_final(ShadeArgs A) {
 	const int yy = P.py + (lane >> 2), xx = P.px + (lane & 3) * 4;
 	if(yy < A.resy) {
 		unsigned char *dd = A.frame + (size_t)yy * A.pitch + (size_t)xx * 3;
+		unsigned bytes[12];
 #pragma unroll
-		for(int l = 0; l < 4; l++)
-			if(xx + l < A.resx) {
-				dd[l * 3 + 0] = (unsigned char)convChannelW(col[2][l]); dd[l * 3 + 1] = (unsigned char)convChannelW(col[1][l]);
-				dd[l * 3 + 2] = (unsigned char)convChannelW(col[0][l]);
-			}
+		for(int l = 0; l < 4; l++) { bytes[l * 3 + 0] = (unsigned)convChannelW(col[2][l]); bytes[l * 3 + 1] = (unsigned)convChannelW(col[1][l]); bytes[l * 3 + 2] = (unsigned)convChannelW(col[0][l]); }
+		if(xx + 3 < A.resx && (A.pitch & 3) == 0 && ((unsigned long long)A.frame & 3) == 0) { // 4 pixels = 12 bytes = three aligned dwords (xx is a multiple of 4)
+			unsigned w[3];
+#pragma unroll
+			for(int k = 0; k < 3; k++) w[k] = bytes[4 * k] | (bytes[4 * k + 1] << 8) | (bytes[4 * k + 2] << 16) | (bytes[4 * k + 3] << 24);
+			unsigned *dw = (unsigned *)dd;
+			dw[0] = w[0]; dw[1] = w[1]; dw[2] = w[2];
+		} else {
+#pragma unroll
+			for(int l = 0; l < 4; l++)
+				if(xx + l < A.resx) { dd[l * 3 + 0] = (unsigned char)bytes[l * 3 + 0]; dd[l * 3 + 1] = (unsigned char)bytes[l * 3 + 1]; dd[l * 3 + 2] = (unsigned char)bytes[l * 3 + 2]; }
+		}
 	}
 }
 
