@@ -139,7 +139,10 @@ class DistributedRenderer:
             self.packet_xy = torch.from_numpy(self.plan.padded_packets(rank)).to(dev)
             # per slot one buffer [4, n, 256] (t, u, v, triId) so that the four planes can travel in ONE collective (payload "hits")
             self.local = [torch.empty((4, n, 256), dtype=torch.float32, device=dev) for _ in range(self.nslots)]
-            self.planes = [(b[0], b[1], b[2], b[3].view(torch.int32)) for b in self.local]
+            if payload == "hits":
+                self.planes = [(b[0], b[1], b[2], b[3].view(torch.int32)) for b in self.local]
+            else:   # the depth shader consumes t only: the kernel neither derives nor stores u, v, triId
+                self.planes = [(b[0], None, None, None) for b in self.local]
             self.bgr = [torch.empty((n, 256, 3), dtype=torch.uint8, device=dev) for _ in range(self.nslots)]
             if rank == 0:
                 self.all_xy = [torch.from_numpy(self.plan.padded_packets(r)).to(dev) for r in range(world_size)]

@@ -9,6 +9,7 @@ Newton step) is compared with tolerance 1e-4 in test_sse_mode_tolerance."""
 import numpy as np
 import pytest
 
+from snail_amd import FPSCamera, scenes
 from tests import oracle_lib as O
 from tests import util
 
@@ -520,4 +521,45 @@ def test_exact_mode_primary_frame_with_degenerate_triangles(torch_mod):
     frame2 = sc.trace_primary(cam, 256, 256)
     torch_mod.cuda.synchronize()
     compare_frames(frame2, ref, "second launch")
+    sc.close()
+
+
+def test_every_sign_octant_and_walk_variant(torch_mod):
+    """The node loop exists once per sign octant (coherent packets) plus once for non-coherent packets, for closest-hit and for
+    any-hit walks: cameras looking into all eight octants from inside the atrium, with a light, so that every variant runs.
+    Hit records, shaded frames and counters equal the oracle's bit for bit; the test checks itself that all octants occur."""
+    import math
+    name = "atrium:0.05"
+    tv, sc, osc = gpu_scene(name)
+    pos, _, _ = scenes.atrium_camera()
+    bmin, bmax = osc.nodes[0]["bmin"], osc.nodes[0]["bmax"]
+    c, e = (bmin + bmax) * 0.5, (bmax - bmin)
+    lights = np.array([[c[0] + 0.1 * e[0], c[1] + 0.2 * e[1], c[2] - 0.1 * e[2], 1.0, 0.9, 0.8, 2.0 * float(e.max())]], dtype=np.float32)
+    resx, resy = 192, 160
+    seen_primary, seen_mixed = set(), 0
+    for yaw in (0.3, 0.3 + math.pi / 2, 0.3 + math.pi, 0.3 + 3 * math.pi / 2):
+        for pitch in (0.7, -0.7):
+            cam = FPSCamera(np.asarray(pos, dtype=np.float32), yaw, pitch).camera()
+            for py in range(0, resy, 16):
+                for px in range(0, resx, 16):
+                    d, idir = O.gen_packet(cam.as_array13(), resx, resy, px, py)
+                    sg = np.signbit(idir.reshape(64, 3, 4)).transpose(1, 0, 2).reshape(3, -1)
+                    if all(sg[k].all() or (~sg[k]).all() for k in range(3)):
+                        seen_primary.add(int(sg[0, 0]) | int(sg[1, 0]) << 1 | int(sg[2, 0]) << 2)
+                    else:
+                        seen_mixed += 1
+            want = osc.render_primary(cam.as_array13(), resx, resy, mode=O.MODE_IEEE)
+            stats = sc.new_stats()
+            fr = sc.trace_primary(cam, resx, resy, stats=stats)
+            torch_mod.cuda.synchronize()
+            for got, w, nm in zip((fr.t, fr.u, fr.v, fr.tri_id), want[:4], "t u v id".split()):
+                util.assert_bit_equal(got.cpu().numpy(), w, "%s yaw %.2f pitch %.2f" % (nm, yaw, pitch))
+            assert np.array_equal(stats.cpu().numpy().astype(np.uint64), want[4])
+            wimg, wst = osc.render_whitted(cam.as_array13(), resx, resy, lights, mode=O.MODE_IEEE, reflections=True)
+            stats = sc.new_stats()
+            img = sc.render_whitted(cam, resx, resy, lights, stats=stats, reflections=True)
+            torch_mod.cuda.synchronize()
+            assert np.array_equal(img.cpu().numpy(), wimg), (yaw, pitch)
+            assert np.array_equal(stats.cpu().numpy().astype(np.uint64), wst), (yaw, pitch)
+    assert seen_primary == set(range(8)) and seen_mixed > 0, (seen_primary, seen_mixed)
     sc.close()
