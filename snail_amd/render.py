@@ -115,7 +115,7 @@ class DistributedRenderer:
     overlaps both.  flush() completes the frames still in flight."""
 
     def __init__(self, scene, resx: int, resy: int, rank: int = 0, world_size: int = 1, group=None, seed: int = 20090501,
-                 payload: str = "rgb8", slots: int = 3, stage_cpu: bool = False):
+                 payload: str = "rgb8", slots: int = 3, stage_cpu: bool = False, force_collective: bool = False):
         import torch
         self.torch = torch
         self.scene = scene
@@ -125,16 +125,19 @@ class DistributedRenderer:
         # stage_cpu: move the payload through host memory so that a CPU backend (gloo) can carry the collective --
         # used to rehearse the multi-rank path on a box whose ranks share one GPU; the product path is RCCL on device buffers
         self.stage_cpu = stage_cpu
+        # force_collective: run the tile plan + shade + gather + scatter route even with ONE rank (the collective then moves rank 0's
+        # buffer to itself) -- lets a single-GPU box exercise the RCCL code path of the multi-GPU bench
+        self.multi = world_size > 1 or force_collective
         self.plan = ShardPlan.make(resx, resy, world_size, seed)
         dev = scene._dev()
         self.nslots = max(1, slots)
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.nslots)]
         self.step = 0
-        self.frames = [scene.alloc_frame(resx, resy) for _ in range(self.nslots if world_size == 1 else (1 if payload == "hits" else 0))] if rank == 0 else []
+        self.frames = [scene.alloc_frame(resx, resy) for _ in range(self.nslots if not self.multi else (1 if payload == "hits" else 0))] if rank == 0 else []
         self.frame = self.frames[0] if self.frames else None
-        self.frame_rgb8 = torch.zeros((resy, resx, 3), dtype=torch.uint8, device=dev) if (rank == 0 and world_size > 1 and payload == "rgb8") else None
+        self.frame_rgb8 = torch.zeros((resy, resx, 3), dtype=torch.uint8, device=dev) if (rank == 0 and self.multi and payload == "rgb8") else None
         self.pending = [None] * self.nslots
-        if world_size > 1:
+        if self.multi:
             n = self.plan.padded
             self.packet_xy = torch.from_numpy(self.plan.padded_packets(rank)).to(dev)
             # per slot one buffer [4, n, 256] (t, u, v, triId) so that the four planes can travel in ONE collective (payload "hits")
@@ -183,7 +186,7 @@ class DistributedRenderer:
         self.step += 1
         st = self.streams[slot]
         with torch.cuda.stream(st):
-            if self.world == 1:
+            if not self.multi:
                 if events: events[0].record(st)
                 out = sc.trace_primary(cam, p.resx, p.resy, out=self.frames[slot], stats=stats, stream=st)
                 if events: events[1].record(st)

@@ -1,0 +1,56 @@
+"""Helper of tests/test_gpu_parity.py::test_rccl_code_path_single_rank (run as a child process): the multi-GPU route of
+DistributedRenderer -- tile plan, packet-list launch, depth shading, per-frame dist.gather over the nccl (= RCCL) backend, rank-0
+scatter -- with ONE rank, so that the RCCL calls themselves run on a single-GPU box.  Prints one JSON line."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from snail_amd import FPSCamera, HostBVH, scenes
+from snail_amd.render import DistributedRenderer
+from snail_amd.scene import Scene
+from tests import oracle_lib as O
+
+
+def main():
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    name, resx, resy = "atrium:0.05", 640, 368
+    tv = scenes.scene_by_name(name)
+    h = HostBVH.build(tv)
+    cam = FPSCamera(*scenes.atrium_camera()).camera()
+    sc = Scene(h, 0)
+    osc = O.OracleScene(tv)
+    t_ref = osc.render_primary(cam.as_array13(), resx, resy, mode=O.MODE_IEEE)
+    out = {}
+    for payload in ("rgb8", "hits"):
+        rnd = DistributedRenderer(sc, resx, resy, 0, 1, payload=payload, force_collective=True)
+        for _ in range(7):
+            rnd.render(cam)
+        fr = rnd.flush()
+        dist.barrier()
+        torch.cuda.synchronize()
+        if payload == "rgb8":
+            want = O.shade_depth(t_ref[0]).reshape(resy, resx, 3)
+            out["rgb8_equal"] = bool(np.array_equal(fr.cpu().numpy(), want))
+        else:
+            out["hits_equal"] = bool(np.array_equal(fr.t.cpu().numpy().view(np.uint32), t_ref[0].view(np.uint32)) and np.array_equal(fr.tri_id.cpu().numpy(), t_ref[3]))
+        t0 = time.perf_counter()
+        for _ in range(30):
+            rnd.render(cam)
+        rnd.flush()
+        torch.cuda.synchronize()
+        out[payload + "_ms_per_frame"] = round((time.perf_counter() - t0) / 30 * 1e3, 4)
+    dist.destroy_process_group()
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -412,6 +412,22 @@ def test_two_rank_bench_rehearsal(torch_mod):
     assert d["config"]["hit_fraction"] > 0.5
 
 
+def test_rccl_code_path_single_rank(torch_mod):
+    """The same route with the nccl (= RCCL) backend and ONE rank (tests/nccl_single_rank.py, a child process): process-group
+    initialisation on the device, the asynchronous dist.gather into per-rank views of one receive buffer, work.wait() on the slot's
+    stream, barrier -- the calls the 2/4/8-GPU bench makes -- with results checked against the oracle for both payloads."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "nccl_single_rank.py")], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["rgb8_equal"] and d["hits_equal"], d
+
+
 @pytest.mark.parametrize("name,resx,resy,nl,refl", [("atrium:0.05", 640, 368, 2, False), ("atrium:0.05", 250, 130, 1, False), ("box", 256, 256, 1, False),
                                                      ("stress:0.05", 320, 192, 3, False), ("atrium:0.05", 320, 192, 0, False),
                                                      ("atrium:0.05", 640, 368, 2, True), ("atrium:0.05", 250, 130, 0, True), ("box", 256, 256, 1, True),
