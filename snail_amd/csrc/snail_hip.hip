@@ -378,6 +378,41 @@ __device__ __forceinline__ bool leafShared(const uint4 *__restrict__ tris, int c
 	return false;
 }
 
+// ---- leaf, per-ray origins (src/triangle.cpp:30-38; no packet-level triangle cull: src/bvh/traverse.cpp:44): wave-uniform
+// scalar triangle fetch, every lane does the full Collide arithmetic for its 4 rays
+template <bool MASK, int M, bool BARY>
+__device__ __forceinline__ void leafPerRay(const uint4 *__restrict__ tris, int count, int firstTri, int lane, int first, int last, const float (&org)[3][4],
+										   Quad &Q, unsigned mask4, int (&tid)[4], float (&bu)[4], float (&bv)[4], Counters &st) {
+	const bool inRange = lane >= first && lane <= last;
+	const int width = last - first + 1;
+	for(int k = 0; k < count; k++) {
+		const Tri t = loadTriScalar(tris, firstTri + k);
+#pragma unroll
+		for(int l = 0; l < 4; l++) {
+			const float det = Q.d[0][l] * t.n[0] + Q.d[1][l] * t.n[1] + Q.d[2][l] * t.n[2];
+			float tv[3] = {org[0][l] - t.a[0], org[1][l] - t.a[1], org[2][l] - t.a[2]};
+			float c0[3] = {t.ba[1] * tv[2] - t.ba[2] * tv[1], t.ba[2] * tv[0] - t.ba[0] * tv[2], t.ba[0] * tv[1] - t.ba[1] * tv[0]};
+			float c1[3] = {tv[1] * t.ca[2] - tv[2] * t.ca[1], tv[2] * t.ca[0] - tv[0] * t.ca[2], tv[0] * t.ca[1] - tv[1] * t.ca[0]};
+			const float tmul = -(tv[0] * t.n[0] + tv[1] * t.n[1] + tv[2] * t.n[2]);
+			const float v = (Q.d[0][l] * c0[0] + Q.d[1][l] * c0[1] + Q.d[2][l] * c0[2]) * t.it0;
+			const float u = (Q.d[0][l] * c1[0] + Q.d[1][l] * c1[1] + Q.d[2][l] * c1[2]) * t.it0;
+			const float duv = det - u - v;
+			const float uvmin = Min3<M>(u, v, duv), uvmax = Max3<M>(u, v, duv);
+			bool test = ((uvmax <= 0.0f) | (uvmin >= 0.0f)) & inRange;
+			if(MASK) test = test & (((mask4 >> l) & 1u) != 0);
+			if(test) {
+				const float idet = 1.0f / det;
+				const float dd = idet * tmul;
+				if(dd < Q.dist[l] && dd > 0.0f) {
+					Q.dist[l] = dd; tid[l] = firstTri + k;
+					if(BARY) { bu[l] = u * idet; bv[l] = v * idet; }
+				}
+			}
+		}
+		st.intersects += width;
+	}
+}
+
 // ---- the packet walk -------------------------------------------------------------------------------
 // SHARED : one origin per packet (primary / shadow)   MASK : per-lane 4-bit masks (secondary rays)
 // SHADOW : any-hit TraverseShadow                      M    : arithmetic mode (above)
@@ -545,39 +580,10 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 			}
 		// ---- leaf (src/bvh/traverse.cpp:34-56 / :98-124) ----
 		const int count = n.aux, firstTri = (int)(n.sub & 0x7fffffffu);
-		const bool inRange = lane >= first && lane <= last;
-		const int width = last - first + 1;
-
 		if(SHARED) {
 			if(leafShared<MASK, SHADOW, M, BARY>(tris, count, firstTri, size, lane, first, last, org, Q, mask4, tid, bu, bv, iv, st)) return;
 		} else {
-			// per-ray origins (reflection / transparency packets, src/triangle.cpp:30-38): wave-uniform scalar triangle fetch
-			for(int k = 0; k < count; k++) {
-				const Tri t = loadTriScalar(tris, firstTri + k);
-#pragma unroll
-				for(int l = 0; l < 4; l++) {
-					const float det = Q.d[0][l] * t.n[0] + Q.d[1][l] * t.n[1] + Q.d[2][l] * t.n[2];
-					float tv[3] = {org[0][l] - t.a[0], org[1][l] - t.a[1], org[2][l] - t.a[2]};
-					float c0[3] = {t.ba[1] * tv[2] - t.ba[2] * tv[1], t.ba[2] * tv[0] - t.ba[0] * tv[2], t.ba[0] * tv[1] - t.ba[1] * tv[0]};
-					float c1[3] = {tv[1] * t.ca[2] - tv[2] * t.ca[1], tv[2] * t.ca[0] - tv[0] * t.ca[2], tv[0] * t.ca[1] - tv[1] * t.ca[0]};
-					const float tmul = -(tv[0] * t.n[0] + tv[1] * t.n[1] + tv[2] * t.n[2]);
-					const float v = (Q.d[0][l] * c0[0] + Q.d[1][l] * c0[1] + Q.d[2][l] * c0[2]) * t.it0;
-					const float u = (Q.d[0][l] * c1[0] + Q.d[1][l] * c1[1] + Q.d[2][l] * c1[2]) * t.it0;
-					const float duv = det - u - v;
-					const float uvmin = Min3<M>(u, v, duv), uvmax = Max3<M>(u, v, duv);
-					bool test = ((uvmax <= 0.0f) | (uvmin >= 0.0f)) & inRange;
-					if(MASK) test = test & (((mask4 >> l) & 1u) != 0);
-					if(test) {
-						const float idet = 1.0f / det;
-						const float dd = idet * tmul;
-						if(dd < Q.dist[l] && dd > 0.0f) {
-							Q.dist[l] = dd; tid[l] = firstTri + k;
-							if(BARY) { bu[l] = u * idet; bv[l] = v * idet; }
-						}
-					}
-				}
-				st.intersects += width;
-			}
+			leafPerRay<MASK, M, BARY>(tris, count, firstTri, lane, first, last, org, Q, mask4, tid, bu, bv, st);
 		}
 		} // alive != 0
 		// ---- pop (src/bvh/traverse.cpp:26-30) ----
@@ -610,21 +616,45 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 #define SNAIL_EXP_PAD "" // experiment hook: extra instructions per node visit (tools/exp_pad.sh)
 #endif
 // slab products of ray L -> tn in t0, tf in t3.  COH: near/far planes known (pn*, pf*); FAST: planes bmin-o / bmax-o, min/max per axis
-#define SNAIL_SLAB_COH(L)                                                                                                                  \
+#define SNAIL_SLAB_COH(L, NX, FX, NY, FY, NZ, FZ)                                                                                           \
 	"v_mul_f32 %[t0], %[ix" L "], %[pnx]\n v_mul_f32 %[t1], %[iy" L "], %[pny]\n v_mul_f32 %[t2], %[iz" L "], %[pnz]\n"                    \
 	"v_mul_f32 %[t3], %[ix" L "], %[pfx]\n v_mul_f32 %[t4], %[iy" L "], %[pfy]\n v_mul_f32 %[t5], %[iz" L "], %[pfz]\n"                    \
 	"v_max3_f32 %[t0], %[t0], %[t1], %[t2]\n v_min3_f32 %[t3], %[t3], %[t4], %[t5]\n"
-#define SNAIL_SLAB_FAST(L)                                                                                                                 \
+#define SNAIL_SLAB_FAST(L, NX, FX, NY, FY, NZ, FZ)                                                                                          \
 	"v_mul_f32 %[t0], %[ix" L "], %[pnx]\n v_mul_f32 %[t3], %[ix" L "], %[pfx]\n v_min_f32 %[u0], %[t0], %[t3]\n v_max_f32 %[t3], %[t0], %[t3]\n" \
 	"v_mul_f32 %[t1], %[iy" L "], %[pny]\n v_mul_f32 %[t4], %[iy" L "], %[pfy]\n v_min_f32 %[t0], %[t1], %[t4]\n v_max_f32 %[t4], %[t1], %[t4]\n" \
 	"v_mul_f32 %[t2], %[iz" L "], %[pnz]\n v_mul_f32 %[t5], %[iz" L "], %[pfz]\n v_min_f32 %[t1], %[t2], %[t5]\n v_max_f32 %[t5], %[t2], %[t5]\n" \
 	"v_max3_f32 %[t0], %[u0], %[t0], %[t1]\n v_min3_f32 %[t3], %[t3], %[t4], %[t5]\n"
+// per-ray origins (mirrored / transparency packets): the plane offsets are per ray too
+#define SNAIL_SLABO_COH(L, NX, FX, NY, FY, NZ, FZ)                                                                                          \
+	"v_sub_f32 %[t0], " NX ", %[ox" L "]\n v_sub_f32 %[t1], " NY ", %[oy" L "]\n v_sub_f32 %[t2], " NZ ", %[oz" L "]\n"                    \
+	"v_sub_f32 %[t3], " FX ", %[ox" L "]\n v_sub_f32 %[t4], " FY ", %[oy" L "]\n v_sub_f32 %[t5], " FZ ", %[oz" L "]\n"                    \
+	"v_mul_f32 %[t0], %[ix" L "], %[t0]\n v_mul_f32 %[t1], %[iy" L "], %[t1]\n v_mul_f32 %[t2], %[iz" L "], %[t2]\n"                       \
+	"v_mul_f32 %[t3], %[ix" L "], %[t3]\n v_mul_f32 %[t4], %[iy" L "], %[t4]\n v_mul_f32 %[t5], %[iz" L "], %[t5]\n"                       \
+	"v_max3_f32 %[t0], %[t0], %[t1], %[t2]\n v_min3_f32 %[t3], %[t3], %[t4], %[t5]\n"
+#define SNAIL_SLABO_FAST(L, NX, FX, NY, FY, NZ, FZ)                                                                                         \
+	"v_sub_f32 %[t0], " NX ", %[ox" L "]\n v_sub_f32 %[t3], " FX ", %[ox" L "]\n v_mul_f32 %[t0], %[ix" L "], %[t0]\n v_mul_f32 %[t3], %[ix" L "], %[t3]\n" \
+	"v_min_f32 %[u0], %[t0], %[t3]\n v_max_f32 %[t3], %[t0], %[t3]\n"                                                                      \
+	"v_sub_f32 %[t1], " NY ", %[oy" L "]\n v_sub_f32 %[t4], " FY ", %[oy" L "]\n v_mul_f32 %[t1], %[iy" L "], %[t1]\n v_mul_f32 %[t4], %[iy" L "], %[t4]\n" \
+	"v_min_f32 %[t0], %[t1], %[t4]\n v_max_f32 %[t4], %[t1], %[t4]\n"                                                                      \
+	"v_sub_f32 %[t2], " NZ ", %[oz" L "]\n v_sub_f32 %[t5], " FZ ", %[oz" L "]\n v_mul_f32 %[t2], %[iz" L "], %[t2]\n v_mul_f32 %[t5], %[iz" L "], %[t5]\n" \
+	"v_min_f32 %[t1], %[t2], %[t5]\n v_max_f32 %[t5], %[t2], %[t5]\n"                                                                      \
+	"v_max3_f32 %[t0], %[u0], %[t0], %[t1]\n v_min3_f32 %[t3], %[t3], %[t4], %[t5]\n"
+// shared origin: the six plane offsets once per node, ahead of the rays; origin operands of the asm statement
+#define SNAIL_PRE_SHARED(NX, FX, NY, FY, NZ, FZ)                                                                                            \
+	" v_sub_f32 %[pnx], " NX ", %[ox]\n v_sub_f32 %[pny], " NY ", %[oy]\n v_sub_f32 %[pnz], " NZ ", %[oz]\n"                               \
+	" v_sub_f32 %[pfx], " FX ", %[ox]\n v_sub_f32 %[pfy], " FY ", %[oy]\n v_sub_f32 %[pfz], " FZ ", %[oz]\n"
+#define SNAIL_PRE_NONE(NX, FX, NY, FY, NZ, FZ) ""
+#define SNAIL_ORG_SHARED() [ox] "v"(org[0][0]), [oy] "v"(org[1][0]), [oz] "v"(org[2][0])
+#define SNAIL_ORG_PERRAY()                                                                                                                 \
+	[ox0] "v"(org[0][0]), [ox1] "v"(org[0][1]), [ox2] "v"(org[0][2]), [ox3] "v"(org[0][3]), [oy0] "v"(org[1][0]), [oy1] "v"(org[1][1]),     \
+		[oy2] "v"(org[1][2]), [oy3] "v"(org[1][3]), [oz0] "v"(org[2][0]), [oz1] "v"(org[2][1]), [oz2] "v"(org[2][2]), [oz3] "v"(org[2][3])
 // the ray's slack -> S.  POS: distances >= 0 (primary): min(tf,dist) - max(tn,0);  ANY: any distance, -inf = masked (shadow):
 // min(min(tf,dist) - tn, tf)
 #define SNAIL_TAIL_POS(L, S) "v_max_f32 %[t0], 0, %[t0]\n v_min_f32 %[t3], %[t3], %[d" L "]\n v_sub_f32 %[" S "], %[t3], %[t0]\n"
 #define SNAIL_TAIL_ANY(L, S) "v_min_f32 %[t4], %[t3], %[d" L "]\n v_sub_f32 %[t4], %[t4], %[t0]\n v_min_f32 %[" S "], %[t4], %[t3]\n"
 #define SNAIL_COUNT " s_add_u32 %[cnt], %[cnt], 1\n"
-#define SNAIL_DESCEND_ASM(SLAB, TAIL, CNTPOP, CNTVISIT, NX, FX, NY, FY, NZ, FZ)                                                            \
+#define SNAIL_DESCEND_ASM(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, NX, FX, NY, FY, NZ, FZ)                                                            \
 	asm volatile("L_pop_%=:\n"                                                                                                             \
 				 " s_cmp_eq_u32 %[sp], 0\n s_cbranch_scc1 L_done_%=\n"                                                                     \
 				 " s_sub_u32 %[sp], %[sp], 1\n" CNTPOP                                                                                     \
@@ -633,9 +663,9 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 " s_and_b32 %[first], %[fl], 0xff\n s_lshr_b32 %[last], %[fl], 8\n s_sub_u32 %[width], %[last], %[first]\n"               \
 				 " s_waitcnt lgkmcnt(0)\n"                                                                                                 \
 				 "L_visit_%=:\n" CNTVISIT                                                                                                  \
-				 " v_sub_f32 %[pnx], " NX ", %[ox]\n v_sub_f32 %[pny], " NY ", %[oy]\n v_sub_f32 %[pnz], " NZ ", %[oz]\n"                  \
-				 " v_sub_f32 %[pfx], " FX ", %[ox]\n v_sub_f32 %[pfy], " FY ", %[oy]\n v_sub_f32 %[pfz], " FZ ", %[oz]\n"                  \
-				 SLAB("0") TAIL("0", "s0") SLAB("1") TAIL("1", "s1") SLAB("2") TAIL("2", "s2") SLAB("3") TAIL("3", "s3")                   \
+				 PRE(NX, FX, NY, FY, NZ, FZ)                                                                                               \
+				 SLAB("0", NX, FX, NY, FY, NZ, FZ) TAIL("0", "s0") SLAB("1", NX, FX, NY, FY, NZ, FZ) TAIL("1", "s1")                       \
+				 SLAB("2", NX, FX, NY, FY, NZ, FZ) TAIL("2", "s2") SLAB("3", NX, FX, NY, FY, NZ, FZ) TAIL("3", "s3")                       \
 				 " v_max_f32 %[s2], %[s2], %[s3]\n v_max3_f32 %[s0], %[s0], %[s1], %[s2]\n"                                                \
 				 SNAIL_EXP_PAD                                                                                                             \
 				 " v_cmp_le_f32 vcc, 0, %[s0]\n"                                                                                           \
@@ -661,8 +691,7 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				   [pnz] "=&v"(vt[2]), [pfx] "=&v"(vt[3]), [pfy] "=&v"(vt[4]), [pfz] "=&v"(vt[5]), [t0] "=&v"(vt[6]), [t1] "=&v"(vt[7]),   \
 				   [t2] "=&v"(vt[8]), [t3] "=&v"(vt[9]), [t4] "=&v"(vt[10]), [t5] "=&v"(vt[11]), [s0] "=&v"(vt[12]), [s1] "=&v"(vt[13]),   \
 				   [s2] "=&v"(vt[14]), [s3] "=&v"(vt[15]), [u0] "=&v"(vt[16])                                                              \
-				 : [base] "s"(nodeBase), [sign16] "s"(sign16), [lane] "v"(lane), [ox] "v"(org[0][0]), [oy] "v"(org[1][0]),                 \
-				   [oz] "v"(org[2][0]), [ix0] "v"(Q.id[0][0]), [ix1] "v"(Q.id[0][1]), [ix2] "v"(Q.id[0][2]), [ix3] "v"(Q.id[0][3]),        \
+				 : [base] "s"(nodeBase), [sign16] "s"(sign16), [lane] "v"(lane), ORGOPS(), [ix0] "v"(Q.id[0][0]), [ix1] "v"(Q.id[0][1]), [ix2] "v"(Q.id[0][2]), [ix3] "v"(Q.id[0][3]),        \
 				   [iy0] "v"(Q.id[1][0]), [iy1] "v"(Q.id[1][1]), [iy2] "v"(Q.id[1][2]), [iy3] "v"(Q.id[1][3]), [iz0] "v"(Q.id[2][0]),      \
 				   [iz1] "v"(Q.id[2][1]), [iz2] "v"(Q.id[2][2]), [iz3] "v"(Q.id[2][3]), [d0] "v"(Q.dist[0]), [d1] "v"(Q.dist[1]),          \
 				   [d2] "v"(Q.dist[2]), [d3] "v"(Q.dist[3])                                                                                \
@@ -674,16 +703,16 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 "s"(sWidth), "s"(sRng), "s"(sAlive), "v"(vt[0]), "v"(vt[1]), "v"(vt[2]), "v"(vt[3]), "v"(vt[4]), "v"(vt[5]), "v"(vt[6]), "v"(vt[7]), \
 				 "v"(vt[8]), "v"(vt[9]), "v"(vt[10]), "v"(vt[11]), "v"(vt[12]), "v"(vt[13]), "v"(vt[14]), "v"(vt[15]), "v"(vt[16]))
 // near/far plane registers by sign octant (bit k set = idir negative on axis k: near plane = bmax[k]); s[84:86] = bmin, s[87:89] = bmax
-#define SNAIL_DESCEND_OCT(SLAB, TAIL, CNTPOP, CNTVISIT, OCT)                                                                               \
+#define SNAIL_DESCEND_OCT(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, OCT)                                                                               \
 	switch(OCT) {                                                                                                                          \
-	case 0: SNAIL_DESCEND_ASM(SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s85", "s88", "s86", "s89"); break;                              \
-	case 1: SNAIL_DESCEND_ASM(SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s85", "s88", "s86", "s89"); break;                              \
-	case 2: SNAIL_DESCEND_ASM(SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s88", "s85", "s86", "s89"); break;                              \
-	case 3: SNAIL_DESCEND_ASM(SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s88", "s85", "s86", "s89"); break;                              \
-	case 4: SNAIL_DESCEND_ASM(SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s85", "s88", "s89", "s86"); break;                              \
-	case 5: SNAIL_DESCEND_ASM(SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s85", "s88", "s89", "s86"); break;                              \
-	case 6: SNAIL_DESCEND_ASM(SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s88", "s85", "s89", "s86"); break;                              \
-	default: SNAIL_DESCEND_ASM(SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s88", "s85", "s89", "s86"); break;                             \
+	case 0: SNAIL_DESCEND_ASM(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s85", "s88", "s86", "s89"); break;                              \
+	case 1: SNAIL_DESCEND_ASM(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s85", "s88", "s86", "s89"); break;                              \
+	case 2: SNAIL_DESCEND_ASM(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s88", "s85", "s86", "s89"); break;                              \
+	case 3: SNAIL_DESCEND_ASM(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s88", "s85", "s86", "s89"); break;                              \
+	case 4: SNAIL_DESCEND_ASM(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s85", "s88", "s89", "s86"); break;                              \
+	case 5: SNAIL_DESCEND_ASM(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s85", "s88", "s89", "s86"); break;                              \
+	case 6: SNAIL_DESCEND_ASM(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s88", "s85", "s89", "s86"); break;                              \
+	default: SNAIL_DESCEND_ASM(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s88", "s85", "s89", "s86"); break;                             \
 	}
 
 // SHADOW=false: closest hit of a primary packet (distances >= 0; visits = 2 * pops - 1: every chain of visits starts with a pop,
@@ -713,11 +742,11 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes, c
 		u64 sRng, sAlive;
 		float vt[17];
 		if(COH) {
-			if(SHADOW) { SNAIL_DESCEND_OCT(SNAIL_SLAB_COH, SNAIL_TAIL_ANY, "", SNAIL_COUNT, oct) }
-			else { SNAIL_DESCEND_OCT(SNAIL_SLAB_COH, SNAIL_TAIL_POS, SNAIL_COUNT, "", oct) }
+			if(SHADOW) { SNAIL_DESCEND_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_ANY, "", SNAIL_COUNT, oct) }
+			else { SNAIL_DESCEND_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_POS, SNAIL_COUNT, "", oct) }
 		} else {
-			if(SHADOW) { SNAIL_DESCEND_ASM(SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, "", SNAIL_COUNT, "s84", "s87", "s85", "s88", "s86", "s89"); }
-			else { SNAIL_DESCEND_ASM(SNAIL_SLAB_FAST, SNAIL_TAIL_POS, SNAIL_COUNT, "", "s84", "s87", "s85", "s88", "s86", "s89"); }
+			if(SHADOW) { SNAIL_DESCEND_ASM(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, "", SNAIL_COUNT, "s84", "s87", "s85", "s88", "s86", "s89"); }
+			else { SNAIL_DESCEND_ASM(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_POS, SNAIL_COUNT, "", "s84", "s87", "s85", "s88", "s86", "s89"); }
 		}
 		if(leafSub == 0) break;
 		if(leafShared<false, SHADOW, COH ? M_COH : M_FAST, false>(tris, leafAux, (int)((unsigned)leafSub & 0x7fffffffu), 64, lane, first, last, org, Q, 15u,
@@ -725,6 +754,28 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes, c
 			break;
 	}
 	st.iters += SHADOW ? (unsigned)cnt : 2u * (unsigned)cnt - 1u;
+}
+
+// closest hit of a packet with per-ray origins (TraversePrimaryN<0,mask>), node loop in assembly as in walkSharedAsm; any
+// distance on entry (masked lanes -inf), `size` quads
+template <bool MASK, bool COH, bool BARY>
+__device__ __forceinline__ void walkPerRayAsm(const uint4 *__restrict__ nodes, const uint4 *__restrict__ tris, int size, int lane, const float (&org)[3][4],
+											  Quad &Q, unsigned mask4, int (&tid)[4], float (&bu)[4], float (&bv)[4], Counters &st, const int oct) {
+	const int signBits = __builtin_amdgcn_readfirstlane((Q.d[0][0] < 0.0f ? 1 : 0) | (Q.d[1][0] < 0.0f ? 2 : 0) | (Q.d[2][0] < 0.0f ? 4 : 0));
+	const int sign16 = signBits << 16;
+	const u64 nodeBase = (u64)nodes;
+	int stkN = 0, stkF = (size - 1) << 8; // slot 0 = the root with the full quad range
+	int sp = 1, first = 0, last = size - 1, cnt = 0;
+	for(;;) {
+		int leafSub, leafAux, sCur, sFl, sOff, sWidth;
+		u64 sRng, sAlive;
+		float vt[17];
+		if(COH) { SNAIL_DESCEND_OCT(SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_COH, SNAIL_TAIL_ANY, SNAIL_COUNT, "", oct) }
+		else { SNAIL_DESCEND_ASM(SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, "", "s84", "s87", "s85", "s88", "s86", "s89"); }
+		if(leafSub == 0) break;
+		leafPerRay<MASK, COH ? M_COH : M_FAST, BARY>(tris, leafAux, (int)((unsigned)leafSub & 0x7fffffffu), lane, first, last, org, Q, mask4, tid, bu, bv, st);
+	}
+	st.iters += 2u * (unsigned)cnt - 1u;
 }
 
 // barycentrics of the final hits, derived after the walk (primary kernel): the same operations on the same
@@ -1381,7 +1432,10 @@ __device__ __forceinline__ void raysPacket(const RaysArgs &A, const int p, float
 			if(lane == 0) A.defer[16 + atomicAdd(&A.defer[0], 1)] = p;
 			return;
 		}
-		if(mode == M_COH) walk<SHARED, MASK, false, M_COH, BARY, DEEP, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, lds, st, oct);
+		if(!SHARED && !DEEP) { // per-ray origins: the hand-written node loop
+			if(mode == M_COH) walkPerRayAsm<MASK, true, BARY>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, st, oct);
+			else walkPerRayAsm<MASK, false, BARY>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, st, 0);
+		} else if(mode == M_COH) walk<SHARED, MASK, false, M_COH, BARY, DEEP, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, lds, st, oct);
 		else walk<SHARED, MASK, false, M_FAST, BARY, DEEP, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, lds, st);
 	}
 	flushStats(A.stats, st, 0u, lane);

@@ -22,9 +22,10 @@ s = st.cpu().numpy()
 print("stats {intersects, iters, rays, skips}:", s.tolist()); print("rays traced per frame:", int(s[2]), "(primary 2088960 + %s %d)" % ("mirrored+shadow" if refl else "shadow", int(s[2]) - 2088960), "skips", int(s[3]))
 for i in range(24): sc.render_whitted(cam, resx, resy, lights, reflections=refl)   # every scratch slot of the scene handle allocated
 torch.cuda.synchronize()
-streams = [torch.cuda.Stream() for _ in range(3)]
-outs = [torch.zeros_like(out) for _ in range(3)]
-for ns in (1, 1, 1, 3, 3, 3):   # the first round after a change of concurrency is a transient (queues, clocks)
+NS = int(os.environ.get("NS", "3"))
+streams = [torch.cuda.Stream() for _ in range(NS)]
+outs = [torch.zeros_like(out) for _ in range(NS)]
+for ns in (1, 1, 1, NS, NS, NS):   # the first round after a change of concurrency is a transient (queues, clocks)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
