@@ -56,6 +56,15 @@ int snail_bvh_build(void *tris64, int nTris, void *nodes32, int *nNodes, int *de
  * reference ships to a render node in SendBVH (src/server.cpp:144-164).  Copies to `device`. */
 SnailScene *snail_scene_create(const void *nodes32, int nNodes, const void *tris64, int nTris, int depth, int device);
 void snail_scene_destroy(SnailScene *);
+/* GPU tree builder option (NOT the parity tree, reported separately): a linear BVH -- Morton order of the
+ * triangle-box centres, one device radix sort, Karras' binary radix tree, bottom-up refit, subtrees of <= maxLeafTris (1..64)
+ * triangles collapsed into leaves -- in the reference's node / triangle record formats, built and kept on `device`; the traversal
+ * entry points below work on it unchanged.  Triangle order (triId) and tree shape differ from BVH::Construct: hit distances agree
+ * with the SAH tree's except where the reference's order-dependent packet culls differ; perm (optional, nTris) maps triId ->
+ * input triangle; *build_ms (optional) = device time of the build.  tri_verts: host, nTris x (v0,v1,v2). */
+SnailScene *snail_scene_create_lbvh(const float *tri_verts, int nTris, int device, int maxLeafTris, int32_t *perm, float *build_ms);
+/* Copy a scene's node (nNodes x 32 B) and / or triangle (nTris x 64 B) records back to the host (either may be NULL). */
+int snail_scene_download(const SnailScene *, void *nodes32, void *tris64);
 int snail_scene_info(const SnailScene *, int *nNodes, int *nTris, int *depth, int *device);
 
 /* ---- primary packets: RayGenerator + SafeInv + TraversePrimary<1,0> ----------------------------- */

@@ -1928,6 +1928,8 @@ void launchLights(const SnailScene *s, const dev::ShadeArgs &A, hipStream_t stre
 
 } // namespace
 
+#include "lbvh.inc"
+
 extern "C" {
 
 const char *snail_last_error(void) { return g_err; }
@@ -1981,6 +1983,37 @@ SnailScene *snail_scene_create(const void *nodes32, int nNodes, const void *tris
 		return nullptr;
 	}
 	return s;
+}
+
+SnailScene *snail_scene_create_lbvh(const float *tri_verts, int nTris, int device, int maxLeafTris, int32_t *perm, float *build_ms) {
+	if(!tri_verts || nTris <= 0 || maxLeafTris < 1 || maxLeafTris > 64) { snail_set_error("snail_scene_create_lbvh: bad arguments (1 <= maxLeafTris <= 64)"); return nullptr; }
+	DeviceGuard guard(device);
+	if(!guard.ok) { snail_set_error("snail_scene_create_lbvh: hipSetDevice(%d) failed", device); return nullptr; }
+	uint4 *dNodes = nullptr, *dTris = nullptr;
+	int depth = 0, fastOK = 0;
+	if(buildLbvhDevice(tri_verts, nTris, maxLeafTris, &dNodes, &dTris, perm, &depth, &fastOK, build_ms)) return nullptr;
+	if(depth > SNAIL_MAX_DEPTH) {
+		(void)hipFree(dNodes); (void)hipFree(dTris);
+		snail_set_error("snail_scene_create_lbvh: depth %d exceeds BVH::maxDepth %d", depth, SNAIL_MAX_DEPTH);
+		return nullptr;
+	}
+	SnailScene *s = new SnailScene();
+	s->device = device; s->nNodes = 2 * nTris - 1; s->nTris = nTris; s->depth = depth; s->fastOK = fastOK;
+	s->dNodes = dNodes; s->dTris = dTris;
+	if(hipMalloc((void **)&s->dStats, 4 * sizeof(unsigned long long)) != hipSuccess) {
+		snail_set_error("snail_scene_create_lbvh: device allocation failed");
+		snail_scene_destroy(s);
+		return nullptr;
+	}
+	return s;
+}
+
+int snail_scene_download(const SnailScene *s, void *nodes32, void *tris64) {
+	if(int rc = checkScene(s, "snail_scene_download")) return rc;
+	DeviceGuard guard(s->device);
+	if(nodes32) HIP_TRY(hipMemcpy(nodes32, s->dNodes, (size_t)s->nNodes * 32, hipMemcpyDeviceToHost));
+	if(tris64) HIP_TRY(hipMemcpy(tris64, s->dTris, (size_t)s->nTris * 64, hipMemcpyDeviceToHost));
+	return 0;
 }
 
 void snail_scene_destroy(SnailScene *s) {

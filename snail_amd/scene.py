@@ -99,6 +99,33 @@ class Scene:
             raise _lib.SnailError("snail_scene_create: %s" % _lib.lib().snail_last_error().decode())
         self._h = C.c_void_p(h)
 
+    @classmethod
+    def from_lbvh(cls, tri_verts: np.ndarray, device: int | None = None, max_leaf_tris: int = 4):
+        """GPU builder option (NOT the parity tree): a linear BVH built and kept on the device
+        (snail_scene_create_lbvh).  The returned scene carries .perm (triId -> input triangle), .build_ms (device time of the
+        build) and a HostBVH downloaded from the device in .bvh (nodes incl. unused slots, tris in tree order)."""
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise _lib.SnailError("no HIP device available: the traversal path has no CPU fallback")
+        self = cls.__new__(cls)
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        tv = np.ascontiguousarray(tri_verts, dtype=np.float32).reshape(-1, 9)
+        perm = np.zeros(len(tv), dtype=np.int32)
+        ms = C.c_float(0.0)
+        h = _lib.lib().snail_scene_create_lbvh(_lib.ptr(tv), len(tv), self.device, int(max_leaf_tris), _lib.ptr(perm), C.addressof(ms))
+        if not h:
+            raise _lib.SnailError("snail_scene_create_lbvh: %s" % _lib.lib().snail_last_error().decode())
+        self._h = C.c_void_p(h)
+        self.perm, self.build_ms = perm, float(ms.value)
+        nn, nt, depth, dev = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        _lib.check(_lib.lib().snail_scene_info(self._h, C.addressof(nn), C.addressof(nt), C.addressof(depth), C.addressof(dev)), "snail_scene_info")
+        from .bvh import NODE_DTYPE, TRI_DTYPE
+        nodes = np.zeros(nn.value, dtype=NODE_DTYPE)
+        tris = np.zeros(nt.value, dtype=TRI_DTYPE)
+        _lib.check(_lib.lib().snail_scene_download(self._h, _lib.ptr(nodes), _lib.ptr(tris)), "snail_scene_download")
+        self.bvh = HostBVH(tris, nodes, depth.value, perm)
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
             _lib.lib().snail_scene_destroy(self._h)

@@ -579,3 +579,68 @@ def test_every_sign_octant_and_walk_variant(torch_mod):
             assert np.array_equal(stats.cpu().numpy().astype(np.uint64), wst), (yaw, pitch)
     assert seen_primary == set(range(8)) and seen_mixed > 0, (seen_primary, seen_mixed)
     sc.close()
+
+
+@pytest.mark.parametrize("name,max_leaf", [("atrium:0.05", 4), ("box", 1), ("stress:0.05", 8), ("chain", 4)])
+def test_gpu_lbvh_builder_option(torch_mod, name, max_leaf):
+    """The GPU builder option (snail_scene_create_lbvh; not the parity tree): (1) the tree is a valid BVH in the reference's record
+    formats -- children adjacent and inside their parent, the leaves partition the triangle array, triangle records bit-identical to
+    Triangle::ComputeData of the permuted input; (2) the traversal kernels on THAT tree equal the oracle's walk of the same tree bit
+    for bit (hit records and counters); (3) the picture agrees with the SAH tree's: same distances except where the reference's
+    order-dependent packet culls differ, same input triangle wherever the distance is the same."""
+    from snail_amd import HostBVH
+    from snail_amd.scene import Scene
+    tv, sc_sah, osc = gpu_scene(name)
+    cam = util.camera_for(name, tv)
+    sc = Scene.from_lbvh(tv, 0, max_leaf_tris=max_leaf)
+    n = len(tv)
+    nodes, tris, perm = sc.bvh.nodes, sc.bvh.tris, sc.perm
+    assert sorted(perm.tolist()) == list(range(n)) and len(nodes) == 2 * n - 1
+    want_tris = HostBVH.triangles(np.asarray(tv, dtype=np.float32).reshape(-1, 3, 3)[perm])
+    for f in ("a", "ba", "ca", "t0", "it0", "plane"):
+        util.assert_bit_equal(tris[f], want_tris[f], "triangle record field " + f)
+    # (1) topology
+    covered = np.zeros(n, dtype=np.int32)
+    stack, max_depth, n_leaves = [(0, 0)], 0, 0
+    while stack:
+        i, d = stack.pop()
+        nd = nodes[i]
+        if nd["sub"] & 0x80000000:
+            first, count = int(nd["sub"] & 0x7fffffff), int(nd["aux"])
+            assert 1 <= count <= max_leaf and first + count <= n
+            covered[first:first + count] += 1
+            tb = np.asarray(tv, dtype=np.float32).reshape(-1, 3, 3)[perm[first:first + count]].reshape(-1, 3)
+            assert (tb.min(axis=0) >= nd["bmin"]).all() and (tb.max(axis=0) <= nd["bmax"]).all()
+            max_depth = max(max_depth, d); n_leaves += 1
+        else:
+            c = int(nd["sub"])
+            assert 0 < c and c + 1 < len(nodes) and (nd["aux"] & 0xffff) <= 2 and (nd["aux"] >> 16) <= 1
+            for k in (0, 1):
+                assert (nodes[c + k]["bmin"] >= nd["bmin"]).all() and (nodes[c + k]["bmax"] <= nd["bmax"]).all()
+                stack.append((c + k, d + 1))
+    assert (covered == 1).all() and max_depth == sc.bvh.depth
+    # (2) the oracle walks the same tree
+    osc2 = O.OracleScene.__new__(O.OracleScene)
+    osc2.tris = np.ascontiguousarray(tris.view(O.TRI_DTYPE)); osc2.nodes = np.ascontiguousarray(nodes.view(O.NODE_DTYPE)); osc2.depth = sc.bvh.depth; osc2.perm = perm
+    resx, resy = 320, 192
+    want = osc2.render_primary(cam.as_array13(), resx, resy, mode=O.MODE_IEEE)
+    stats = sc.new_stats()
+    fr = sc.trace_primary(cam, resx, resy, stats=stats)
+    torch_mod.cuda.synchronize()
+    for got, w, nm in zip((fr.t, fr.u, fr.v, fr.tri_id), want[:4], "t u v id".split()):
+        util.assert_bit_equal(got.cpu().numpy(), w, "lbvh " + nm)
+    assert np.array_equal(stats.cpu().numpy().astype(np.uint64), want[4])
+    # (3) against the SAH tree
+    fs = sc_sah.trace_primary(cam, resx, resy)
+    torch_mod.cuda.synchronize()
+    t1, t2 = fr.t.cpu().numpy(), fs.t.cpu().numpy()
+    same_t = t1.view(np.uint32) == t2.view(np.uint32)
+    assert same_t.mean() > 0.995, same_t.mean()
+    assert (np.isfinite(t1) == np.isfinite(t2)).mean() > 0.999
+    hit = same_t & np.isfinite(t1)
+    src1 = perm[fr.tri_id.cpu().numpy()[hit]]
+    src2 = sc_sah.bvh.perm[fs.tri_id.cpu().numpy()[hit]]
+    assert (src1 == src2).mean() > 0.995
+    assert sc.build_ms > 0.0
+    sc.close()
+    sc_sah.close()
