@@ -167,6 +167,10 @@ int snail_render_whitted_dev(SnailScene *, const float cam[13], int resx, int re
  * B_alg(ray) = 32*V_n + 64*V_t + 16. */
 int snail_account_primary(SnailScene *, const float cam[13], int resx, int resy, int x0, int y0, int w, int h, uint64_t out[4]);
 
+/* Diagnostic: time per launch of an EMPTY kernel of `blocks` x `threads` (what the workgroup dispatcher alone sustains), averaged
+ * over `reps` back-to-back launches on the default stream of the current device.  tools/dispatch_rate.py. */
+int snail_debug_dispatch_rate(int blocks, int threads, int reps, float *ms_per_launch);
+
 /* Diagnostic: per-packet cost of one full-frame primary launch, row-major over the packet grid:
  * out4[p*4 + {0,1,2,3}] = {loop iterations, quad x triangle tests, shader-clock cycles of that wavefront,
  * start time >> 6}.  For load-balance studies (tools/packet_costs.py); not on any product path. */

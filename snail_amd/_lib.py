@@ -29,6 +29,7 @@ SIGNATURES = {
     "snail_scene_info": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "snail_scene_create_lbvh": (_VP, [_VP, _I, _I, _I, _VP, _VP]),
     "snail_scene_download": (_I, [_VP, _VP, _VP]),
+    "snail_debug_dispatch_rate": (_I, [_I, _I, _I, _VP]),
     "snail_trace_primary": (_I, [_VP, _F13, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "snail_trace_primary_dev": (_I, [_VP, _F13, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "snail_trace_packets_dev": (_I, [_VP, _F13, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP]),

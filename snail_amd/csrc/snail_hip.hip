@@ -1594,6 +1594,9 @@ __global__ __launch_bounds__(256) void k_planar_to_frame(const int4 *tiles, cons
 	}
 }
 
+// diagnostic: what the workgroup dispatcher alone sustains (tools/dispatch_rate.py)
+__global__ void k_nop(int *sink) { if(sink && threadIdx.x == 0 && blockIdx.x == 0x7fffffff) *sink = 1; }
+
 // ---- single-ray accounting walk: V_n, V_t per ray ----------------------------
 struct AccountArgs {
 	const uint4 *nodes, *tris;
@@ -2275,6 +2278,23 @@ int snail_planar_to_frame_dev(const int32_t *dTiles, const int64_t *dInOffsets, 
 	hipLaunchKernelGGL(dev::k_planar_to_frame, dim3(4, nTiles), dim3(256), 0, (hipStream_t)stream, (const int4 *)dTiles, (const long long *)dInOffsets,
 					   nTiles, planar, frame, pitch, resx, resy);
 	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+int snail_debug_dispatch_rate(int blocks, int threads, int reps, float *ms_per_launch) {
+	if(blocks <= 0 || threads <= 0 || threads > 1024 || reps <= 0 || !ms_per_launch) { snail_set_error("snail_debug_dispatch_rate: bad arguments"); return 1; }
+	hipEvent_t e0, e1;
+	HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+	hipLaunchKernelGGL(dev::k_nop, dim3(blocks), dim3(threads), 0, 0, (int *)nullptr);
+	HIP_TRY(hipDeviceSynchronize());
+	HIP_TRY(hipEventRecord(e0, 0));
+	for(int r = 0; r < reps; r++) hipLaunchKernelGGL(dev::k_nop, dim3(blocks), dim3(threads), 0, 0, (int *)nullptr);
+	HIP_TRY(hipEventRecord(e1, 0));
+	HIP_TRY(hipDeviceSynchronize());
+	float ms = 0.0f;
+	HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	*ms_per_launch = ms / reps;
 	return 0;
 }
 
