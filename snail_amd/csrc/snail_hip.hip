@@ -1754,6 +1754,13 @@ bool originSane(const float *o) {
 	return true;
 }
 
+// depth > 62 needs the second stack register pair (DEEP instantiations).  SNAIL_DEBUG_FORCE_DEEP=1 selects them for any scene
+// (the deep-BVH stack study of BASELINE config 5, tools/quick_time.py)
+bool useDeep(const SnailScene *s) {
+	static const bool force = getenv("SNAIL_DEBUG_FORCE_DEEP") && atoi(getenv("SNAIL_DEBUG_FORCE_DEEP")) != 0;
+	return force || s->depth > 62;
+}
+
 int checkScene(const SnailScene *s, const char *fn) {
 	if(!s || !s->dNodes || !s->dTris) { snail_set_error("%s: invalid scene handle", fn); return 1; }
 	return 0;
@@ -1811,7 +1818,7 @@ int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0
 	static const int dynLds = getenv("SNAIL_DEBUG_DYNLDS") ? atoi(getenv("SNAIL_DEBUG_DYNLDS")) : 0;
 	// a scene with sane records defers (practically) nothing: a handful of blocks suffices; an unsafe scene defers every packet
 	const int exactBlocks = A.fastOK ? (blocks < 8 ? blocks : 8) : (blocks < 2048 ? blocks : 2048);
-	if(s->depth > 62) {
+	if(useDeep(s)) {
 		hipLaunchKernelGGL(dev::k_primary<true>, dim3(blocks), dim3(64), dynLds, stream, A);
 		hipLaunchKernelGGL(dev::k_primary_exact<true>, dim3(exactBlocks), dim3(64), 0, stream, A);
 	} else {
@@ -1859,7 +1866,7 @@ int shadeScratch(SnailScene *s, SnailScene::ShadeScratch &W, size_t packets, siz
 
 template <bool SHARED, bool MASK>
 void launchRaysKernels(const SnailScene *s, const dev::RaysArgs &A, int blocks, int exactBlocks, hipStream_t stream) {
-	const bool deep = s->depth > 62, bary = A.bary != nullptr;
+	const bool deep = useDeep(s), bary = A.bary != nullptr;
 #define SNAIL_RAYS_LAUNCH(D, B)                                                                                                            \
 	do {                                                                                                                                   \
 		hipLaunchKernelGGL((dev::k_rays<SHARED, MASK, D, B>), dim3(blocks), dim3(64), 0, stream, A);                                        \
@@ -1920,7 +1927,7 @@ void launchLights(const SnailScene *s, const dev::ShadeArgs &A, hipStream_t stre
 	const dim3 grid(A.nBlocks, A.nLights);
 	const int total = A.nBlocks * A.nLights;
 	const int exactBlocks = A.fastOK ? (total < 8 ? total : 8) : (total < 2048 ? total : 2048);
-	if(s->depth > 62) {
+	if(useDeep(s)) {
 		hipLaunchKernelGGL((dev::k_light<true, SRC>), grid, dim3(64), 0, stream, A);
 		hipLaunchKernelGGL((dev::k_light_exact<true, SRC>), dim3(exactBlocks), dim3(64), 0, stream, A);
 	} else {
