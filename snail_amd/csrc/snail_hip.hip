@@ -419,13 +419,12 @@ __device__ __forceinline__ void leafPerRay(const uint4 *__restrict__ tris, int c
 // BARY   : keep barycentrics up to date in registers (else the caller derives them from the final triId)
 // DEEP   : scene depth > 62, stack slots >= 64 live in a second VGPR pair
 // DISTPOS: every lane's distance is >= 0 on entry (primary packets) -> single-compare slab test
-// OCT    : M_COH only: the packet's sign octant as a compile-time constant (0..7; bit k = idir negative on axis k), so that
-//          the near/far plane choice costs nothing at run time; -1 = decide per node with a scalar XOR-swap
+// oct    : M_COH only: the packet's sign octant from classify() (bit k = idir negative on axis k)
 // Stack: lane i of (stkNode, stkFL) is slot i.
-template <bool SHARED, bool MASK, bool SHADOW, int M, bool BARY, bool DEEP, bool DISTPOS, int OCT = -1>
+template <bool SHARED, bool MASK, bool SHADOW, int M, bool BARY, bool DEEP, bool DISTPOS>
 __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint4 *__restrict__ tris, int size, int lane,
 									 const float (&org)[3][4] /* SHARED: [c][0] uniform */, Quad &Q, unsigned mask4, int (&tid)[4],
-									 float (&bu)[4], float (&bv)[4], float *lds, Counters &st, const int oct = 0 /* M_COH with OCT < 0: classify()'s octant */) {
+									 float (&bu)[4], float (&bv)[4], float *lds, Counters &st, const int oct = 0) {
 	constexpr bool EXACT = M == M_EXACT;
 	Interval iv;
 	{ // RayInterval ctor (src/ray_group.h:296-333)
@@ -507,13 +506,9 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				float pn[3], pf[3];
 #pragma unroll
 				for(int k = 0; k < 3; k++) {
-					if(OCT >= 0) { // compile-time octant: the scalar unit (one per CU, the scarcest issue resource of this kernel) does nothing
-						pn[k] = ((OCT >> k) & 1) ? n.bmax[k] : n.bmin[k]; pf[k] = ((OCT >> k) & 1) ? n.bmin[k] : n.bmax[k];
-					} else {
-						const int lo = __float_as_int(n.bmin[k]), hi = __float_as_int(n.bmax[k]);
-						const int sw = (lo ^ hi) & octMask[k];
-						pn[k] = __int_as_float(lo ^ sw); pf[k] = __int_as_float(hi ^ sw);
-					}
+					const int lo = __float_as_int(n.bmin[k]), hi = __float_as_int(n.bmax[k]);
+					const int sw = (lo ^ hi) & octMask[k];
+					pn[k] = __int_as_float(lo ^ sw); pf[k] = __int_as_float(hi ^ sw);
 					if(SHARED) { pn[k] = pn[k] - org[k][0]; pf[k] = pf[k] - org[k][0]; }
 				}
 #pragma unroll
@@ -597,13 +592,14 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 	}
 }
 
-// ---- the primary packet walk of the main kernel, node loop in assembly ---------------------------------------------------
-// Same algorithm and the same IEEE operations as walk<true,false,false,M_COH,false,false,true,OCT> (shared origin, no masks,
-// every ray of the packet in sign octant OCT, distances >= 0, tree depth <= 62); only the descend / cull / push / pop loop is
-// written by hand, because the compiler's version of it carries ~25 % register-shuffling (loop-carried copies around the
-// stack VGPRs and the node SGPRs, hazard padding around its inline v_min/v_max): 82 instead of ~103 instructions per inner
-// node, and this kernel's time is its instruction count (profiles/README.md).  One asm statement = "pop, then descend until
-// a leaf survives its box test (-> the C++ leaf code) or the stack is empty".
+// ---- the node loop in assembly -------------------------------------------------------------------------------------------
+// Same algorithm and the same IEEE operations as dev::walk in its M_COH / M_FAST modes for trees of depth <= 62; only the descend /
+// cull / push / pop loop is written by hand, because the compiler's version of it carries register shuffling (loop-carried copies
+// around the stack VGPRs and the node SGPRs, hazard padding around its inline v_min/v_max): 56 VALU + ~24 scalar instructions per
+// inner node of a coherent shared-origin packet, against ~103 for the compiler at the time (profiles/README.md).  One asm statement
+// = "pop, then descend until a leaf survives its box test (-> the C++ leaf code) or the stack is empty".  Variants are assembled
+// from string macros: slab products (coherent: near/far planes by sign octant, one statement per octant; non-coherent: min/max per
+// axis), shared or per-ray origins, the slack formula (distances >= 0, or any distance with -inf = masked), what is counted.
 //   node record  s[84:91] = bmin.xyz, bmax.xyz, sub, aux            stack: lane i of (stkN, stkF) = slot i
 //   slab test    tn = max3_k(id_k * (near_k - o_k)), tf = min3_k(id_k * (far_k - o_k));  lane passes <=> max(tn,0) <= min(tf,dist)
 //                quad passes <=> max_l(min(tf,dist) - max(tn,0)) >= 0   (finite operands, fp32 denormals on: exact sign)
