@@ -102,6 +102,15 @@ def gather_planes(local, rank: int, world: int, group=None, gathered=None):
     return gathered if rank == 0 else None
 
 
+def reduce_stats(stats, rank: int, world: int, group=None):
+    """TreeStats of a frame summed onto rank 0 (src/node.cpp:358-359 MPI_Send of each node's TreeStats, src/server.cpp:406-414):
+    one tiny SUM-reduce of the {intersects, iters, rays, skips} counter vector.  In place; backend-agnostic."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.reduce(stats, dst=0, op=dist.ReduceOp.SUM, group=group)
+    return stats if rank == 0 else None
+
+
 class DistributedRenderer:
     """One process per GPU.  With world_size 1 the frame's hit records are traced directly in frame layout (no
     collective).  With world_size > 1 every rank traces its tiles' packets (hit records stay in its HBM, where a
@@ -219,6 +228,16 @@ class DistributedRenderer:
                 return self.frame_rgb8
             self.pending[slot] = dist.gather(self.bgr[slot], self.gathered[slot] if self.rank == 0 else None, dst=0, group=self.group, async_op=True)
         return self.frame_rgb8
+
+    def reduce_stats(self, stats):
+        """Sum the ranks' TreeStats accumulators (device int64[4], Scene.new_stats()) onto rank 0; call after flush()."""
+        if self.stage_cpu and self.world > 1:
+            host = stats.cpu()
+            out = reduce_stats(host, self.rank, self.world, self.group)
+            if out is not None:
+                stats.copy_(out)
+            return stats if self.rank == 0 else None
+        return reduce_stats(stats, self.rank, self.world, self.group)
 
     def flush(self):
         """Complete every frame still in flight (call after the last render() of a sequence)."""

@@ -59,6 +59,15 @@ def _worker(rank, world, port, resx, resy, q):
         local = torch.from_numpy(np.stack([frame_to_packets(t, xy), frame_to_packets(u, xy), frame_to_packets(v, xy),
                                            frame_to_packets(tid, xy).view(np.float32)], axis=0))
         got = R.gather_planes(local, rank, world)
+        # TreeStats travel as one SUM-reduce (src/node.cpp:358-359): each rank's counters over ITS tiles add up to the frame's
+        mine = np.zeros(4, dtype=np.int64)
+        for x, y, w, h in plan.tiles[plan.owner == rank].tolist():
+            mine += osc.render_primary(cam.as_array13(), resx, resy, rect=(x, y, w, h), mode=O.MODE_IEEE, threads=1)[4].astype(np.int64)
+        total = R.reduce_stats(torch.from_numpy(mine), rank, world)
+        if rank == 0:
+            whole = osc.render_primary(cam.as_array13(), resx, resy, mode=O.MODE_IEEE, threads=2)[4].astype(np.int64)
+            if not np.array_equal(total.numpy(), whole):
+                q.put(("stats mismatch %s vs %s" % (total.numpy(), whole), 0, [])); return
         # the rgb8 payload of the GPU path: shaded bytes, asynchronous gather (same call DistributedRenderer makes)
         bgr_full = O.shade_depth(t).reshape(resy, resx, 3)
         bgr_local = torch.from_numpy(np.stack([frame_to_packets(bgr_full[:, :, c], xy) for c in range(3)], axis=2).copy())
