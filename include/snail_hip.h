@@ -15,6 +15,11 @@
  * synchronise and are graph-capturable; the un-suffixed entry points take HOST pointers, run on the
  * scene's device and return after the results are in the host buffers.
  *
+ * Concurrency: a SnailScene may be used from several HIP streams at once -- launches keep their per-launch scratch (deferred-packet
+ * lists, the staged shading intermediates) in 8 round-robin slots guarded by events, so a slot's next user waits, on the device,
+ * for its previous one -- but the handle is not thread-safe: make the calls on one scene from one host thread at a time.
+ * snail_last_error() is per host thread.
+ *
  * Record layouts are the reference's own:
  *   node  = 32 B  `BVH::Node`  (src/bvh/tree.h:60-72): bbox min[3], max[3]; subNode|first (bit 31 =
  *                 leaf); {short axis, short firstNode} (inner) or int count (leaf)
