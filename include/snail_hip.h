@@ -12,7 +12,7 @@
  * status on failure with the text available from snail_last_error() (the reference aborts through
  * FATAL/ASSERT, src/rtbase.h:13 -- the adapter turns non-zero into that behaviour).  Buffers are
  * caller-owned.  `*_dev` entry points take DEVICE pointers and a hipStream_t (as void*), never
- * synchronise and are graph-capturable; the un-suffixed entry points take HOST pointers, run on the
+ * synchronise and are graph-capturable (once a first call with that frame size has allocated the handle's scratch); the un-suffixed entry points take HOST pointers, run on the
  * scene's device and return after the results are in the host buffers.
  *
  * Concurrency: a SnailScene may be used from several HIP streams at once -- launches keep their per-launch scratch (deferred-packet

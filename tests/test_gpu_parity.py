@@ -644,3 +644,31 @@ def test_gpu_lbvh_builder_option(torch_mod, name, max_leaf):
     assert sc.build_ms > 0.0
     sc.close()
     sc_sah.close()
+
+
+def test_dev_entry_points_are_graph_capturable(torch_mod):
+    """include/snail_hip.h promises that the *_dev entry points never synchronise and can be captured into a HIP graph once their
+    scratch exists: capture one primary frame and one staged config-3 frame, replay, compare with the direct launches."""
+    name = "atrium:0.05"
+    tv, sc, osc = gpu_scene(name)
+    cam = util.camera_for(name, tv)
+    resx, resy = 320, 192
+    lights = np.array([[0.0, 10.0, 0.0, 1.0, 0.9, 0.8, 90.0]], dtype=np.float32)
+    ref = sc.trace_primary(cam, resx, resy)
+    ref_img = sc.render_whitted(cam, resx, resy, lights, reflections=True)
+    for _ in range(10):                                   # every round-robin scratch slot allocated
+        sc.trace_primary(cam, resx, resy); sc.render_whitted(cam, resx, resy, lights, reflections=True)
+    torch_mod.cuda.synchronize()
+    fr = sc.alloc_frame(resx, resy)
+    img = torch_mod.zeros_like(ref_img)
+    g = torch_mod.cuda.CUDAGraph()
+    with torch_mod.cuda.graph(g):
+        sc.trace_primary(cam, resx, resy, out=fr)
+        sc.render_whitted(cam, resx, resy, lights, out=img, reflections=True)
+    fr.t.fill_(0); img.fill_(0)
+    for _ in range(3):
+        g.replay()
+    torch_mod.cuda.synchronize()
+    assert torch_mod.equal(fr.t, ref.t) and torch_mod.equal(fr.tri_id, ref.tri_id) and torch_mod.equal(fr.u, ref.u)
+    assert torch_mod.equal(img, ref_img)
+    sc.close()
