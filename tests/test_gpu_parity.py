@@ -672,3 +672,23 @@ def test_dev_entry_points_are_graph_capturable(torch_mod):
     assert torch_mod.equal(fr.t, ref.t) and torch_mod.equal(fr.tri_id, ref.tri_id) and torch_mod.equal(fr.u, ref.u)
     assert torch_mod.equal(img, ref_img)
     sc.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5])
+def test_gpu_lbvh_tiny_inputs(torch_mod, n):
+    """Edge cases of the GPU builder: a single triangle (one leaf, no internal node), two, three, five."""
+    from snail_amd.scene import Scene
+    tv = np.ascontiguousarray(scenes.box_scene()[:n])
+    cam = util.camera_for("box", scenes.box_scene())
+    sc = Scene.from_lbvh(tv, 0, max_leaf_tris=1)
+    osc2 = O.OracleScene.__new__(O.OracleScene)
+    osc2.tris = np.ascontiguousarray(sc.bvh.tris.view(O.TRI_DTYPE)); osc2.nodes = np.ascontiguousarray(sc.bvh.nodes.view(O.NODE_DTYPE))
+    osc2.depth = sc.bvh.depth; osc2.perm = sc.perm
+    assert len(sc.bvh.nodes) == 2 * n - 1 and sorted(sc.perm.tolist()) == list(range(n))
+    want = osc2.render_primary(cam.as_array13(), 128, 96, mode=O.MODE_IEEE)
+    fr = sc.trace_primary(cam, 128, 96)
+    torch_mod.cuda.synchronize()
+    for got, w, nm in zip((fr.t, fr.u, fr.v, fr.tri_id), want[:4], "t u v id".split()):
+        util.assert_bit_equal(got.cpu().numpy(), w, "lbvh n=%d %s" % (n, nm))
+    assert np.isfinite(want[0]).any()
+    sc.close()
