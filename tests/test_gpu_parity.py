@@ -692,3 +692,41 @@ def test_gpu_lbvh_tiny_inputs(torch_mod, n):
         util.assert_bit_equal(got.cpu().numpy(), w, "lbvh n=%d %s" % (n, nm))
     assert np.isfinite(want[0]).any()
     sc.close()
+
+
+@pytest.mark.parametrize("name", ["atrium:0.05", "stress:0.05", "box"])
+def test_fuzzed_cameras_and_frame_sizes(torch_mod, name):
+    """Seeded fuzz: cameras anywhere in and around the scene (also far outside, looking away, axis-parallel view directions, very
+    narrow and very wide fields of view), frame sizes that are not multiples of the packet or the tile, down to 1x1 -- primary hit
+    records and the staged config-3 frame (with the mirrored bounce) against the oracle, bit for bit, counters included."""
+    import math
+    tv, sc, osc = gpu_scene(name)
+    rng = np.random.RandomState(sum(name.encode()) % 1000 + 7)
+    bmin, bmax = osc.nodes[0]["bmin"], osc.nodes[0]["bmax"]
+    c, e = (bmin + bmax) * 0.5, (bmax - bmin)
+    sizes = [(1, 1), (5, 3), (16, 16), (17, 33), (100, 7), (64, 130), (129, 65), (200, 120)]
+    for case in range(16):
+        where = rng.rand()
+        pos = c + (rng.rand(3) - 0.5) * e * (0.8 if where < 0.6 else 3.5)
+        yaw = [0.0, math.pi / 2, math.pi, rng.rand() * 2 * math.pi][case % 4] if case % 3 == 0 else rng.rand() * 2 * math.pi
+        pitch = 0.0 if case % 5 == 0 else (rng.rand() - 0.5) * 2.6
+        pd = [1.0, 0.15, 6.0, 1.0][case % 4]
+        cam = FPSCamera(pos.astype(np.float32), yaw, pitch, plane_dist=pd).camera()
+        resx, resy = sizes[case % len(sizes)]
+        want = osc.render_primary(cam.as_array13(), resx, resy, mode=O.MODE_IEEE)
+        stats = sc.new_stats()
+        fr = sc.trace_primary(cam, resx, resy, stats=stats)
+        torch_mod.cuda.synchronize()
+        for got, w, nm in zip((fr.t, fr.u, fr.v, fr.tri_id), want[:4], "t u v id".split()):
+            util.assert_bit_equal(got.cpu().numpy(), w, "%s case %d %s" % (name, case, nm))
+        assert np.array_equal(stats.cpu().numpy().astype(np.uint64), want[4]), (case, stats.cpu().numpy(), want[4])
+        lights = np.array([[*(c + (rng.rand(3) - 0.5) * e * 0.7), 1.0, 0.8, 0.6, float(e.max()) * (0.3 + 2.0 * rng.rand())],
+                           [*(pos + 0.01), 0.5, 0.5, 0.9, float(e.max())]], dtype=np.float32)[:1 + case % 2]
+        refl = case % 2 == 0
+        wimg, wst = osc.render_whitted(cam.as_array13(), resx, resy, lights, mode=O.MODE_IEEE, reflections=refl)
+        stats = sc.new_stats()
+        img = sc.render_whitted(cam, resx, resy, lights, stats=stats, reflections=refl)
+        torch_mod.cuda.synchronize()
+        assert np.array_equal(img.cpu().numpy(), wimg), (name, case, int((img.cpu().numpy() != wimg).sum()))
+        assert np.array_equal(stats.cpu().numpy().astype(np.uint64), wst), (name, case, stats.cpu().numpy(), wst)
+    sc.close()
