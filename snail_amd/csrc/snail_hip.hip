@@ -597,7 +597,10 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 // cull / push / pop loop is written by hand, because the compiler's version of it carries register shuffling (loop-carried copies
 // around the stack VGPRs and the node SGPRs, hazard padding around its inline v_min/v_max): 56 VALU + ~24 scalar instructions per
 // inner node of a coherent shared-origin packet, against ~103 for the compiler at the time (profiles/README.md).  One asm statement
-// = "pop, then descend until a leaf survives its box test (-> the C++ leaf code) or the stack is empty".  Variants are assembled
+// = "pop, then descend until a leaf survives its box test (-> the C++ leaf code) or the stack is empty".  Inside the loop EXEC is the
+// quad range [first,last] (s_bfm_b64 + s_bitset1_b64 whenever the range changes): the compare of the slab test then yields the
+// clipped mask directly (VALU compares and lane reads/writes that target SGPRs are the expensive instructions here, 2.4-4 cycles
+// against 1.6 for a multiply: profiles/README.md); v_readlane / v_writelane ignore EXEC; every exit restores EXEC = all lanes.  Variants are assembled
 // from string macros: slab products (coherent: near/far planes by sign octant, one statement per octant; non-coherent: min/max per
 // axis), shared or per-ray origins, the slack formula (distances >= 0, or any distance with -inf = masked), what is counted.
 //   node record  s[84:91] = bmin.xyz, bmax.xyz, sub, aux            stack: lane i of (stkN, stkF) = slot i
@@ -657,6 +660,7 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 " v_readlane_b32 %[cur], %[stkN], %[sp]\n v_readlane_b32 %[fl], %[stkF], %[sp]\n"                                         \
 				 " s_lshl_b32 %[off], %[cur], 5\n s_load_dwordx8 s[84:91], %[base], %[off]\n"                                              \
 				 " s_and_b32 %[first], %[fl], 0xff\n s_lshr_b32 %[last], %[fl], 8\n s_sub_u32 %[width], %[last], %[first]\n"               \
+				 " s_bfm_b64 exec, %[width], %[first]\n s_bitset1_b64 exec, %[last]\n"                                                     \
 				 " s_waitcnt lgkmcnt(0)\n"                                                                                                 \
 				 "L_visit_%=:\n" CNTVISIT                                                                                                  \
 				 PRE(NX, FX, NY, FY, NZ, FZ)                                                                                               \
@@ -665,10 +669,10 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 " v_max_f32 %[s2], %[s2], %[s3]\n v_max3_f32 %[s0], %[s0], %[s1], %[s2]\n"                                                \
 				 SNAIL_EXP_PAD                                                                                                             \
 				 " v_cmp_le_f32 vcc, 0, %[s0]\n"                                                                                           \
-				 " v_subrev_u32 %[t0], %[first], %[lane]\n v_cmp_ge_u32 %[rng], %[width], %[t0]\n"                                         \
-				 " s_and_b64 %[alive], vcc, %[rng]\n s_cbranch_scc0 L_pop_%=\n"                                                            \
+				 " s_and_b64 %[alive], vcc, exec\n s_cbranch_scc0 L_pop_%=\n"                                                              \
 				 " s_ff1_i32_b64 %[first], %[alive]\n s_flbit_i32_b64 %[last], %[alive]\n s_xor_b32 %[last], %[last], 63\n"                \
 				 " s_sub_u32 %[width], %[last], %[first]\n"                                                                                \
+				 " s_bfm_b64 exec, %[width], %[first]\n s_bitset1_b64 exec, %[last]\n"                                                     \
 				 " s_cmp_lt_i32 s90, 0\n s_cbranch_scc1 L_leaf_%=\n"                                                                       \
 				 " s_lshr_b32 %[cur], %[sign16], s91\n s_xor_b32 %[cur], %[cur], s91\n s_bfe_u32 %[cur], %[cur], 0x10010\n"                \
 				 " s_add_u32 %[fl], s90, 1\n s_sub_u32 %[fl], %[fl], %[cur]\n"                                                             \
@@ -680,7 +684,7 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 " s_waitcnt lgkmcnt(0)\n s_branch L_visit_%=\n"                                                                           \
 				 "L_leaf_%=:\n s_mov_b32 %[leafSub], s90\n s_mov_b32 %[leafAux], s91\n s_branch L_end_%=\n"                                \
 				 "L_done_%=:\n s_mov_b32 %[leafSub], 0\n s_mov_b32 %[leafAux], 0\n"                                                        \
-				 "L_end_%=:\n"                                                                                                             \
+				 "L_end_%=:\n s_mov_b64 exec, -1\n"                                                                                        \
 				 : [sp] "+s"(sp), [first] "+s"(first), [last] "+s"(last), [cnt] "+s"(cnt), [stkN] "+v"(stkN), [stkF] "+v"(stkF),           \
 				   [leafSub] "=&s"(leafSub), [leafAux] "=&s"(leafAux), [cur] "=&s"(sCur), [fl] "=&s"(sFl), [off] "=&s"(sOff),              \
 				   [width] "=&s"(sWidth), [rng] "=&s"(sRng), [alive] "=&s"(sAlive), [pnx] "=&v"(vt[0]), [pny] "=&v"(vt[1]),                \

@@ -3,7 +3,7 @@
 # tools/build_pad_variants.sh (-> snail_amd/exp/lib_*.so, which travel with the snapshot); results in profiles/README.md.  Runs on the GPU box; overwrites the box's copy of libsnailhip.so.
 set -u
 cp snail_amd/libsnailhip.so /tmp/lib_base.so
-for v in base mulchain mul2 max3 subs mov salu20 nop20; do
+for v in base mulchain mul2 max3 subs mov salu20 nop20 vcmp rfl; do
   if [ $v = base ]; then cp /tmp/lib_base.so snail_amd/libsnailhip.so; else cp snail_amd/exp/lib_$v.so snail_amd/libsnailhip.so; fi
   timeout -k 10 200 python bench.py --no-cpu-baseline > gpurun_out/exp_$v.json 2> gpurun_out/exp_$v.err || exit 1
   python - $v <<'PY'
