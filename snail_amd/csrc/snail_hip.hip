@@ -652,14 +652,32 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 // min(min(tf,dist) - tn, tf)
 #define SNAIL_TAIL_POS(L, S) "v_max_f32 %[t0], 0, %[t0]\n v_min_f32 %[t3], %[t3], %[d" L "]\n v_sub_f32 %[" S "], %[t3], %[t0]\n"
 #define SNAIL_TAIL_ANY(L, S) "v_min_f32 %[t4], %[t3], %[d" L "]\n v_sub_f32 %[t4], %[t4], %[t0]\n v_min_f32 %[" S "], %[t4], %[t3]\n"
+// the traversal stack inside the loop.  2W: two words per entry (node; first | last << 8) in two VGPRs.  1W: one word, node | first << 20
+// | last << 26, for trees of at most 2^20 node slots: one lane read per pop and one lane write per push instead of two (these are
+// the most expensive instructions of the loop, ~4 cycles each against 1.6 for a multiply)
+#define SNAIL_POP_2W                                                                                                                       \
+	" v_readlane_b32 %[cur], %[stkN], %[sp]\n v_readlane_b32 %[fl], %[stkF], %[sp]\n"                                                      \
+	" s_and_b32 %[first], %[fl], 0xff\n s_lshr_b32 %[last], %[fl], 8\n"
+#define SNAIL_POP_1W                                                                                                                       \
+	" v_readlane_b32 %[fl], %[stkN], %[sp]\n"                                                                                              \
+	" s_and_b32 %[cur], %[fl], 0xfffff\n s_bfe_u32 %[first], %[fl], 0x60014\n s_lshr_b32 %[last], %[fl], 26\n"
+// push (far child in %[fl]; %[off] is free)
+#define SNAIL_PUSH_2W                                                                                                                      \
+	" s_lshl_b32 %[off], %[last], 8\n s_or_b32 %[off], %[off], %[first]\n"                                                                 \
+	" s_mov_b32 m0, %[sp]\n v_writelane_b32 %[stkN], %[fl], m0\n v_writelane_b32 %[stkF], %[off], m0\n"
+#define SNAIL_PUSH_1W                                                                                                                      \
+	" s_lshl_b32 %[off], %[last], 6\n s_or_b32 %[off], %[off], %[first]\n s_lshl_b32 %[off], %[off], 20\n s_or_b32 %[off], %[off], %[fl]\n" \
+	" s_mov_b32 m0, %[sp]\n v_writelane_b32 %[stkN], %[off], m0\n"
 #define SNAIL_COUNT " s_add_u32 %[cnt], %[cnt], 1\n"
-#define SNAIL_DESCEND_ASM(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, NX, FX, NY, FY, NZ, FZ)                                                            \
+#define SNAIL_DESCEND_ASM(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, NX, FX, NY, FY, NZ, FZ)                                                 \
+	SNAIL_DESCEND_ASM_S(SNAIL_POP_2W, SNAIL_PUSH_2W, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, NX, FX, NY, FY, NZ, FZ)
+#define SNAIL_DESCEND_ASM_S(POP, PUSH, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, NX, FX, NY, FY, NZ, FZ)                                                            \
 	asm volatile("L_pop_%=:\n"                                                                                                             \
 				 " s_cmp_eq_u32 %[sp], 0\n s_cbranch_scc1 L_done_%=\n"                                                                     \
 				 " s_sub_u32 %[sp], %[sp], 1\n" CNTPOP                                                                                     \
-				 " v_readlane_b32 %[cur], %[stkN], %[sp]\n v_readlane_b32 %[fl], %[stkF], %[sp]\n"                                         \
+				 POP                                                                                                                       \
 				 " s_lshl_b32 %[off], %[cur], 5\n s_load_dwordx8 s[84:91], %[base], %[off]\n"                                              \
-				 " s_and_b32 %[first], %[fl], 0xff\n s_lshr_b32 %[last], %[fl], 8\n s_sub_u32 %[width], %[last], %[first]\n"               \
+				 " s_sub_u32 %[width], %[last], %[first]\n"                                                                                \
 				 " s_bfm_b64 exec, %[width], %[first]\n s_bitset1_b64 exec, %[last]\n"                                                     \
 				 " s_waitcnt lgkmcnt(0)\n"                                                                                                 \
 				 "L_visit_%=:\n" CNTVISIT                                                                                                  \
@@ -678,8 +696,7 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 " s_add_u32 %[fl], s90, 1\n s_sub_u32 %[fl], %[fl], %[cur]\n"                                                             \
 				 " s_add_u32 %[cur], s90, %[cur]\n s_lshl_b32 %[off], %[cur], 5\n"                                                         \
 				 " s_load_dwordx8 s[84:91], %[base], %[off]\n"                                                                             \
-				 " s_lshl_b32 %[off], %[last], 8\n s_or_b32 %[off], %[off], %[first]\n"                                                    \
-				 " s_mov_b32 m0, %[sp]\n v_writelane_b32 %[stkN], %[fl], m0\n v_writelane_b32 %[stkF], %[off], m0\n"                       \
+				 PUSH                                                                                                                      \
 				 " s_add_u32 %[sp], %[sp], 1\n"                                                                                            \
 				 " s_waitcnt lgkmcnt(0)\n s_branch L_visit_%=\n"                                                                           \
 				 "L_leaf_%=:\n s_mov_b32 %[leafSub], s90\n s_mov_b32 %[leafAux], s91\n s_branch L_end_%=\n"                                \
@@ -703,23 +720,24 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 "s"(sWidth), "s"(sRng), "s"(sAlive), "v"(vt[0]), "v"(vt[1]), "v"(vt[2]), "v"(vt[3]), "v"(vt[4]), "v"(vt[5]), "v"(vt[6]), "v"(vt[7]), \
 				 "v"(vt[8]), "v"(vt[9]), "v"(vt[10]), "v"(vt[11]), "v"(vt[12]), "v"(vt[13]), "v"(vt[14]), "v"(vt[15]), "v"(vt[16]))
 // near/far plane registers by sign octant (bit k set = idir negative on axis k: near plane = bmax[k]); s[84:86] = bmin, s[87:89] = bmax
-#define SNAIL_DESCEND_OCT(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, OCT)                                                                               \
+#define SNAIL_DESCEND_OCT(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, OCT) SNAIL_DESCEND_OCT_S(SNAIL_POP_2W, SNAIL_PUSH_2W, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, OCT)
+#define SNAIL_DESCEND_OCT_S(POP, PUSH, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, OCT)                                                                               \
 	switch(OCT) {                                                                                                                          \
-	case 0: SNAIL_DESCEND_ASM(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s85", "s88", "s86", "s89"); break;                              \
-	case 1: SNAIL_DESCEND_ASM(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s85", "s88", "s86", "s89"); break;                              \
-	case 2: SNAIL_DESCEND_ASM(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s88", "s85", "s86", "s89"); break;                              \
-	case 3: SNAIL_DESCEND_ASM(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s88", "s85", "s86", "s89"); break;                              \
-	case 4: SNAIL_DESCEND_ASM(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s85", "s88", "s89", "s86"); break;                              \
-	case 5: SNAIL_DESCEND_ASM(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s85", "s88", "s89", "s86"); break;                              \
-	case 6: SNAIL_DESCEND_ASM(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s88", "s85", "s89", "s86"); break;                              \
-	default: SNAIL_DESCEND_ASM(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s88", "s85", "s89", "s86"); break;                             \
+	case 0: SNAIL_DESCEND_ASM_S(POP, PUSH, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s85", "s88", "s86", "s89"); break;                              \
+	case 1: SNAIL_DESCEND_ASM_S(POP, PUSH, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s85", "s88", "s86", "s89"); break;                              \
+	case 2: SNAIL_DESCEND_ASM_S(POP, PUSH, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s88", "s85", "s86", "s89"); break;                              \
+	case 3: SNAIL_DESCEND_ASM_S(POP, PUSH, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s88", "s85", "s86", "s89"); break;                              \
+	case 4: SNAIL_DESCEND_ASM_S(POP, PUSH, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s85", "s88", "s89", "s86"); break;                              \
+	case 5: SNAIL_DESCEND_ASM_S(POP, PUSH, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s85", "s88", "s89", "s86"); break;                              \
+	case 6: SNAIL_DESCEND_ASM_S(POP, PUSH, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s88", "s85", "s89", "s86"); break;                              \
+	default: SNAIL_DESCEND_ASM_S(POP, PUSH, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s88", "s85", "s89", "s86"); break;                             \
 	}
 
 // SHADOW=false: closest hit of a primary packet (distances >= 0; visits = 2 * pops - 1: every chain of visits starts with a pop,
 // the root is pushed here, and every push is popped).  SHADOW=true: any hit of a shadow packet (masked lanes -inf; the walk ends
 // when a triangle occludes the whole packet, so every visit is counted).  COH: one asm statement per sign octant, picked by a
 // wave-uniform switch at every (re-)entry, i.e. once per leaf; the leaf code exists once.
-template <bool SHADOW, bool COH>
+template <bool SHADOW, bool COH, bool PACK = false>
 __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes, const uint4 *__restrict__ tris, int lane, const float (&org)[3][4],
 											  Quad &Q, int (&tid)[4], float *lds, Counters &st, const int oct) {
 	Interval iv;
@@ -735,19 +753,23 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes, c
 	const int sign16 = signBits << 16;
 	const u64 nodeBase = (u64)nodes;
 	float bu[4], bv[4]; // not maintained here (finalBarycentrics)
-	int stkN = 0, stkF = 63 << 8; // slot 0 = the root with the full quad range
+	int stkN = PACK ? (63 << 26) : 0, stkF = 63 << 8; // slot 0 = the root with the full quad range
 	int sp = 1, first = 0, last = 63, cnt = 0;
 	for(;;) {
 		int leafSub, leafAux, sCur, sFl, sOff, sWidth;
 		u64 sRng, sAlive;
 		float vt[17];
-		if(COH) {
-			if(SHADOW) { SNAIL_DESCEND_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_ANY, "", SNAIL_COUNT, oct) }
-			else { SNAIL_DESCEND_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_POS, SNAIL_COUNT, "", oct) }
-		} else {
-			if(SHADOW) { SNAIL_DESCEND_ASM(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, "", SNAIL_COUNT, "s84", "s87", "s85", "s88", "s86", "s89"); }
-			else { SNAIL_DESCEND_ASM(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_POS, SNAIL_COUNT, "", "s84", "s87", "s85", "s88", "s86", "s89"); }
+#define SNAIL_SHARED_VARIANTS(POP, PUSH)                                                                                                   \
+		if(COH) {                                                                                                                          \
+			if(SHADOW) { SNAIL_DESCEND_OCT_S(POP, PUSH, SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_ANY, "", SNAIL_COUNT, oct) } \
+			else { SNAIL_DESCEND_OCT_S(POP, PUSH, SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_POS, SNAIL_COUNT, "", oct) }      \
+		} else {                                                                                                                           \
+			if(SHADOW) { SNAIL_DESCEND_ASM_S(POP, PUSH, SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, "", SNAIL_COUNT, "s84", "s87", "s85", "s88", "s86", "s89"); } \
+			else { SNAIL_DESCEND_ASM_S(POP, PUSH, SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_POS, SNAIL_COUNT, "", "s84", "s87", "s85", "s88", "s86", "s89"); } \
 		}
+		if(PACK) { SNAIL_SHARED_VARIANTS(SNAIL_POP_1W, SNAIL_PUSH_1W) }
+		else { SNAIL_SHARED_VARIANTS(SNAIL_POP_2W, SNAIL_PUSH_2W) }
+#undef SNAIL_SHARED_VARIANTS
 		if(leafSub == 0) break;
 		if(leafShared<false, SHADOW, COH ? M_COH : M_FAST, false>(tris, leafAux, (int)((unsigned)leafSub & 0x7fffffffu), 64, lane, first, last, org, Q, 15u,
 																   tid, bu, bv, iv, st))
@@ -855,6 +877,7 @@ struct PrimaryArgs {
 	const int2 *packetXY;		  // ... or explicit packet list (packet-major layout)
 	int nPackets, pw, ph;		  // packet grid of the rect
 	int nBlocks;
+	int pack;                     // at most 2^20 node slots: one-word stack entries in the hand-written walks
 	int packetMajor;              // rect mode: store packet-major ([cy*pw+cx][256], the reference's quad order) instead of frame layout
 	int fastOK;
 	float *t, *u, *v;
@@ -941,6 +964,9 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 	} else if(DEEP) { // depth > 62: the C++ walk with its second stack register pair
 		if(mode == M_COH) walk<true, false, false, M_COH, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, oct);
 		else walk<true, false, false, M_FAST, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st);
+	} else if(A.pack) {
+		if(mode == M_COH) walkSharedAsm<false, true, true>(A.nodes, A.tris, lane, org, Q, tid, lds, st, oct);
+		else walkSharedAsm<false, false, true>(A.nodes, A.tris, lane, org, Q, tid, lds, st, 0);
 	} else if(mode == M_COH) walkSharedAsm<false, true>(A.nodes, A.tris, lane, org, Q, tid, lds, st, oct);
 	else walkSharedAsm<false, false>(A.nodes, A.tris, lane, org, Q, tid, lds, st, 0);
 	if(A.u || A.v) finalBarycentrics(A.tris, org, Q, tid, bu, bv); // (the staged shading pipeline asks for t and triId only)
@@ -1029,6 +1055,7 @@ struct ShadeArgs {
 	GenConst g;
 	int resx, resy, pw, ph, fastOK;
 	int nBlocks;         // grid.x of the per-packet kernels (packets padded to whole XCD regions)
+	int pack;            // at most 2^20 node slots: one-word stack entries in the hand-written walks
 	int nLights;
 	float lights[SNAIL_MAX_LIGHTS][7];
 	float ambient[3], color[3];
@@ -1219,6 +1246,9 @@ __device__ __forceinline__ void lightPacket(const ShadeArgs &A, const int li, co
 		if(DEEP) {
 			if(mode == M_COH) walk<true, false, true, M_COH, false, DEEP, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st, oct);
 			else walk<true, false, true, M_FAST, false, DEEP, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st);
+		} else if(A.pack) {
+			if(mode == M_COH) walkSharedAsm<true, true, true>(A.nodes, A.tris, lane, lorg, Q, stid, lds, st, oct);
+			else walkSharedAsm<true, false, true>(A.nodes, A.tris, lane, lorg, Q, stid, lds, st, 0);
 		} else if(mode == M_COH) walkSharedAsm<true, true>(A.nodes, A.tris, lane, lorg, Q, stid, lds, st, oct);
 		else walkSharedAsm<true, false>(A.nodes, A.tris, lane, lorg, Q, stid, lds, st, 0);
 	}
@@ -1761,6 +1791,12 @@ bool useDeep(const SnailScene *s) {
 	return force || s->depth > 62;
 }
 
+// one-word stack entries need node indices below 2^20.  SNAIL_DEBUG_NO_PACK=1 keeps the two-word form (A/B measurements)
+int stackPack(const SnailScene *s) {
+	static const bool off = getenv("SNAIL_DEBUG_NO_PACK") && atoi(getenv("SNAIL_DEBUG_NO_PACK")) != 0;
+	return !off && s->nNodes <= (1 << 20) ? 1 : 0;
+}
+
 int checkScene(const SnailScene *s, const char *fn) {
 	if(!s || !s->dNodes || !s->dTris) { snail_set_error("%s: invalid scene handle", fn); return 1; }
 	return 0;
@@ -1780,6 +1816,7 @@ int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0
 	A.stats = (dev::u64 *)dStats;
 	A.cost = dCost;
 	A.packetMajor = packetMajor ? 1 : 0;
+	A.pack = stackPack(s);
 	int blocks;
 	if(dPacketXY) {
 		if(nPackets <= 0) return 0;
@@ -2210,6 +2247,7 @@ int snail_render_whitted_dev(SnailScene *s, const float cam[13], int resx, int r
 	A.g = makeGen(cam, resx, resy);
 	A.resx = resx; A.resy = resy; A.pw = (resx + 15) / 16; A.ph = (resy + 15) / 16;
 	A.fastOK = s->fastOK && originSane(cam);
+	A.pack = stackPack(s);
 	A.nLights = nLights;
 	for(int n = 0; n < nLights; n++) for(int k = 0; k < 7; k++) A.lights[n][k] = lights7[n * 7 + k];
 	for(int c = 0; c < 3; c++) { A.ambient[c] = ambient[c]; A.color[c] = color[c]; }
