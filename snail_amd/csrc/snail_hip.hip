@@ -737,24 +737,28 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 // the root is pushed here, and every push is popped).  SHADOW=true: any hit of a shadow packet (masked lanes -inf; the walk ends
 // when a triangle occludes the whole packet, so every visit is counted).  COH: one asm statement per sign octant, picked by a
 // wave-uniform switch at every (re-)entry, i.e. once per leaf; the leaf code exists once.
-template <bool SHADOW, bool COH, bool PACK = false>
-__device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes, const uint4 *__restrict__ tris, int lane, const float (&org)[3][4],
-											  Quad &Q, int (&tid)[4], float *lds, Counters &st, const int oct) {
+template <bool SHADOW, bool COH, bool PACK, bool MASK, bool BARY, bool POSDIST>
+__device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes, const uint4 *__restrict__ tris, int size, int lane,
+											  const float (&org)[3][4], Quad &Q, unsigned mask4, int (&tid)[4], float (&bu)[4], float (&bv)[4], float *lds,
+											  Counters &st, const int oct) {
 	Interval iv;
-	if(SHADOW) {
-		unsigned act4 = 0;
+	{ // RayInterval ctor (src/ray_group.h:296-333), as in dev::walk
+		unsigned act4 = lane < size ? 15u : 0u;
+		if(SHADOW) {
+			act4 = 0;
+			if(lane < size)
 #pragma unroll
-		for(int l = 0; l < 4; l++) act4 |= (Q.dist[l] >= 0.0f ? 1u : 0u) << l;
-		computeMinMax<false, true>(Q.d, act4, 64, lane, lds, iv.minDir, iv.maxDir);
-	} else computeMinMax<false, false>(Q.d, 15u, 64, lane, lds, iv.minDir, iv.maxDir);
+				for(int l = 0; l < 4; l++) act4 |= (Q.dist[l] >= 0.0f ? 1u : 0u) << l;
+		} else if(MASK) act4 = lane < size ? (mask4 & 15u) : 0u;
+		computeMinMax<false, (MASK || SHADOW)>(Q.d, act4, size, lane, lds, iv.minDir, iv.maxDir);
+	}
 #pragma unroll
 	for(int k = 0; k < 3; k++) { iv.minIDir[k] = iv.maxIDir[k] = 0.0f; iv.minOrg[k] = iv.maxOrg[k] = org[k][0]; }
 	const int signBits = __builtin_amdgcn_readfirstlane((Q.d[0][0] < 0.0f ? 1 : 0) | (Q.d[1][0] < 0.0f ? 2 : 0) | (Q.d[2][0] < 0.0f ? 4 : 0));
 	const int sign16 = signBits << 16;
 	const u64 nodeBase = (u64)nodes;
-	float bu[4], bv[4]; // not maintained here (finalBarycentrics)
-	int stkN = PACK ? (63 << 26) : 0, stkF = 63 << 8; // slot 0 = the root with the full quad range
-	int sp = 1, first = 0, last = 63, cnt = 0;
+	int stkN = PACK ? ((size - 1) << 26) : 0, stkF = (size - 1) << 8; // slot 0 = the root with the full quad range
+	int sp = 1, first = 0, last = size - 1, cnt = 0;
 	for(;;) {
 		int leafSub, leafAux, sCur, sFl, sOff, sWidth;
 		u64 sRng, sAlive;
@@ -762,17 +766,19 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes, c
 #define SNAIL_SHARED_VARIANTS(POP, PUSH)                                                                                                   \
 		if(COH) {                                                                                                                          \
 			if(SHADOW) { SNAIL_DESCEND_OCT_S(POP, PUSH, SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_ANY, "", SNAIL_COUNT, oct) } \
-			else { SNAIL_DESCEND_OCT_S(POP, PUSH, SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_POS, SNAIL_COUNT, "", oct) }      \
+			else if(POSDIST) { SNAIL_DESCEND_OCT_S(POP, PUSH, SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_POS, SNAIL_COUNT, "", oct) } \
+			else { SNAIL_DESCEND_OCT_S(POP, PUSH, SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_ANY, SNAIL_COUNT, "", oct) }      \
 		} else {                                                                                                                           \
 			if(SHADOW) { SNAIL_DESCEND_ASM_S(POP, PUSH, SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, "", SNAIL_COUNT, "s84", "s87", "s85", "s88", "s86", "s89"); } \
-			else { SNAIL_DESCEND_ASM_S(POP, PUSH, SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_POS, SNAIL_COUNT, "", "s84", "s87", "s85", "s88", "s86", "s89"); } \
+			else if(POSDIST) { SNAIL_DESCEND_ASM_S(POP, PUSH, SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_POS, SNAIL_COUNT, "", "s84", "s87", "s85", "s88", "s86", "s89"); } \
+			else { SNAIL_DESCEND_ASM_S(POP, PUSH, SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, "", "s84", "s87", "s85", "s88", "s86", "s89"); } \
 		}
 		if(PACK) { SNAIL_SHARED_VARIANTS(SNAIL_POP_1W, SNAIL_PUSH_1W) }
 		else { SNAIL_SHARED_VARIANTS(SNAIL_POP_2W, SNAIL_PUSH_2W) }
 #undef SNAIL_SHARED_VARIANTS
 		if(leafSub == 0) break;
-		if(leafShared<false, SHADOW, COH ? M_COH : M_FAST, false>(tris, leafAux, (int)((unsigned)leafSub & 0x7fffffffu), 64, lane, first, last, org, Q, 15u,
-																   tid, bu, bv, iv, st))
+		if(leafShared<MASK, SHADOW, COH ? M_COH : M_FAST, BARY>(tris, leafAux, (int)((unsigned)leafSub & 0x7fffffffu), size, lane, first, last, org, Q, mask4,
+																 tid, bu, bv, iv, st))
 			break;
 	}
 	st.iters += SHADOW ? (unsigned)cnt : 2u * (unsigned)cnt - 1u;
@@ -887,7 +893,6 @@ struct PrimaryArgs {
 	int *defer;		// [0] = count, [1] = finished blocks of the M_EXACT pass, [2..] = logical indices of deferred packets
 };
 
-#define WAVES_PER_BLOCK 4
 #define LDS_FLOATS_PER_WAVE (64 * 12 + 64)
 
 // Block -> packet mapping of the primary kernel.  ONE WAVE PER BLOCK: packet costs vary ~10x (p5 66 K .. max
@@ -965,10 +970,10 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 		if(mode == M_COH) walk<true, false, false, M_COH, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, oct);
 		else walk<true, false, false, M_FAST, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st);
 	} else if(A.pack) {
-		if(mode == M_COH) walkSharedAsm<false, true, true>(A.nodes, A.tris, lane, org, Q, tid, lds, st, oct);
-		else walkSharedAsm<false, false, true>(A.nodes, A.tris, lane, org, Q, tid, lds, st, 0);
-	} else if(mode == M_COH) walkSharedAsm<false, true>(A.nodes, A.tris, lane, org, Q, tid, lds, st, oct);
-	else walkSharedAsm<false, false>(A.nodes, A.tris, lane, org, Q, tid, lds, st, 0);
+		if(mode == M_COH) walkSharedAsm<false, true, true, false, false, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, oct);
+		else walkSharedAsm<false, false, true, false, false, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, 0);
+	} else if(mode == M_COH) walkSharedAsm<false, true, false, false, false, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, oct);
+	else walkSharedAsm<false, false, false, false, false, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, 0);
 	if(A.u || A.v) finalBarycentrics(A.tris, org, Q, tid, bu, bv); // (the staged shading pipeline asks for t and triId only)
 
 	flushStats(A.stats, st, 256u, lane);
@@ -1247,10 +1252,10 @@ __device__ __forceinline__ void lightPacket(const ShadeArgs &A, const int li, co
 			if(mode == M_COH) walk<true, false, true, M_COH, false, DEEP, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st, oct);
 			else walk<true, false, true, M_FAST, false, DEEP, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st);
 		} else if(A.pack) {
-			if(mode == M_COH) walkSharedAsm<true, true, true>(A.nodes, A.tris, lane, lorg, Q, stid, lds, st, oct);
-			else walkSharedAsm<true, false, true>(A.nodes, A.tris, lane, lorg, Q, stid, lds, st, 0);
-		} else if(mode == M_COH) walkSharedAsm<true, true>(A.nodes, A.tris, lane, lorg, Q, stid, lds, st, oct);
-		else walkSharedAsm<true, false>(A.nodes, A.tris, lane, lorg, Q, stid, lds, st, 0);
+			if(mode == M_COH) walkSharedAsm<true, true, true, false, false, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st, oct);
+			else walkSharedAsm<true, false, true, false, false, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st, 0);
+		} else if(mode == M_COH) walkSharedAsm<true, true, false, false, false, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st, oct);
+		else walkSharedAsm<true, false, false, false, false, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st, 0);
 	}
 	flushStats(A.stats, st, rays, lane);
 	const size_t packets = (size_t)A.pw * A.ph;
@@ -1465,6 +1470,9 @@ __device__ __forceinline__ void raysPacket(const RaysArgs &A, const int p, float
 		if(!SHARED && !DEEP) { // per-ray origins: the hand-written node loop
 			if(mode == M_COH) walkPerRayAsm<MASK, true, BARY>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, st, oct);
 			else walkPerRayAsm<MASK, false, BARY>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, st, 0);
+		} else if(SHARED && !DEEP) { // shared origin, any distances on entry
+			if(mode == M_COH) walkSharedAsm<false, true, false, MASK, BARY, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, lds, st, oct);
+			else walkSharedAsm<false, false, false, MASK, BARY, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, lds, st, 0);
 		} else if(mode == M_COH) walk<SHARED, MASK, false, M_COH, BARY, DEEP, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, lds, st, oct);
 		else walk<SHARED, MASK, false, M_FAST, BARY, DEEP, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, lds, st);
 	}
@@ -1494,11 +1502,10 @@ __global__ __launch_bounds__(64) void k_rays_exact(RaysArgs A) {
 }
 
 // ---- shadow packets: TraverseShadow(ShadowContext&) -----------------------------------------------
-__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_shadow(RaysArgs A) {
-	__shared__ float ldsAll[WAVES_PER_BLOCK][LDS_FLOATS_PER_WAVE];
+// same launch structure as k_rays: one wave per block, M_EXACT packets deferred to the second launch
+template <bool DEEP, bool EXACTPASS>
+__device__ __forceinline__ void shadowPacket(const RaysArgs &A, const int p, float *lds) {
 	const int lane = threadIdx.x & 63;
-	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	const int p = (int)blockIdx.x * WAVES_PER_BLOCK + wave;
 	if(p >= A.nPackets) return;
 	const int size = A.size;
 	const bool live = lane < size;
@@ -1520,16 +1527,38 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void k_shadow(RaysArgs A) {
 	float bu[4] = {0, 0, 0, 0}, bv[4] = {0, 0, 0, 0};
 
 	Counters st = {0, 0, 0};
-	bool fin = finite4(Q.id) && finite4(Q.d) && finite4(org);
+	if(EXACTPASS) walk<true, false, true, M_EXACT, false, DEEP, false>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, lds, st);
+	else {
+		bool fin = finite4(Q.id) && finite4(Q.d) && finite4(org);
 #pragma unroll
-	for(int l = 0; l < 4; l++) fin = fin && !(Q.dist[l] != Q.dist[l]);
-	int oct;
-	const int mode = classify(A.fastOK != 0, fin, live, Q.id, Q.dist, oct);
-	if(mode == M_COH) walk<true, false, true, M_COH, false, true, false>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st, oct);
-	else if(mode == M_FAST) walk<true, false, true, M_FAST, false, true, false>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
-	else walk<true, false, true, M_EXACT, false, true, false>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, ldsAll[wave], st);
+		for(int l = 0; l < 4; l++) fin = fin && !(Q.dist[l] != Q.dist[l]);
+		int oct;
+		const int mode = classify(A.fastOK != 0, fin, live, Q.id, Q.dist, oct);
+		if(mode == M_EXACT) {
+			if(lane == 0) A.defer[16 + atomicAdd(&A.defer[0], 1)] = p;
+			return;
+		}
+		if(DEEP) {
+			if(mode == M_COH) walk<true, false, true, M_COH, false, DEEP, false>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, lds, st, oct);
+			else walk<true, false, true, M_FAST, false, DEEP, false>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, lds, st);
+		} else if(mode == M_COH) walkSharedAsm<true, true, false, false, false, false>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, lds, st, oct);
+		else walkSharedAsm<true, false, false, false, false, false>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, lds, st, 0);
+	}
 	flushStats(A.stats, st, 0u, lane);
 	if(live) *(float4 *)(A.distance + q * 4) = make_float4(Q.dist[0], Q.dist[1], Q.dist[2], Q.dist[3]);
+}
+template <bool DEEP>
+__global__ __launch_bounds__(64) void k_shadow(RaysArgs A) {
+	__shared__ float lds[LDS_FLOATS_PER_WAVE];
+	shadowPacket<DEEP, false>(A, interleave16((int)blockIdx.x), lds);
+}
+template <bool DEEP>
+__global__ __launch_bounds__(64) void k_shadow_exact(RaysArgs A) {
+	__shared__ float lds[LDS_FLOATS_PER_WAVE];
+	const int n = __builtin_amdgcn_readfirstlane(A.defer[0]);
+	for(int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) shadowPacket<DEEP, true>(A, __builtin_amdgcn_readfirstlane(A.defer[16 + i]), lds);
+	__threadfence();
+	if((threadIdx.x & 63) == 0 && atomicAdd(&A.defer[1], 1) == (int)gridDim.x - 1) { A.defer[0] = 0; A.defer[1] = 0; }
 }
 
 // ---- packet-major -> frame scatter ------------------------------------------------------------------
@@ -1928,12 +1957,6 @@ int launchRays(SnailScene *s, bool shadow, int nPackets, int size, int sharedOri
 	A.origin = origin; A.dir = dir; A.idir = idir; A.mask = mask;
 	A.distance = distance; A.object = object; A.bary = bary;
 	A.stats = (dev::u64 *)dStats;
-	if(shadow) {
-		const int blocks = (nPackets + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-		hipLaunchKernelGGL(dev::k_shadow, dim3(blocks), dim3(WAVES_PER_BLOCK * 64), 0, stream, A);
-		HIP_TRY(hipGetLastError());
-		return 0;
-	}
 	const int blocks = ((nPackets + 127) / 128) * 128;
 	SnailScene::RayDefer &R = s->rayDefer[s->rayCount++ % SnailScene::kDeferSlots];
 	if((size_t)nPackets + 16 > R.cap) { // grown synchronously when a larger batch than ever before arrives
@@ -1948,7 +1971,15 @@ int launchRays(SnailScene *s, bool shadow, int nPackets, int size, int sharedOri
 	if(R.used) HIP_TRY(hipStreamWaitEvent(stream, R.done, 0));
 	A.defer = R.p;
 	const int exactBlocks = A.fastOK ? (blocks < 8 ? blocks : 8) : (blocks < 2048 ? blocks : 2048);
-	if(sharedOrigin && mask) launchRaysKernels<true, true>(s, A, blocks, exactBlocks, stream);
+	if(shadow) {
+		if(useDeep(s)) {
+			hipLaunchKernelGGL(dev::k_shadow<true>, dim3(blocks), dim3(64), 0, stream, A);
+			hipLaunchKernelGGL(dev::k_shadow_exact<true>, dim3(exactBlocks), dim3(64), 0, stream, A);
+		} else {
+			hipLaunchKernelGGL(dev::k_shadow<false>, dim3(blocks), dim3(64), 0, stream, A);
+			hipLaunchKernelGGL(dev::k_shadow_exact<false>, dim3(exactBlocks), dim3(64), 0, stream, A);
+		}
+	} else if(sharedOrigin && mask) launchRaysKernels<true, true>(s, A, blocks, exactBlocks, stream);
 	else if(sharedOrigin) launchRaysKernels<true, false>(s, A, blocks, exactBlocks, stream);
 	else if(mask) launchRaysKernels<false, true>(s, A, blocks, exactBlocks, stream);
 	else launchRaysKernels<false, false>(s, A, blocks, exactBlocks, stream);
