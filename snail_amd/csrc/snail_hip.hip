@@ -1596,11 +1596,24 @@ __device__ __forceinline__ int convChannel(float c) { // Trunc(Clamp(c * 255, 0,
 	return (int)v;
 }
 __global__ __launch_bounds__(256) void k_shade_depth(const float *t, int nRays, unsigned char *bgr) {
-	const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+	const int i = (int)(blockIdx.x * 256 + threadIdx.x) * 4; // 4 rays per thread: one 16-B load, three 4-B stores (nRays is a multiple of 256)
 	if(i >= nRays) return;
-	const float dist = 1.0f / t[i];              // Condition(t > inf, 0, Inv(t)): the condition is never true
-	const int r = convChannel(dist * 20.0f), g = convChannel(dist * 250.0f), b = convChannel(dist * 2.0f);
-	bgr[(size_t)i * 3 + 0] = (unsigned char)b; bgr[(size_t)i * 3 + 1] = (unsigned char)g; bgr[(size_t)i * 3 + 2] = (unsigned char)r;
+	const float4 tv = *(const float4 *)(t + i);
+	const float tt[4] = {tv.x, tv.y, tv.z, tv.w};
+	unsigned bytes[12];
+#pragma unroll
+	for(int l = 0; l < 4; l++) {
+		const float dist = 1.0f / tt[l];         // Condition(t > inf, 0, Inv(t)): the condition is never true
+		bytes[l * 3 + 0] = (unsigned)convChannel(dist * 2.0f); bytes[l * 3 + 1] = (unsigned)convChannel(dist * 250.0f); bytes[l * 3 + 2] = (unsigned)convChannel(dist * 20.0f);
+	}
+	if(((unsigned long long)bgr & 3) == 0) {
+		unsigned *o = (unsigned *)(bgr + (size_t)i * 3);
+#pragma unroll
+		for(int k = 0; k < 3; k++) o[k] = bytes[4 * k] | (bytes[4 * k + 1] << 8) | (bytes[4 * k + 2] << 16) | (bytes[4 * k + 3] << 24);
+	} else {
+#pragma unroll
+		for(int k = 0; k < 12; k++) bgr[(size_t)i * 3 + k] = (unsigned char)bytes[k];
+	}
 }
 __global__ __launch_bounds__(256) void k_bgr_to_frame(const int2 *packetXY, int nPackets, int resx, int resy, const unsigned char *src,
 														unsigned char *frame, int pitch) {
@@ -1612,6 +1625,13 @@ __global__ __launch_bounds__(256) void k_bgr_to_frame(const int2 *packetXY, int 
 	if(yy >= resy) return;
 	const unsigned char *s = src + ((size_t)p * 256 + (size_t)lane * 4) * 3;
 	unsigned char *d = frame + (size_t)yy * pitch + (size_t)xx * 3;
+	if(xx + 3 < resx && (pitch & 3) == 0 && (((unsigned long long)frame | (unsigned long long)src) & 3) == 0) { // 4 pixels = three aligned dwords
+		const unsigned *sw = (const unsigned *)s;
+		unsigned *dw = (unsigned *)d;
+		const unsigned a = sw[0], b = sw[1], c = sw[2];
+		dw[0] = a; dw[1] = b; dw[2] = c;
+		return;
+	}
 	for(int l = 0; l < 4; l++)
 		if(xx + l < resx) { d[l * 3 + 0] = s[l * 3 + 0]; d[l * 3 + 1] = s[l * 3 + 1]; d[l * 3 + 2] = s[l * 3 + 2]; }
 }
@@ -2320,7 +2340,7 @@ int snail_shade_depth_dev(const float *t, int nPackets, uint8_t *bgr, void *stre
 	if(nPackets <= 0) return 0;
 	if(!t || !bgr) { snail_set_error("snail_shade_depth_dev: null buffer"); return 1; }
 	const int n = nPackets * 256;
-	hipLaunchKernelGGL(dev::k_shade_depth, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, n, bgr);
+	hipLaunchKernelGGL(dev::k_shade_depth, dim3((n / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, n, bgr);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
