@@ -91,6 +91,11 @@ int snail_trace_primary_dev(SnailScene *, const float cam[13], int resx, int res
  * [p*256 + q*4 + lane], i.e. exactly the Context arrays host shading reads (bary as two planes). */
 int snail_trace_packets_dev(SnailScene *, const float cam[13], int resx, int resy, const int32_t *d_packet_xy, int nPackets,
                             float *d_t, float *d_u, float *d_v, int32_t *d_triId, uint64_t *d_stats, void *stream);
+/* The same launch with the gVals[1] depth shading + ConvColor (src/scene_trace.cpp:128-137, src/render.cpp:11-17) fused into the
+ * kernel's epilogue: the only output is d_bgr, packet-major [nPackets][256][3] bytes (4-byte aligned) -- what a render node returns
+ * per tile.  Equal byte for byte to snail_trace_packets_dev followed by snail_shade_depth_dev. */
+int snail_trace_packets_shaded_dev(SnailScene *, const float cam[13], int resx, int resy, const int32_t *d_packet_xy, int nPackets,
+                                   uint8_t *d_bgr, uint64_t *d_stats, void *stream);
 /* Scatter packet-major planes into row-major resx*resy frame planes (clipped to the image). */
 int snail_packets_to_frame_dev(const int32_t *d_packet_xy, int nPackets, int resx, int resy,
                                const float *d_pt, const float *d_pu, const float *d_pv, const int32_t *d_pid,

@@ -33,6 +33,7 @@ SIGNATURES = {
     "snail_trace_primary": (_I, [_VP, _F13, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "snail_trace_primary_dev": (_I, [_VP, _F13, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "snail_trace_packets_dev": (_I, [_VP, _F13, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "snail_trace_packets_shaded_dev": (_I, [_VP, _F13, _I, _I, _VP, _I, _VP, _VP, _VP]),
     "snail_packets_to_frame_dev": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "snail_trace_rays": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "snail_trace_rays_dev": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),

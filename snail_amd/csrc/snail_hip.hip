@@ -871,6 +871,14 @@ __device__ __forceinline__ void flushStats(u64 *stats, const Counters &st, unsig
 	}
 }
 
+// Trunc(Clamp(c * 255, 0, 255)) of ConvColor (src/render.cpp:11-17); Clamp = Min(Max(v, lo), hi), veclib/vecbase.h:75-77
+__device__ __forceinline__ int convChannelW(float c) {
+	float v = c * 255.0f;
+	v = v > 0.0f ? v : 0.0f;
+	v = v < 255.0f ? v : 255.0f;
+	return (int)v;
+}
+
 // ---- primary kernel: RayGenerator::Generate + SafeInv + TraversePrimary<1,0> ----------------------
 struct GenConst {
 	float tright[3], tup[3], txyz[3][4], org[3];
@@ -888,6 +896,7 @@ struct PrimaryArgs {
 	int fastOK;
 	float *t, *u, *v;
 	int *id;
+	unsigned char *bgr; // packet-major B,G,R of the gVals[1] depth shading (src/scene_trace.cpp:128-137), 3 B/ray, or null
 	u64 *stats;
 	unsigned *cost; // diagnostic: per packet {iters, intersects, shader cycles, start time low bits}
 	int *defer;		// [0] = count, [1] = finished blocks of the M_EXACT pass, [2..] = logical indices of deferred packets
@@ -983,6 +992,17 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 		A.cost[(size_t)pidx * 4 + 2] = (unsigned)(tEnd - tStart); A.cost[(size_t)pidx * 4 + 3] = (unsigned)(tStart >> 6);
 	}
 
+	if(A.bgr) { // fused gVals[1] depth shading + ConvColor: c = Inv(t) * (20, 250, 2), bytes B,G,R (same operations as k_shade_depth)
+		unsigned bytes[12];
+#pragma unroll
+		for(int l = 0; l < 4; l++) {
+			const float dist = 1.0f / Q.dist[l];
+			bytes[l * 3 + 0] = (unsigned)convChannelW(dist * 2.0f); bytes[l * 3 + 1] = (unsigned)convChannelW(dist * 250.0f); bytes[l * 3 + 2] = (unsigned)convChannelW(dist * 20.0f);
+		}
+		unsigned *o = (unsigned *)(A.bgr + ((size_t)pidx * 256 + (size_t)lane * 4) * 3);
+#pragma unroll
+		for(int k = 0; k < 3; k++) o[k] = bytes[4 * k] | (bytes[4 * k + 1] << 8) | (bytes[4 * k + 2] << 16) | (bytes[4 * k + 3] << 24);
+	}
 	if(A.packetXY || A.packetMajor) { // packet-major (Context layout)
 		const size_t o = (size_t)pidx * 256 + (size_t)lane * 4;
 		if(A.t) *(float4 *)(A.t + o) = make_float4(Q.dist[0], Q.dist[1], Q.dist[2], Q.dist[3]);
@@ -1079,12 +1099,6 @@ struct ShadeArgs {
 	u64 *stats;
 };
 
-__device__ __forceinline__ int convChannelW(float c) {
-	float v = c * 255.0f;
-	v = v > 0.0f ? v : 0.0f;
-	v = v < 255.0f ? v : 255.0f;
-	return (int)v;
-}
 
 struct PacketPos {
 	int px, py;
@@ -1853,7 +1867,7 @@ int checkScene(const SnailScene *s, const char *fn) {
 
 int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0, int y0, int w, int h, const int32_t *dPacketXY,
 				  int nPackets, float *t, float *u, float *v, int32_t *id, uint64_t *dStats, hipStream_t stream, unsigned *dCost = nullptr,
-				  bool packetMajor = false) {
+				  bool packetMajor = false, uint8_t *dBgr = nullptr) {
 	if(resx <= 0 || resy <= 0) { snail_set_error("snail_trace_primary: bad resolution %dx%d", resx, resy); return 1; }
 	dev::PrimaryArgs A;
 	memset(&A, 0, sizeof(A));
@@ -1865,6 +1879,7 @@ int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0
 	A.stats = (dev::u64 *)dStats;
 	A.cost = dCost;
 	A.packetMajor = packetMajor ? 1 : 0;
+	A.bgr = dBgr;
 	A.pack = stackPack(s);
 	int blocks;
 	if(dPacketXY) {
@@ -2160,6 +2175,15 @@ int snail_trace_packets_dev(SnailScene *s, const float cam[13], int resx, int re
 	if(!dPacketXY && nPackets > 0) { snail_set_error("snail_trace_packets_dev: null packet list"); return 1; }
 	DeviceGuard guard(s->device);
 	return launchPrimary(s, cam, resx, resy, 0, 0, 0, 0, dPacketXY, nPackets, t, u, v, id, dStats, (hipStream_t)stream);
+}
+
+int snail_trace_packets_shaded_dev(SnailScene *s, const float cam[13], int resx, int resy, const int32_t *dPacketXY, int nPackets, uint8_t *bgr,
+								   uint64_t *dStats, void *stream) {
+	if(int rc = checkScene(s, "snail_trace_packets_shaded_dev")) return rc;
+	if((!dPacketXY || !bgr) && nPackets > 0) { snail_set_error("snail_trace_packets_shaded_dev: null buffer"); return 1; }
+	if((unsigned long long)bgr & 3) { snail_set_error("snail_trace_packets_shaded_dev: d_bgr must be 4-byte aligned"); return 1; }
+	DeviceGuard guard(s->device);
+	return launchPrimary(s, cam, resx, resy, 0, 0, 0, 0, dPacketXY, nPackets, nullptr, nullptr, nullptr, nullptr, dStats, (hipStream_t)stream, nullptr, false, bgr);
 }
 
 int snail_packets_to_frame_dev(const int32_t *dPacketXY, int nPackets, int resx, int resy, const float *pt, const float *pu, const float *pv,

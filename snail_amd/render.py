@@ -149,12 +149,10 @@ class DistributedRenderer:
         if self.multi:
             n = self.plan.padded
             self.packet_xy = torch.from_numpy(self.plan.padded_packets(rank)).to(dev)
-            # per slot one buffer [4, n, 256] (t, u, v, triId) so that the four planes can travel in ONE collective (payload "hits")
-            self.local = [torch.empty((4, n, 256), dtype=torch.float32, device=dev) for _ in range(self.nslots)]
             if payload == "hits":
+                # per slot one buffer [4, n, 256] (t, u, v, triId) so that the four planes can travel in ONE collective
+                self.local = [torch.empty((4, n, 256), dtype=torch.float32, device=dev) for _ in range(self.nslots)]
                 self.planes = [(b[0], b[1], b[2], b[3].view(torch.int32)) for b in self.local]
-            else:   # the depth shader consumes t only: the kernel neither derives nor stores u, v, triId
-                self.planes = [(b[0], None, None, None) for b in self.local]
             self.bgr = [torch.empty((n, 256, 3), dtype=torch.uint8, device=dev) for _ in range(self.nslots)]
             if rank == 0:
                 self.all_xy = [torch.from_numpy(self.plan.padded_packets(r)).to(dev) for r in range(world_size)]
@@ -202,7 +200,10 @@ class DistributedRenderer:
                 return out
             self._finish(slot)                       # the slot's buffers are free again after this
             if events: events[0].record(st)
-            sc.trace_packets(cam, p.resx, p.resy, self.packet_xy, out=self.planes[slot], stats=stats, stream=st)
+            if self.payload == "hits":
+                sc.trace_packets(cam, p.resx, p.resy, self.packet_xy, out=self.planes[slot], stats=stats, stream=st)
+            else:   # rgb8 payload: the depth shading is fused into the traversal kernel's epilogue
+                sc.trace_packets_shaded(cam, p.resx, p.resy, self.packet_xy, out=self.bgr[slot], stats=stats, stream=st)
             if events: events[1].record(st)
             if self.payload == "hits":
                 gather_planes(self.local[slot], self.rank, self.world, self.group, self.gathered[slot] if self.rank == 0 else None)
@@ -211,7 +212,6 @@ class DistributedRenderer:
                         g = self.gathered[slot][r]
                         sc.packets_to_frame(self.all_xy[r], (g[0], g[1], g[2], g[3].view(torch.int32)), self.frame, stream=st)
                 return self.frame
-            sc.shade_depth(self.planes[slot][0], out=self.bgr[slot], stream=st)
             if self.stage_cpu:
                 # rehearsal transport: same buffers and the same completion path as the RCCL route, bytes moved through the host
                 host = self.bgr[slot].cpu()                      # synchronises the slot stream

@@ -190,6 +190,19 @@ class Scene:
         _lib.check(rc, "snail_trace_packets_dev")
         return out
 
+    def trace_packets_shaded(self, cam: Camera, resx: int, resy: int, packet_xy, out=None, stats=None, stream=None):
+        """trace_packets with the gVals[1] depth shading fused into the kernel: returns packet-major [n,256,3] uint8 (B,G,R), equal
+        to shade_depth(trace_packets(...)[0]) byte for byte."""
+        torch = _torch()
+        n = int(packet_xy.shape[0])
+        if out is None:
+            out = torch.empty((n, 256, 3), dtype=torch.uint8, device=self._dev())
+        cam13 = np.ascontiguousarray(cam.as_array13(), dtype=np.float32)
+        rc = _lib.lib().snail_trace_packets_shaded_dev(self._h, _lib.ptr(cam13), resx, resy, _lib.ptr(packet_xy), n, _lib.ptr(out), _lib.ptr(stats),
+                                                       _stream_ptr(stream))
+        _lib.check(rc, "snail_trace_packets_shaded_dev")
+        return out
+
     @staticmethod
     def packets_to_frame(packet_xy, planes, frame: HitFrame, stream=None):
         resy, resx = frame.t.shape

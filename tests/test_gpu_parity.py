@@ -363,6 +363,7 @@ def test_depth_shading_and_tile_pipeline(torch_mod):
             xy = torch_mod.from_numpy(plan.padded_packets(r)).cuda()
             planes = sc.trace_packets(cam, resx, resy, xy)
             bgr = sc.shade_depth(planes[0])
+            assert torch_mod.equal(sc.trace_packets_shaded(cam, resx, resy, xy), bgr)      # the fused kernel epilogue
             sc.packets_bgr_to_frame(xy, bgr, frame)
         torch_mod.cuda.synchronize()
         got = frame.cpu().numpy()
