@@ -6,7 +6,8 @@
  * `template <class AccStruct> class Scene` (src/scene.h:26-58) and, one level up, the tile API of
  * src/render.h:16-28.  A per-packet GPU call (256 rays) would be launch-latency bound, so this
  * boundary sits at frame / tile / packet-batch granularity; include/snail_adapter.hpp re-exposes the
- * reference's own shapes (an AccStruct-conforming class and Render(...) overloads) on top of it.
+ * reference's own shapes on top of it (an AccStruct-conforming class, with which the reference's own
+ * Render<AccStruct> / Scene<AccStruct> templates instantiate unchanged, and a frame-granular TraceFrame).
  *
  * Conventions: plain pointers and sizes only; every function returns 0 on success and a non-zero
  * status on failure with the text available from snail_last_error() (the reference aborts through
