@@ -731,3 +731,14 @@ def test_fuzzed_cameras_and_frame_sizes(torch_mod, name):
         assert np.array_equal(img.cpu().numpy(), wimg), (name, case, int((img.cpu().numpy() != wimg).sum()))
         assert np.array_equal(stats.cpu().numpy().astype(np.uint64), wst), (name, case, stats.cpu().numpy(), wst)
     sc.close()
+
+
+def test_many_streams_share_one_scene_handle(torch_mod):
+    """tools/stress_streams.py: 600 launches over 6 HIP streams mixing every device entry point on one scene handle (the round-robin
+    scratch slots and their events), every result equal to the one computed alone."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_streams.py"), "600"], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and "mismatches: 0" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
