@@ -165,7 +165,11 @@ int snail_planar_to_frame_dev(const int32_t *d_tiles, const int64_t *d_in_offset
  * origin of lanes the mirrored packet masks off (no primary hit; uninitialised or non-finite in the reference) are zeros: such
  * a lane has distance -inf and is culled by every box test, so a finite value there cannot influence a result.
  * d_stats[2] += primary rays + mirrored lanes + shadow lanes with N.L > 0.  The frame is shaded in stages over packet-major
- * intermediates held by the scene handle (8 frames may be in flight on different streams). */
+ * intermediates held by the scene handle (8 frames may be in flight on different streams).
+ * Store: every pixel inside resx x resy gets its own colour.  (For a tile width that is not a multiple of 4 the reference's
+ * interleaved store copies the FIRST pixel's colour into the other 1-2 pixels of the row's last quad and writes one byte past
+ * them, src/render.cpp:183-188 -- an artefact of its 4-byte writes that is not reproduced; widths that are multiples of 4, which
+ * is what its server demands (src/server.cpp:227-231), are byte-identical.) */
 #define SNAIL_WHITTED_REFLECTIONS 1
 int snail_render_whitted_dev(SnailScene *, const float cam[13], int resx, int resy, const float *lights7, int nLights,
                              const float ambient[3], const float color[3], int flags, uint8_t *d_frame_bgr, int pitch, uint64_t *d_stats,
