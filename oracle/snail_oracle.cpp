@@ -356,7 +356,7 @@ struct Stats { uint64_t intersects = 0, iters = 0, rays = 0, skips = 0; };
 
 struct StackElem { int node; short first, last; };
 
-// optional instrumentation (tools/range_hist.py): [0,64) inner visits by (last-first) on entry, [64,128) leaf visits likewise,
+// optional instrumentation (tests/range_hist.py): [0,64) inner visits by (last-first) on entry, [64,128) leaf visits likewise,
 // [128,192) leaf visits by (last-first) after the box test.  Single-threaded use only.
 uint64_t *g_rangeHist = nullptr;
 

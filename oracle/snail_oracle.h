@@ -120,7 +120,7 @@ void orc_render_whitted(const OrcNode *nodes, const OrcTri *tris, const OrcCamer
 void orc_planar_encode_tile(const uint8_t *frame_bgr, int pitch, int x, int y, int w, int h, uint8_t *out);
 void orc_planar_decode_tile(const uint8_t *planes, int x, int y, int w, int h, uint8_t *frame_bgr, int pitch);
 
-/* instrumentation for tools/range_hist.py: hist[192] (see snail_oracle.cpp); NULL switches it off. Single-threaded only. */
+/* instrumentation for tests/range_hist.py: hist[192] (see snail_oracle.cpp); NULL switches it off. Single-threaded only. */
 void orc_debug_range_hist(uint64_t *hist);
 
 /* arithmetic primitives exposed for the veclib pin test */

@@ -1,5 +1,5 @@
 """Histogram of the active quad range (last-first+1) at node and leaf visits of primary packets, from the oracle's
-instrumented walk (test infrastructure; single-threaded).  Usage: python tools/range_hist.py [scene] [resx resy]"""
+instrumented walk (test infrastructure; single-threaded).  Usage: python tests/range_hist.py [scene] [resx resy]"""
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
