@@ -175,6 +175,12 @@ int snail_render_whitted_dev(SnailScene *, const float cam[13], int resx, int re
                              const float ambient[3], const float color[3], int flags, uint8_t *d_frame_bgr, int pitch, uint64_t *d_stats,
                              void *stream);
 
+/* The same for an explicit list of packets (a rank's tiles): output = packet-major B,G,R bytes [nPackets][256][3] (4-byte aligned),
+ * to be gathered and scattered with snail_packets_bgr_to_frame_dev -- a render node with the reference's simple shading on. */
+int snail_render_whitted_packets_dev(SnailScene *, const float cam[13], int resx, int resy, const int32_t *d_packet_xy, int nPackets,
+                                     const float *lights7, int nLights, const float ambient[3], const float color[3], int flags,
+                                     uint8_t *d_bgr_packets, uint64_t *d_stats, void *stream);
+
 /* ---- measurement support ------------------------------------------------------------------------- */
 /* Single-ray, cache-less accounting walk of SURVEY.md section 8(d) over the same padded packet set as
  * snail_trace_primary: d_out[0] += rays, [1] += sum V_n (node boxes tested), [2] += sum V_t

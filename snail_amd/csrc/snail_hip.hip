@@ -1079,6 +1079,9 @@ struct ShadeArgs {
 	const uint4 *nodes, *tris;
 	GenConst g;
 	int resx, resy, pw, ph, fastOK;
+	const int2 *packetXY; // explicit packet list (tile sharding): packet li = packetXY[li], intermediates and output indexed by li; or null = the frame's grid
+	int nPackets;        // packet slots of the intermediates: list length, or pw * ph
+	unsigned char *bgrPackets; // list mode: packet-major B,G,R output [nPackets][256][3] instead of the frame
 	int nBlocks;         // grid.x of the per-packet kernels (packets padded to whole XCD regions)
 	int pack;            // at most 2^20 node slots: one-word stack entries in the hand-written walks
 	int nLights;
@@ -1106,10 +1109,17 @@ struct PacketPos {
 	bool valid;
 };
 __device__ __forceinline__ PacketPos packetOf(const ShadeArgs &A, int li) {
+	PacketPos P;
+	if(A.packetXY) {
+		P.valid = li < A.nPackets;
+		const int2 xy = A.packetXY[P.valid ? li : 0];
+		P.px = __builtin_amdgcn_readfirstlane(xy.x); P.py = __builtin_amdgcn_readfirstlane(xy.y);
+		P.pidx = (size_t)li;
+		return P;
+	}
 	const int nrx = (A.pw + 3) >> 2;
 	const int region = li >> 4, kk = li & 15;
 	const int cx = (region % nrx) * 4 + (kk & 3), cy = (region / nrx) * 4 + (kk >> 2);
-	PacketPos P;
 	P.valid = cx < A.pw && cy < A.ph;
 	P.px = cx * 16; P.py = cy * 16;
 	P.pidx = (size_t)cy * A.pw + cx;
@@ -1272,7 +1282,7 @@ __device__ __forceinline__ void lightPacket(const ShadeArgs &A, const int li, co
 		else walkSharedAsm<true, false, false, false, false, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st, 0);
 	}
 	flushStats(A.stats, st, rays, lane);
-	const size_t packets = (size_t)A.pw * A.ph;
+	const size_t packets = (size_t)A.nPackets;
 	*(float4 *)(A.sDist + ((size_t)n * packets + P.pidx) * 256 + (size_t)lane * 4) = make_float4(Q.dist[0], Q.dist[1], Q.dist[2], Q.dist[3]);
 }
 
@@ -1352,7 +1362,7 @@ __global__ __launch_bounds__(64) void k_final(ShadeArgs A) {
 	if(A.nLights) {
 		float tMin[3], tMax[3];
 		hitBounds(S, tMin, tMax);
-		const size_t packets = (size_t)A.pw * A.ph;
+		const size_t packets = (size_t)A.nPackets;
 		for(int n = 0; n < A.nLights; n++) {
 			const float lp[3] = {A.lights[n][0], A.lights[n][1], A.lights[n][2]};
 			const float lc[3] = {A.lights[n][3], A.lights[n][4], A.lights[n][5]};
@@ -1403,12 +1413,18 @@ __global__ __launch_bounds__(64) void k_final(ShadeArgs A) {
 		}
 		return;
 	}
+	unsigned bytes[12];
+#pragma unroll
+	for(int l = 0; l < 4; l++) { bytes[l * 3 + 0] = (unsigned)convChannelW(col[2][l]); bytes[l * 3 + 1] = (unsigned)convChannelW(col[1][l]); bytes[l * 3 + 2] = (unsigned)convChannelW(col[0][l]); }
+	if(A.bgrPackets) { // tile sharding: packet-major bytes, what a render node returns (scattered by snail_packets_bgr_to_frame_dev)
+		unsigned *o = (unsigned *)(A.bgrPackets + (quad * 4) * 3);
+#pragma unroll
+		for(int k = 0; k < 3; k++) o[k] = bytes[4 * k] | (bytes[4 * k + 1] << 8) | (bytes[4 * k + 2] << 16) | (bytes[4 * k + 3] << 24);
+		return;
+	}
 	const int yy = P.py + (lane >> 2), xx = P.px + (lane & 3) * 4;
 	if(yy < A.resy) {
 		unsigned char *dd = A.frame + (size_t)yy * A.pitch + (size_t)xx * 3;
-		unsigned bytes[12];
-#pragma unroll
-		for(int l = 0; l < 4; l++) { bytes[l * 3 + 0] = (unsigned)convChannelW(col[2][l]); bytes[l * 3 + 1] = (unsigned)convChannelW(col[1][l]); bytes[l * 3 + 2] = (unsigned)convChannelW(col[0][l]); }
 		if(xx + 3 < A.resx && (A.pitch & 3) == 0 && ((unsigned long long)A.frame & 3) == 0) { // 4 pixels = 12 bytes = three aligned dwords (xx is a multiple of 4)
 			unsigned w[3];
 #pragma unroll
@@ -2306,14 +2322,16 @@ int snail_trace_shadow(SnailScene *s, int nPackets, int size, const float *origi
 	return 0;
 }
 
-int snail_render_whitted_dev(SnailScene *s, const float cam[13], int resx, int resy, const float *lights7, int nLights, const float ambient[3],
-							 const float color[3], int flags, uint8_t *frame, int pitch, uint64_t *dStats, void *stream) {
-	if(int rc = checkScene(s, "snail_render_whitted_dev")) return rc;
-	if(resx <= 0 || resy <= 0 || !frame || pitch < resx * 3 || nLights < 0 || nLights > SNAIL_MAX_LIGHTS || (nLights && !lights7) || !ambient || !color ||
-	   (flags & ~SNAIL_WHITTED_REFLECTIONS)) {
-		snail_set_error("snail_render_whitted_dev: bad arguments (at most %d lights; flags = SNAIL_WHITTED_REFLECTIONS or 0)", SNAIL_MAX_LIGHTS);
+static int renderWhitted(const char *fn, SnailScene *s, const float cam[13], int resx, int resy, const int32_t *dPacketXY, int nPacketsList, const float *lights7,
+						 int nLights, const float ambient[3], const float color[3], int flags, uint8_t *frame, int pitch, uint8_t *bgrPackets, uint64_t *dStats,
+						 void *stream) {
+	if(int rc = checkScene(s, fn)) return rc;
+	if(resx <= 0 || resy <= 0 || nLights < 0 || nLights > SNAIL_MAX_LIGHTS || (nLights && !lights7) || !ambient || !color || (flags & ~SNAIL_WHITTED_REFLECTIONS) ||
+	   (dPacketXY ? (!bgrPackets || ((unsigned long long)bgrPackets & 3)) : (!frame || pitch < resx * 3))) {
+		snail_set_error("%s: bad arguments (at most %d lights; flags = SNAIL_WHITTED_REFLECTIONS or 0; 4-byte aligned output)", fn, SNAIL_MAX_LIGHTS);
 		return 1;
 	}
+	if(dPacketXY && nPacketsList <= 0) return 0;
 	DeviceGuard guard(s->device);
 	const bool refl = (flags & SNAIL_WHITTED_REFLECTIONS) != 0;
 	dev::ShadeArgs A;
@@ -2327,9 +2345,17 @@ int snail_render_whitted_dev(SnailScene *s, const float cam[13], int resx, int r
 	for(int n = 0; n < nLights; n++) for(int k = 0; k < 7; k++) A.lights[n][k] = lights7[n * 7 + k];
 	for(int c = 0; c < 3; c++) { A.ambient[c] = ambient[c]; A.color[c] = color[c]; }
 	A.frame = frame; A.pitch = pitch; A.stats = (dev::u64 *)dStats;
-	const int packets = A.pw * A.ph;
-	const int nRegions = ((A.pw + 3) / 4) * ((A.ph + 3) / 4);
-	const int blocks = ((nRegions + 7) / 8) * 8 * 16;
+	A.packetXY = (const int2 *)dPacketXY; A.bgrPackets = bgrPackets;
+	int packets, blocks;
+	if(dPacketXY) {
+		packets = nPacketsList;
+		blocks = ((packets + 127) / 128) * 128;
+	} else {
+		packets = A.pw * A.ph;
+		const int nRegions = ((A.pw + 3) / 4) * ((A.ph + 3) / 4);
+		blocks = ((nRegions + 7) / 8) * 8 * 16;
+	}
+	A.nPackets = packets;
 	A.nBlocks = blocks;
 	SnailScene::ShadeScratch &W = s->shade[s->shadeCount++ % SnailScene::kDeferSlots];
 	if(int rc = shadeScratch(s, W, (size_t)packets, (size_t)blocks, refl)) return rc;
@@ -2342,8 +2368,10 @@ int snail_render_whitted_dev(SnailScene *s, const float cam[13], int resx, int r
 	A.defer = W.defer;
 	const hipStream_t st = (hipStream_t)stream;
 	const dim3 grid(blocks), wave(64);
-	// the primary packets (the bench kernel), hit records packet-major in grid order
-	if(int rc = launchPrimary(s, cam, resx, resy, 0, 0, resx, resy, nullptr, 0, W.hitT, nullptr, nullptr, W.hitId, dStats, st, nullptr, true)) return rc;
+	// the primary packets (the bench kernel), hit records packet-major
+	if(dPacketXY) {
+		if(int rc = launchPrimary(s, cam, resx, resy, 0, 0, 0, 0, dPacketXY, packets, W.hitT, nullptr, nullptr, W.hitId, dStats, st)) return rc;
+	} else if(int rc = launchPrimary(s, cam, resx, resy, 0, 0, resx, resy, nullptr, 0, W.hitT, nullptr, nullptr, W.hitId, dStats, st, nullptr, true)) return rc;
 	if(refl) { // the nested RayTrace of the mirrored packets
 		hipLaunchKernelGGL((dev::k_final<dev::SRC_PRIMARY, dev::DST_MIRROR>), grid, wave, 0, st, A);
 		HIP_TRY(hipGetLastError());
@@ -2358,6 +2386,19 @@ int snail_render_whitted_dev(SnailScene *s, const float cam[13], int resx, int r
 	HIP_TRY(hipEventRecord(W.done, st));
 	W.used = true;
 	return 0;
+}
+
+int snail_render_whitted_dev(SnailScene *s, const float cam[13], int resx, int resy, const float *lights7, int nLights, const float ambient[3],
+							 const float color[3], int flags, uint8_t *frame, int pitch, uint64_t *dStats, void *stream) {
+	return renderWhitted("snail_render_whitted_dev", s, cam, resx, resy, nullptr, 0, lights7, nLights, ambient, color, flags, frame, pitch, nullptr, dStats, stream);
+}
+
+int snail_render_whitted_packets_dev(SnailScene *s, const float cam[13], int resx, int resy, const int32_t *dPacketXY, int nPackets, const float *lights7,
+									 int nLights, const float ambient[3], const float color[3], int flags, uint8_t *bgrPackets, uint64_t *dStats, void *stream) {
+	if(!dPacketXY && nPackets > 0) { snail_set_error("snail_render_whitted_packets_dev: null packet list"); return 1; }
+	if(nPackets <= 0) return 0;
+	return renderWhitted("snail_render_whitted_packets_dev", s, cam, resx, resy, dPacketXY, nPackets, lights7, nLights, ambient, color, flags, nullptr, 0, bgrPackets,
+						 dStats, stream);
 }
 
 int snail_shade_depth_dev(const float *t, int nPackets, uint8_t *bgr, void *stream) {

@@ -124,7 +124,8 @@ class DistributedRenderer:
     overlaps both.  flush() completes the frames still in flight."""
 
     def __init__(self, scene, resx: int, resy: int, rank: int = 0, world_size: int = 1, group=None, seed: int = 20090501,
-                 payload: str = "rgb8", slots: int = 3, stage_cpu: bool = False, force_collective: bool = False):
+                 payload: str = "rgb8", slots: int = 3, stage_cpu: bool = False, force_collective: bool = False, lights7=None,
+                 ambient=(0.1, 0.1, 0.1), color=(1.0, 1.0, 1.0), reflections: bool = False):
         import torch
         self.torch = torch
         self.scene = scene
@@ -134,6 +135,9 @@ class DistributedRenderer:
         # stage_cpu: move the payload through host memory so that a CPU backend (gloo) can carry the collective --
         # used to rehearse the multi-rank path on a box whose ranks share one GPU; the product path is RCCL on device buffers
         self.stage_cpu = stage_cpu
+        # lights7 given: the rgb8 tiles are shaded with the reference's simple shading + point lights (Scene.render_whitted_packets,
+        # BASELINE config 3, optionally with the mirrored bounce) instead of the depth shading
+        self.lights7, self.ambient, self.color, self.reflections = lights7, ambient, color, reflections
         # force_collective: run the tile plan + shade + gather + scatter route even with ONE rank (the collective then moves rank 0's
         # buffer to itself) -- lets a single-GPU box exercise the RCCL code path of the multi-GPU bench
         self.multi = world_size > 1 or force_collective
@@ -202,6 +206,9 @@ class DistributedRenderer:
             if events: events[0].record(st)
             if self.payload == "hits":
                 sc.trace_packets(cam, p.resx, p.resy, self.packet_xy, out=self.planes[slot], stats=stats, stream=st)
+            elif self.lights7 is not None:   # rgb8 payload, config-3 shading
+                sc.render_whitted_packets(cam, p.resx, p.resy, self.packet_xy, self.lights7, self.ambient, self.color, out=self.bgr[slot], stats=stats,
+                                          stream=st, reflections=self.reflections)
             else:   # rgb8 payload: the depth shading is fused into the traversal kernel's epilogue
                 sc.trace_packets_shaded(cam, p.resx, p.resy, self.packet_xy, out=self.bgr[slot], stats=stats, stream=st)
             if events: events[1].record(st)

@@ -278,6 +278,21 @@ class Scene:
         _lib.check(rc, "snail_render_whitted_dev")
         return out
 
+    def render_whitted_packets(self, cam: Camera, resx: int, resy: int, packet_xy, lights7, ambient=(0.1, 0.1, 0.1), color=(1.0, 1.0, 1.0), out=None,
+                               stats=None, stream=None, reflections: bool = False):
+        """render_whitted for an explicit packet list (a rank's tiles): packet-major [n,256,3] uint8 (B,G,R)."""
+        torch = _torch()
+        n = int(packet_xy.shape[0])
+        if out is None:
+            out = torch.empty((n, 256, 3), dtype=torch.uint8, device=self._dev())
+        lights = np.ascontiguousarray(lights7, dtype=np.float32).reshape(-1, 7)
+        cam13 = np.ascontiguousarray(cam.as_array13(), dtype=np.float32)
+        amb = np.ascontiguousarray(ambient, dtype=np.float32); col = np.ascontiguousarray(color, dtype=np.float32)
+        rc = _lib.lib().snail_render_whitted_packets_dev(self._h, _lib.ptr(cam13), resx, resy, _lib.ptr(packet_xy), n, _lib.ptr(lights), len(lights),
+                                                         _lib.ptr(amb), _lib.ptr(col), 1 if reflections else 0, _lib.ptr(out), _lib.ptr(stats), _stream_ptr(stream))
+        _lib.check(rc, "snail_render_whitted_packets_dev")
+        return out
+
     def trace_primary_host(self, cam: Camera, resx: int, resy: int, rect=None):
         """Host-buffer entry point (what a C++ host would call): numpy planes in, numpy planes out."""
         x0, y0, w, h = rect if rect is not None else (0, 0, resx, resy)

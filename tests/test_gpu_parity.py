@@ -742,3 +742,31 @@ def test_many_streams_share_one_scene_handle(torch_mod):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_streams.py"), "600"], capture_output=True, text=True, timeout=300, cwd=root)
     assert r.returncode == 0 and "mismatches: 0" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_config3_shading_through_the_tile_plan(torch_mod):
+    """BASELINE configs 3 x 4: the staged config-3 pipeline on each rank's packet list (with the mirrored bounce), gathered and
+    scattered like the depth-shaded tiles -- for 1, 2 and 3 ranks on this GPU the frame and the summed counters equal the oracle's."""
+    from snail_amd import render as R
+    name = "atrium:0.05"
+    tv, sc, osc = gpu_scene(name)
+    cam = util.camera_for(name, tv)
+    resx, resy = 328, 200
+    bmin, bmax = osc.nodes[0]["bmin"], osc.nodes[0]["bmax"]
+    c, e = (bmin + bmax) * 0.5, (bmax - bmin)
+    lights = np.array([[c[0], c[1] + 0.35 * e[1], c[2], 1.0, 0.9, 0.8, 2.0 * float(e.max())]], dtype=np.float32)
+    for refl in (False, True):
+        want, wst = osc.render_whitted(cam.as_array13(), resx, resy, lights, mode=O.MODE_IEEE, reflections=refl)
+        for world in (1, 2, 3):
+            plan = R.ShardPlan.make(resx, resy, world)
+            frame = torch_mod.zeros((resy, resx, 3), dtype=torch_mod.uint8, device="cuda")
+            stats = sc.new_stats()
+            for r in range(world):
+                xy = torch_mod.from_numpy(plan.packets[r]).cuda()          # unpadded: every packet exactly once, so the counters add up
+                bgr = sc.render_whitted_packets(cam, resx, resy, xy, lights, stats=stats, reflections=refl)
+                sc.packets_bgr_to_frame(xy, bgr, frame)
+            torch_mod.cuda.synchronize()
+            got = frame.cpu().numpy()
+            assert np.array_equal(got, want), (refl, world, int((got != want).sum()))
+            assert np.array_equal(stats.cpu().numpy().astype(np.uint64), wst), (refl, world, stats.cpu().numpy(), wst)
+    sc.close()
