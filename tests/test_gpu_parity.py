@@ -643,6 +643,13 @@ def test_gpu_lbvh_builder_option(torch_mod, name, max_leaf):
     src2 = sc_sah.bvh.perm[fs.tri_id.cpu().numpy()[hit]]
     assert (src1 == src2).mean() > 0.995
     assert sc.build_ms > 0.0
+    # the downloaded arrays are a valid input for snail_scene_create (unused slots are empty leaves): re-upload, same picture
+    from snail_amd.scene import Scene as _Scene
+    sc2 = _Scene(sc.bvh, 0)
+    fr2 = sc2.trace_primary(cam, resx, resy)
+    torch_mod.cuda.synchronize()
+    assert torch_mod.equal(fr2.t, fr.t) and torch_mod.equal(fr2.tri_id, fr.tri_id)
+    sc2.close()
     sc.close()
     sc_sah.close()
 
