@@ -1,0 +1,52 @@
+"""Seeded soak of the generic entry points (not collected by pytest): random batches of secondary packets (shared / per-ray origins,
+lane masks, packet sizes 1..64, optional non-finite poison -> M_EXACT deferral) and shadow packets, GPU against the oracle bit for bit.
+Usage: python tests/soak_rays.py [batches] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from snail_amd.scene import Scene, Context, ShadowContext
+from tests import oracle_lib as O, util
+
+batches = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.RandomState(seed)
+names = ["atrium:0.05", "stress:0.05", "chain"]
+scn = {}
+for n in names:
+    tv, hb, osc = util.scene_pair(n)
+    scn[n] = (tv, Scene(hb, 0), osc, util.camera_for(n, tv))
+tt = torch.from_numpy
+bad = 0; t0 = time.time()
+for b in range(batches):
+    name = names[rng.randint(len(names))]
+    tv, sc, osc, cam = scn[name]
+    size = int([64, 64, 64, 16, 1, rng.randint(1, 65)][rng.randint(6)])
+    npk = int(rng.randint(1, 40))
+    if rng.rand() < 0.7:
+        shared, masked, poison = bool(rng.rand() < 0.5), bool(rng.rand() < 0.5), bool(rng.rand() < 0.15)
+        if poison and size < 3: poison = False
+        origin, dirs, idir, mask, dist, obj, bary = util.secondary_packets(osc, cam, 640, 368, npk, seed=int(rng.randint(1 << 30)), shared=shared, masked=masked,
+                                                                           size=size, poison=poison)
+        d2, o2, b2 = dist.copy(), obj.copy(), bary.copy()
+        ost = osc.trace_rays(origin, dirs, idir, mask, d2, o2, b2, npk, size, shared, mode=O.MODE_IEEE)
+        ctx = Context(tt(origin).cuda(), tt(dirs).cuda(), tt(idir).cuda(), tt(dist.copy()).cuda(), tt(obj.copy()).cuda(), tt(bary.copy()).cuda(),
+                      size=size, shared_origin=shared, mask=None if mask is None else tt(mask).cuda())
+        st = sc.new_stats(); sc.traverse_primary(ctx, stats=st); torch.cuda.synchronize()
+        s = st.cpu().numpy().astype(np.uint64)
+        ok = (np.array_equal(ctx.object.cpu().numpy(), o2) and np.array_equal(ctx.distance.cpu().numpy().view(np.uint32), d2.view(np.uint32)) and
+              np.array_equal(ctx.barycentric.cpu().numpy().view(np.uint32), b2.view(np.uint32)) and s[0] == ost[0] and s[1] == ost[1])
+        what = "rays shared=%s masked=%s size=%d poison=%s npk=%d" % (shared, masked, size, poison, npk)
+    else:
+        origin, dirs, idir, dist = util.shadow_packets(osc, npk, seed=int(rng.randint(1 << 30)), size=size)
+        d2 = dist.copy()
+        ost = osc.trace_shadow(origin, dirs, idir, d2, npk, size, mode=O.MODE_IEEE)
+        ctx = ShadowContext(tt(origin).cuda(), tt(dirs).cuda(), tt(idir).cuda(), tt(dist.copy()).cuda(), size=size)
+        st = sc.new_stats(); sc.traverse_shadow(ctx, stats=st); torch.cuda.synchronize()
+        s = st.cpu().numpy().astype(np.uint64)
+        ok = np.array_equal(ctx.distance.cpu().numpy().view(np.uint32), d2.view(np.uint32)) and s[0] == ost[0] and s[1] == ost[1] and s[3] == ost[3]
+        what = "shadow size=%d npk=%d" % (size, npk)
+    if not ok:
+        bad += 1; print("MISMATCH batch %d %s: %s" % (b, name, what), flush=True)
+    if b % 200 == 199: print("%d batches, %d mismatches, %.0f s" % (b + 1, bad, time.time() - t0), flush=True)
+print("done: %d batches, %d mismatches" % (batches, bad))
+sys.exit(1 if bad else 0)
