@@ -757,7 +757,7 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes, c
 	const int signBits = __builtin_amdgcn_readfirstlane((Q.d[0][0] < 0.0f ? 1 : 0) | (Q.d[1][0] < 0.0f ? 2 : 0) | (Q.d[2][0] < 0.0f ? 4 : 0));
 	const int sign16 = signBits << 16;
 	const u64 nodeBase = (u64)nodes;
-	int stkN = PACK ? ((size - 1) << 26) : 0, stkF = (size - 1) << 8; // slot 0 = the root with the full quad range
+	int stkN = PACK ? (int)((unsigned)(size - 1) << 26) : 0, stkF = (size - 1) << 8; // slot 0 = the root with the full quad range
 	int sp = 1, first = 0, last = size - 1, cnt = 0;
 	for(;;) {
 		int leafSub, leafAux, sCur, sFl, sOff, sWidth;
