@@ -461,14 +461,13 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 		st.iters++;
 		const bool isLeaf = (n.sub & 0x80000000u) != 0;
 		// children are adjacent (src/bvh/tree.cpp:153-157); near = firstNode ^ sign[axis] (src/bvh/traverse.cpp:71-74).
-		// The near child's record is fetched NOW (one scalar load, in flight during the box test) and simply
-		// dropped if this node is culled or is a leaf (then index 0, the root: always valid, always cached).
+		// The near child's record is requested here (for a leaf: index 0, the root, always valid); the compiler is free to sink
+		// the load into the descend branch and does -- measured either way, the waves wait for the VALU pipe, not for this load.
 		const int axis = n.aux & 0xffff;
 		const int firstNode = ((n.aux >> 16) ^ (signBits >> axis)) & 1;
 		const int nearIdx = isLeaf ? 0 : (int)n.sub + firstNode;
 		const int farIdx = (int)n.sub + (firstNode ^ 1);
 		const Node nn = loadNode(nodes, nearIdx);
-		__builtin_amdgcn_sched_barrier(0); // keep the fetch ahead of the slab arithmetic it overlaps with
 
 		// ---- BBox::TestInterval + BBox::Test (src/bounding_box.cpp:208-236, :61-142 / :144-200) ----
 		u64 passMask = 0; // quads with a surviving lane (before clipping to [first,last])
