@@ -178,3 +178,15 @@ def test_cpp_adapter_compiles_and_links(tmp_path):
     exe = build_adapter_mock(tmp_path)
     out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
     assert "compiled and linked" in out
+
+
+def test_tile_layout_offsets():
+    """Scene.tile_layout: first packet and byte offset of each tile's planes when tiles are stored back to back (render.tile_packets order)."""
+    from snail_amd import render as R
+    from snail_amd.scene import Scene
+    tiles = R.divide_image(40, 100)                       # 16x64 tiles with partial right / bottom tiles
+    first, off, total = Scene.tile_layout(tiles)
+    npk = [((w + 15) // 16) * ((h + 15) // 16) for _, _, w, h in tiles.tolist()]
+    assert first.tolist() == np.concatenate([[0], np.cumsum(npk)[:-1]]).tolist()
+    assert off.tolist() == np.concatenate([[0], np.cumsum([3 * w * h for _, _, w, h in tiles.tolist()])[:-1]]).tolist()
+    assert total == 3 * 40 * 100 and len(R.tile_packets(tiles)) == sum(npk)
