@@ -32,6 +32,11 @@ SSE arithmetic mode = what the reference executes on x86) timed on this box's ho
 only, on whole frames of the same workload until ~15 CPU-core-seconds are spent."""
 from __future__ import annotations
 
+import os
+# four frames in flight want four hardware queues of their own: with the runtime's default of 4 queues per process, streams share
+# queues with each other and with the runtime's own work (measured: 20.5 G with 3 streams / 4 queues, 22.1 G with 4 streams / >= 6
+# queues, 5 or more streams slower again; profiles/README.md).  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import argparse
 import json
 import math
@@ -99,7 +104,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal only: all ranks share GPU 0 and the per-frame gather is staged through host memory")
-    ap.add_argument("--streams", type=int, default=3, help="frames in flight (HIP streams); 1 = strictly serial frames")
+    ap.add_argument("--streams", type=int, default=4, help="frames in flight (HIP streams); 1 = strictly serial frames")
     args = ap.parse_args()
 
     import numpy as np

@@ -119,12 +119,13 @@ class DistributedRenderer:
     (src/node.cpp:336-349: rgb8 per tile) -- and scatters them into the frame.  `payload="hits"` gathers the
     16-B/px hit records instead (5.3x the bytes, synchronous).
 
-    Frames are pipelined over `slots` HIP streams (default 3 frames in flight): the traversal of frame i+1 fills the
+    Frames are pipelined over `slots` HIP streams (default 4 frames in flight; give the process at least as many hardware queues,
+    GPU_MAX_HW_QUEUES >= 6 in the environment before HIP initialises, or streams share queues and serialise): the traversal of frame i+1 fills the
     CUs that frame i's heaviest packets leave idle, and the asynchronous gather of frame i (RCCL's own stream)
     overlaps both.  flush() completes the frames still in flight."""
 
     def __init__(self, scene, resx: int, resy: int, rank: int = 0, world_size: int = 1, group=None, seed: int = 20090501,
-                 payload: str = "rgb8", slots: int = 3, stage_cpu: bool = False, force_collective: bool = False, lights7=None,
+                 payload: str = "rgb8", slots: int = 4, stage_cpu: bool = False, force_collective: bool = False, lights7=None,
                  ambient=(0.1, 0.1, 0.1), color=(1.0, 1.0, 1.0), reflections: bool = False):
         import torch
         self.torch = torch

@@ -1,6 +1,7 @@
 """What the multi-GPU route costs on top of the traversal, measured with ONE rank on one GPU (nccl backend, force_collective):
 tile plan + packet-list launch + depth shading + dist.gather (to itself) + scatter, against the plain single-GPU frame."""
 import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.distributed as dist
 from snail_amd import FPSCamera, HostBVH, scenes

@@ -1,6 +1,8 @@
 """The GPU builder option (snail_scene_create_lbvh) against the parity tree (host SAH sweep): build time and primary-ray throughput
 of the same kernels on either tree.  Usage: python tools/lbvh_time.py [scene] [max_leaf_tris]"""
-import sys, os, time
+import sys, os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from snail_amd import HostBVH, scenes, FPSCamera
@@ -23,7 +25,7 @@ while stack:
 print("%s: %d triangles; SAH sweep (host) %.3f s -> %d nodes, depth %d; LBVH (device) %.2f ms of kernels, %.1f ms incl. upload/download -> %d nodes in use, depth %d"
       % (name, len(tv), t_sah, h.n_nodes, h.depth, lb.build_ms, t_lb * 1e3, used, lb.bvh.depth))
 for label, sc in (("SAH ", Scene(h, 0)), ("LBVH", lb)):
-    rnd = DistributedRenderer(sc, resx, resy, 0, 1, slots=3)
+    rnd = DistributedRenderer(sc, resx, resy, 0, 1, slots=4)
     st = sc.new_stats(); sc.trace_primary(cam, resx, resy, stats=st); torch.cuda.synchronize(); s = st.cpu().numpy()
     for rep in range(3):
         for _ in range(20): rnd.render(cam)

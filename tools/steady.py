@@ -2,6 +2,7 @@
 that the launch's tail is amortised and PMC counters (which serialise dispatches) describe the saturated machine.
 Usage: python tools/steady.py [R] [reps]"""
 import sys, os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from snail_amd import HostBVH, scenes, FPSCamera

@@ -1,6 +1,7 @@
 """Timing of BASELINE config 3 (primary + shadow packets, staged on the device; optional third argument `refl` = one mirrored
 bounce) -- development aid."""
 import sys, os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # one hardware queue per stream (before HIP initialises)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from snail_amd import HostBVH, scenes, FPSCamera
@@ -22,7 +23,7 @@ s = st.cpu().numpy()
 print("stats {intersects, iters, rays, skips}:", s.tolist()); print("rays traced per frame:", int(s[2]), "(primary 2088960 + %s %d)" % ("mirrored+shadow" if refl else "shadow", int(s[2]) - 2088960), "skips", int(s[3]))
 for i in range(24): sc.render_whitted(cam, resx, resy, lights, reflections=refl)   # every scratch slot of the scene handle allocated
 torch.cuda.synchronize()
-NS = int(os.environ.get("NS", "3"))
+NS = int(os.environ.get("NS", "4"))
 streams = [torch.cuda.Stream() for _ in range(NS)]
 outs = [torch.zeros_like(out) for _ in range(NS)]
 for ns in (1, 1, 1, NS, NS, NS):   # the first round after a change of concurrency is a transient (queues, clocks)
