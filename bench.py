@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal only: all ranks share GPU 0 and the per-frame gather is staged through host memory")
-    ap.add_argument("--streams", type=int, default=4, help="frames in flight (HIP streams); 1 = strictly serial frames")
+    ap.add_argument("--streams", type=int, default=0, help="frames in flight (HIP streams); 0 = 4 on one GPU, 3 on the multi-GPU route (whose collective adds a fourth active stream); 1 = strictly serial frames")
     args = ap.parse_args()
 
     import numpy as np
@@ -149,7 +149,7 @@ def main():
         cam = survey_camera(tv)
     scene = Scene(hbvh, local_rank)
     resx, resy = frame_size_for(world)
-    rnd = DistributedRenderer(scene, resx, resy, rank, world, slots=args.streams, stage_cpu=rehearsal)
+    rnd = DistributedRenderer(scene, resx, resy, rank, world, slots=args.streams if args.streams > 0 else None, stage_cpu=rehearsal)
     total_rays = rnd.rays_per_frame() if world > 1 else resx * ((resy + 15) // 16 * 16)
 
     # ---- algorithmic bytes (outside the timed region) ----

@@ -111,6 +111,20 @@ def reduce_stats(stats, rank: int, world: int, group=None):
     return stats if rank == 0 else None
 
 
+_STREAMS = {}
+
+
+def _stream_pool(torch, dev, n):
+    """The HIP streams frames are pipelined over, created once per device and shared by every renderer of the process: the runtime
+    deals streams to its hardware queues round-robin as they are created, so a second set of streams would share queues with the
+    first one (and with each other) and serialise."""
+    key = (dev.type, dev.index)
+    pool = _STREAMS.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[:n]
+
+
 class DistributedRenderer:
     """One process per GPU.  With world_size 1 the frame's hit records are traced directly in frame layout (no
     collective).  With world_size > 1 every rank traces its tiles' packets (hit records stay in its HBM, where a
@@ -119,13 +133,13 @@ class DistributedRenderer:
     (src/node.cpp:336-349: rgb8 per tile) -- and scatters them into the frame.  `payload="hits"` gathers the
     16-B/px hit records instead (5.3x the bytes, synchronous).
 
-    Frames are pipelined over `slots` HIP streams (default 4 frames in flight; give the process at least as many hardware queues,
+    Frames are pipelined over `slots` HIP streams (default 4 frames in flight, 3 when a collective runs beside them; give the process at least as many hardware queues,
     GPU_MAX_HW_QUEUES >= 6 in the environment before HIP initialises, or streams share queues and serialise): the traversal of frame i+1 fills the
     CUs that frame i's heaviest packets leave idle, and the asynchronous gather of frame i (RCCL's own stream)
     overlaps both.  flush() completes the frames still in flight."""
 
     def __init__(self, scene, resx: int, resy: int, rank: int = 0, world_size: int = 1, group=None, seed: int = 20090501,
-                 payload: str = "rgb8", slots: int = 4, stage_cpu: bool = False, force_collective: bool = False, lights7=None,
+                 payload: str = "rgb8", slots: int | None = None, stage_cpu: bool = False, force_collective: bool = False, lights7=None,
                  ambient=(0.1, 0.1, 0.1), color=(1.0, 1.0, 1.0), reflections: bool = False):
         import torch
         self.torch = torch
@@ -144,8 +158,10 @@ class DistributedRenderer:
         self.multi = world_size > 1 or force_collective
         self.plan = ShardPlan.make(resx, resy, world_size, seed)
         dev = scene._dev()
-        self.nslots = max(1, slots)
-        self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.nslots)]
+        # four ACTIVE streams is the sweet spot on this part (profiles/README.md): 4 frames in flight on one GPU, 3 on the multi-GPU
+        # route, where the collective's own stream is the fourth
+        self.nslots = max(1, slots) if slots is not None else (3 if self.multi else 4)
+        self.streams = _stream_pool(torch, dev, self.nslots)
         self.step = 0
         self.frames = [scene.alloc_frame(resx, resy) for _ in range(self.nslots if not self.multi else (1 if payload == "hits" else 0))] if rank == 0 else []
         self.frame = self.frames[0] if self.frames else None

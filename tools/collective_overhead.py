@@ -13,8 +13,9 @@ dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cu
 tv = scenes.scene_by_name("atrium"); h = HostBVH.build(tv)
 cam = FPSCamera(*scenes.atrium_camera()).camera()
 sc = Scene(h, 0)
-for label, kw in (("single-GPU route (hit records in frame layout)", {}), ("multi-GPU route, rgb8 payload", dict(force_collective=True)),
-                  ("multi-GPU route, hits payload", dict(force_collective=True, payload="hits"))):
+SLOTS = int(os.environ["SLOTS"]) if "SLOTS" in os.environ else None    # default: 4 frames in flight alone, 3 beside the collective
+for label, kw in (("single-GPU route (hit records in frame layout)", dict(slots=SLOTS)), ("multi-GPU route, rgb8 payload", dict(force_collective=True, slots=SLOTS)),
+                  ("multi-GPU route, hits payload", dict(force_collective=True, payload="hits", slots=SLOTS))):
     rnd = DistributedRenderer(sc, 1920, 1080, 0, 1, **kw)
     for rep in range(3):
         for _ in range(30): rnd.render(cam)
