@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal only: all ranks share GPU 0 and the per-frame gather is staged through host memory")
     ap.add_argument("--streams", type=int, default=0, help="frames in flight (HIP streams); 0 = 4 on one GPU, 3 on the multi-GPU route (whose collective adds a fourth active stream); 1 = strictly serial frames")
+    ap.add_argument("--feedback-order", type=int, default=1, help="1 (default) = dispatch packets heaviest first by the node visits of an earlier frame (DistributedRenderer feedback_order)")
     args = ap.parse_args()
 
     import numpy as np
@@ -149,7 +150,8 @@ def main():
         cam = survey_camera(tv)
     scene = Scene(hbvh, local_rank)
     resx, resy = frame_size_for(world)
-    rnd = DistributedRenderer(scene, resx, resy, rank, world, slots=args.streams if args.streams > 0 else None, stage_cpu=rehearsal)
+    rnd = DistributedRenderer(scene, resx, resy, rank, world, slots=args.streams if args.streams > 0 else None, stage_cpu=rehearsal,
+                              feedback_order=bool(args.feedback_order))
     total_rays = rnd.rays_per_frame() if world > 1 else resx * ((resy + 15) // 16 * 16)
 
     # ---- algorithmic bytes (outside the timed region) ----
@@ -197,7 +199,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: gloo, ranks share one GPU -- not a measurement)",
             "config": {"workload": "%s (%d tris, sponza.obj stand-in) %dx%d primary rays, hit records (t,u,v,triId)" % (args.scene, hbvh.n_tris, resx, resy),
                        "rays_per_step": total_rays, "packets": "16x16 px = 1 wavefront", "bvh_nodes": hbvh.n_nodes, "bvh_depth": hbvh.depth,
-                       "bvh_build_s": round(build_s, 3), "hit_fraction": round(hit_frac, 5), "frames_in_flight": rnd.nslots,
+                       "bvh_build_s": round(build_s, 3), "hit_fraction": round(hit_frac, 5), "frames_in_flight": rnd.nslots, "packet_order": "heaviest first (node visits of an earlier frame)" if rnd.feedback else "built-in region interleave",
                        "traversal_stack": "VGPR pair per wave (lane i = slot i), at most bvh_depth+1 = %d slots; LDS 0 B/wave in the main kernel (3328 B/wave only in the deferred M_EXACT pass)" % (hbvh.depth + 1),
                        "parallelism": "tiles16x64-roundrobin-x%d + depth-shade + async RCCL gather of rgb8 tiles to rank 0" % world if world > 1 else "single-gpu"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),

@@ -97,6 +97,23 @@ int snail_trace_packets_dev(SnailScene *, const float cam[13], int resx, int res
  * per tile.  Equal byte for byte to snail_trace_packets_dev followed by snail_shade_depth_dev. */
 int snail_trace_packets_shaded_dev(SnailScene *, const float cam[13], int resx, int resy, const int32_t *d_packet_xy, int nPackets,
                                    uint8_t *d_bgr, uint64_t *d_stats, void *stream);
+/* Dispatch-order feedback (no counterpart in the reference, whose thread pool pulls tiles dynamically, src/render.cpp:258-267 /
+ * src/thread_pool.cpp): packet costs are heavy-tailed, and a frame ends with its heaviest packets.  The *_ordered_dev launches are
+ * the launches above plus two optional device arrays of nSlots int32 -- nSlots = snail_primary_slots(w, h) for a rect (>= the
+ * number of its packets; some slots hold no packet) and nPackets for a list:
+ *   d_slot_cost (out): node visits of each slot's packet in THIS launch (0 for an empty slot);
+ *   d_order     (in) : the slot each workgroup takes, a permutation of [0, nSlots); NULL = the built-in order.
+ * snail_order_from_cost_dev turns the costs of one frame into the order of the next (heaviest first; stream-ordered, one small
+ * kernel on the CURRENT device, no scratch).  Results never depend on the order: hit records and counters are identical.
+ * The caller keeps d_order unchanged while a launch reading it is in flight. */
+int snail_primary_slots(int w, int h);
+int snail_trace_primary_ordered_dev(SnailScene *, const float cam[13], int resx, int resy, int x0, int y0, int w, int h,
+                                    float *d_t, float *d_u, float *d_v, int32_t *d_triId, uint64_t *d_stats,
+                                    const int32_t *d_order, int32_t *d_slot_cost, void *stream);
+int snail_trace_packets_ordered_dev(SnailScene *, const float cam[13], int resx, int resy, const int32_t *d_packet_xy, int nPackets,
+                                    float *d_t, float *d_u, float *d_v, int32_t *d_triId, uint64_t *d_stats,
+                                    const int32_t *d_order, int32_t *d_slot_cost, void *stream);
+int snail_order_from_cost_dev(const int32_t *d_slot_cost, int nSlots, int32_t *d_order, void *stream);
 /* Scatter packet-major planes into row-major resx*resy frame planes (clipped to the image). */
 int snail_packets_to_frame_dev(const int32_t *d_packet_xy, int nPackets, int resx, int resy,
                                const float *d_pt, const float *d_pu, const float *d_pv, const int32_t *d_pid,

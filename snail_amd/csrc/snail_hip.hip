@@ -898,6 +898,9 @@ struct PrimaryArgs {
 	unsigned char *bgr; // packet-major B,G,R of the gVals[1] depth shading (src/scene_trace.cpp:128-137), 3 B/ray, or null
 	u64 *stats;
 	unsigned *cost; // diagnostic: per packet {iters, intersects, shader cycles, start time low bits}
+	const int *order; // dispatch order (block -> slot index, a permutation of [0, nSlots)) or null = the built-in interleave
+	int *slotCost;	  // out, per slot: node visits of its packet (0 for a slot without a packet) or null
+	int nSlots;		  // rect mode: nBlocks; list mode: nPackets
 	int *defer;		// [0] = count, [1] = finished blocks of the M_EXACT pass, [2..] = logical indices of deferred packets
 };
 
@@ -925,7 +928,7 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 	int px, py, pidx;
 	if(A.packetXY) {
 		pidx = li;
-		if(pidx >= A.nPackets) return;
+		if((unsigned)pidx >= (unsigned)A.nPackets) return;
 		int2 xy = A.packetXY[pidx];
 		px = __builtin_amdgcn_readfirstlane(xy.x);
 		py = __builtin_amdgcn_readfirstlane(xy.y);
@@ -934,7 +937,10 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 		const int region = li >> 4, k = li & 15;
 		const int rx = region % nrx, ry = region / nrx;
 		const int cx = rx * 4 + (k & 3), cy = ry * 4 + (k >> 2);
-		if(cx >= A.pw || cy >= A.ph) return;
+		if(cx >= A.pw || cy >= A.ph) {
+			if(A.slotCost && lane == 0 && (unsigned)li < (unsigned)A.nSlots) A.slotCost[li] = 0;
+			return;
+		}
 		px = A.x0 + cx * 16;
 		py = A.y0 + cy * 16;
 		pidx = cy * A.pw + cx;
@@ -985,6 +991,7 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 	if(A.u || A.v) finalBarycentrics(A.tris, org, Q, tid, bu, bv); // (the staged shading pipeline asks for t and triId only)
 
 	flushStats(A.stats, st, 256u, lane);
+	if(A.slotCost && lane == 0) A.slotCost[li] = (int)st.iters;
 	if(A.cost && lane == 0) {
 		const u64 tEnd = __builtin_amdgcn_s_memtime();
 		A.cost[(size_t)pidx * 4 + 0] = st.iters; A.cost[(size_t)pidx * 4 + 1] = st.intersects;
@@ -1035,7 +1042,48 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 template <bool DEEP>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_primary(PrimaryArgs A) {
 	__shared__ float lds[LDS_FLOATS_PER_WAVE];
-	primaryPacket<DEEP, false>(A, interleave16((int)blockIdx.x), lds);
+	int li = interleave16((int)blockIdx.x);
+	if(A.order) { // fed-back dispatch order (snail_order_from_cost_dev): heaviest packets of the previous frame first
+		if((int)blockIdx.x >= A.nSlots) return;
+		li = __builtin_amdgcn_readfirstlane(A.order[blockIdx.x]);
+		if((unsigned)li >= (unsigned)A.nSlots) return;
+	}
+	primaryPacket<DEEP, false>(A, li, lds);
+}
+
+// Dispatch order from per-slot costs: slots in (approximately) descending cost -- a counting sort over 4096 cost classes, one
+// workgroup, no scratch.  The hardware dispatcher hands blocks to CUs in index order, so this is longest-processing-time-first
+// scheduling of the packets; ties and the order inside a class are arbitrary (results never depend on the dispatch order).
+__global__ __launch_bounds__(1024) void k_order_from_cost(const int *__restrict__ cost, int n, int *__restrict__ order) {
+	__shared__ int bins[4096];
+	__shared__ int part[1024];
+	__shared__ int maxCost;
+	const int tid = (int)threadIdx.x;
+	if(tid == 0) maxCost = 0;
+	for(int i = tid; i < 4096; i += 1024) bins[i] = 0;
+	__syncthreads();
+	int m = 0;
+	for(int i = tid; i < n; i += 1024) m = max(m, cost[i]);
+	atomicMax(&maxCost, m);
+	__syncthreads();
+	int shift = 0;
+	while((maxCost >> shift) > 4095) shift++;
+	for(int i = tid; i < n; i += 1024) atomicAdd(&bins[4095 - min(max(cost[i], 0) >> shift, 4095)], 1); // class 0 = heaviest
+	__syncthreads();
+	// exclusive scan of the 4096 class counts: 4 per thread, then a Hillis-Steele scan of the 1024 partial sums
+	const int c0 = bins[tid * 4], c1 = bins[tid * 4 + 1], c2 = bins[tid * 4 + 2], c3 = bins[tid * 4 + 3];
+	part[tid] = c0 + c1 + c2 + c3;
+	__syncthreads();
+	for(int d = 1; d < 1024; d <<= 1) {
+		const int add = tid >= d ? part[tid - d] : 0;
+		__syncthreads();
+		part[tid] += add;
+		__syncthreads();
+	}
+	const int base = part[tid] - (c0 + c1 + c2 + c3);
+	bins[tid * 4] = base; bins[tid * 4 + 1] = base + c0; bins[tid * 4 + 2] = base + c0 + c1; bins[tid * 4 + 3] = base + c0 + c1 + c2;
+	__syncthreads();
+	for(int i = tid; i < n; i += 1024) order[atomicAdd(&bins[4095 - min(max(cost[i], 0) >> shift, 4095)], 1)] = i;
 }
 
 // the deferred M_EXACT packets (grid-stride over the list; the last block to finish re-arms the list for its next use)
@@ -1882,7 +1930,7 @@ int checkScene(const SnailScene *s, const char *fn) {
 
 int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0, int y0, int w, int h, const int32_t *dPacketXY,
 				  int nPackets, float *t, float *u, float *v, int32_t *id, uint64_t *dStats, hipStream_t stream, unsigned *dCost = nullptr,
-				  bool packetMajor = false, uint8_t *dBgr = nullptr) {
+				  bool packetMajor = false, uint8_t *dBgr = nullptr, const int32_t *dOrder = nullptr, int32_t *dSlotCost = nullptr) {
 	if(resx <= 0 || resy <= 0) { snail_set_error("snail_trace_primary: bad resolution %dx%d", resx, resy); return 1; }
 	dev::PrimaryArgs A;
 	memset(&A, 0, sizeof(A));
@@ -1914,6 +1962,8 @@ int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0
 		blocks = ((nRegions + 7) / 8) * 8 * 16;
 	}
 	A.nBlocks = blocks;
+	A.nSlots = dPacketXY ? nPackets : blocks;
+	A.order = dOrder; A.slotCost = dSlotCost;
 	s->lastBlocks = blocks; s->lastThreads = 64;
 	// deferred-packet list of this launch (re-allocated, synchronously, only when a larger frame than ever before arrives)
 	if(blocks + 2 > s->deferCap) {
@@ -2182,6 +2232,35 @@ int snail_trace_primary_dev(SnailScene *s, const float cam[13], int resx, int re
 	if(int rc = checkScene(s, "snail_trace_primary_dev")) return rc;
 	DeviceGuard guard(s->device);
 	return launchPrimary(s, cam, resx, resy, x0, y0, w, h, nullptr, 0, t, u, v, id, dStats, (hipStream_t)stream);
+}
+
+int snail_primary_slots(int w, int h) {
+	if(w <= 0 || h <= 0) return 0;
+	const int pw = (w + 15) / 16, ph = (h + 15) / 16;
+	return (((pw + 3) / 4) * ((ph + 3) / 4) + 7) / 8 * 8 * 16;
+}
+
+int snail_trace_primary_ordered_dev(SnailScene *s, const float cam[13], int resx, int resy, int x0, int y0, int w, int h, float *t, float *u,
+									float *v, int32_t *id, uint64_t *dStats, const int32_t *dOrder, int32_t *dSlotCost, void *stream) {
+	if(int rc = checkScene(s, "snail_trace_primary_ordered_dev")) return rc;
+	DeviceGuard guard(s->device);
+	return launchPrimary(s, cam, resx, resy, x0, y0, w, h, nullptr, 0, t, u, v, id, dStats, (hipStream_t)stream, nullptr, false, nullptr, dOrder, dSlotCost);
+}
+
+int snail_trace_packets_ordered_dev(SnailScene *s, const float cam[13], int resx, int resy, const int32_t *dPacketXY, int nPackets, float *t,
+									float *u, float *v, int32_t *id, uint64_t *dStats, const int32_t *dOrder, int32_t *dSlotCost, void *stream) {
+	if(int rc = checkScene(s, "snail_trace_packets_ordered_dev")) return rc;
+	if(!dPacketXY && nPackets > 0) { snail_set_error("snail_trace_packets_ordered_dev: null packet list"); return 1; }
+	DeviceGuard guard(s->device);
+	return launchPrimary(s, cam, resx, resy, 0, 0, 0, 0, dPacketXY, nPackets, t, u, v, id, dStats, (hipStream_t)stream, nullptr, false, nullptr, dOrder, dSlotCost);
+}
+
+int snail_order_from_cost_dev(const int32_t *dSlotCost, int nSlots, int32_t *dOrder, void *stream) {
+	if(nSlots <= 0) return 0;
+	if(!dSlotCost || !dOrder) { snail_set_error("snail_order_from_cost_dev: null buffer"); return 1; }
+	hipLaunchKernelGGL(dev::k_order_from_cost, dim3(1), dim3(1024), 0, (hipStream_t)stream, dSlotCost, nSlots, dOrder);
+	HIP_TRY(hipGetLastError());
+	return 0;
 }
 
 int snail_trace_packets_dev(SnailScene *s, const float cam[13], int resx, int resy, const int32_t *dPacketXY, int nPackets, float *t,

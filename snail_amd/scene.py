@@ -165,19 +165,47 @@ class Scene:
                         torch.zeros((resy, resx), dtype=torch.int32, device=d))
 
     # ---- primary packets ----------------------------------------------------------------------
-    def trace_primary(self, cam: Camera, resx: int, resy: int, rect=None, out: HitFrame | None = None, stats=None, stream=None) -> HitFrame:
-        """Trace every 16x16 packet of `rect` (x0,y0,w,h; default the whole image)."""
+    def trace_primary(self, cam: Camera, resx: int, resy: int, rect=None, out: HitFrame | None = None, stats=None, stream=None, order=None,
+                      slot_cost=None) -> HitFrame:
+        """Trace every 16x16 packet of `rect` (x0,y0,w,h; default the whole image).  `order` / `slot_cost`: optional int32 device
+        tensors of primary_slots(w, h) entries -- the dispatch-order feedback of snail_trace_primary_ordered_dev."""
         x0, y0, w, h = rect if rect is not None else (0, 0, resx, resy)
         out = out if out is not None else self.alloc_frame(resx, resy)
         cam13 = np.ascontiguousarray(cam.as_array13(), dtype=np.float32)
+        if order is not None or slot_cost is not None:
+            n = self.primary_slots(w, h)
+            for a in (order, slot_cost):
+                if a is not None and (a.numel() != n or a.dtype != _torch().int32 or not a.is_contiguous()):
+                    raise ValueError(f"order / slot_cost must be contiguous int32 tensors of {n} entries")
+            rc = _lib.lib().snail_trace_primary_ordered_dev(self._h, _lib.ptr(cam13), resx, resy, x0, y0, w, h, _lib.ptr(out.t), _lib.ptr(out.u),
+                                                            _lib.ptr(out.v), _lib.ptr(out.tri_id), _lib.ptr(stats), _lib.ptr(order), _lib.ptr(slot_cost),
+                                                            _stream_ptr(stream))
+            _lib.check(rc, "snail_trace_primary_ordered_dev")
+            return out
         rc = _lib.lib().snail_trace_primary_dev(self._h, _lib.ptr(cam13), resx, resy, x0, y0, w, h, _lib.ptr(out.t), _lib.ptr(out.u),
                                                 _lib.ptr(out.v), _lib.ptr(out.tri_id), _lib.ptr(stats), _stream_ptr(stream))
         _lib.check(rc, "snail_trace_primary_dev")
         return out
 
-    def trace_packets(self, cam: Camera, resx: int, resy: int, packet_xy, out=None, stats=None, stream=None):
+    @staticmethod
+    def primary_slots(w: int, h: int) -> int:
+        """Dispatch slots of a w x h rect (>= its packets): the length of the order / slot_cost arrays of trace_primary."""
+        return int(_lib.lib().snail_primary_slots(w, h))
+
+    @staticmethod
+    def order_from_cost(slot_cost, order=None, stream=None):
+        """Heaviest-first dispatch order (a permutation, int32) from the per-slot costs of a previous launch; stream-ordered."""
+        torch = _torch()
+        order = order if order is not None else torch.empty_like(slot_cost)
+        with torch.cuda.device(slot_cost.device):
+            rc = _lib.lib().snail_order_from_cost_dev(_lib.ptr(slot_cost), int(slot_cost.numel()), _lib.ptr(order), _stream_ptr(stream))
+        _lib.check(rc, "snail_order_from_cost_dev")
+        return order
+
+    def trace_packets(self, cam: Camera, resx: int, resy: int, packet_xy, out=None, stats=None, stream=None, order=None, slot_cost=None):
         """Trace an explicit packet list (int32 device tensor [n,2] of top-left pixels); results are
-        packet-major [n,256] in the reference's quad order (t, u, v, tri_id)."""
+        packet-major [n,256] in the reference's quad order (t, u, v, tri_id).  `order` / `slot_cost`: optional int32 device tensors
+        of n entries (snail_trace_packets_ordered_dev)."""
         torch = _torch()
         n = int(packet_xy.shape[0])
         if out is None:
@@ -185,6 +213,15 @@ class Scene:
             out = (torch.empty((n, 256), dtype=torch.float32, device=d), torch.empty((n, 256), dtype=torch.float32, device=d),
                    torch.empty((n, 256), dtype=torch.float32, device=d), torch.empty((n, 256), dtype=torch.int32, device=d))
         cam13 = np.ascontiguousarray(cam.as_array13(), dtype=np.float32)
+        if order is not None or slot_cost is not None:
+            for a in (order, slot_cost):
+                if a is not None and (a.numel() != n or a.dtype != torch.int32 or not a.is_contiguous()):
+                    raise ValueError(f"order / slot_cost must be contiguous int32 tensors of {n} entries")
+            rc = _lib.lib().snail_trace_packets_ordered_dev(self._h, _lib.ptr(cam13), resx, resy, _lib.ptr(packet_xy), n, _lib.ptr(out[0]), _lib.ptr(out[1]),
+                                                            _lib.ptr(out[2]), _lib.ptr(out[3]), _lib.ptr(stats), _lib.ptr(order), _lib.ptr(slot_cost),
+                                                            _stream_ptr(stream))
+            _lib.check(rc, "snail_trace_packets_ordered_dev")
+            return out
         rc = _lib.lib().snail_trace_packets_dev(self._h, _lib.ptr(cam13), resx, resy, _lib.ptr(packet_xy), n, _lib.ptr(out[0]), _lib.ptr(out[1]),
                                                 _lib.ptr(out[2]), _lib.ptr(out[3]), _lib.ptr(stats), _stream_ptr(stream))
         _lib.check(rc, "snail_trace_packets_dev")

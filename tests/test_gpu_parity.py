@@ -777,3 +777,75 @@ def test_config3_shading_through_the_tile_plan(torch_mod):
             assert np.array_equal(got, want), (refl, world, int((got != want).sum()))
             assert np.array_equal(stats.cpu().numpy().astype(np.uint64), wst), (refl, world, stats.cpu().numpy(), wst)
     sc.close()
+
+
+@pytest.mark.parametrize("name,resx,resy", [("atrium:0.05", 640, 368), ("stress:0.05", 250, 130), ("box", 16, 16)])
+def test_dispatch_order_feedback_changes_nothing_but_the_order(torch_mod, name, resx, resy):
+    """snail_trace_primary_ordered_dev / snail_trace_packets_ordered_dev / snail_order_from_cost_dev: the per-slot costs add up to
+    the frame's node-visit counter, the derived order is a permutation with non-increasing cost classes, and a frame dispatched in that
+    order (or in a reversed / random one) has the hit records and counters of the oracle.  DistributedRenderer(feedback_order=True)
+    end to end."""
+    from snail_amd import render as R
+    tv, sc, osc = gpu_scene(name)
+    cam = util.camera_for(name, tv)
+    ref = osc.render_primary(cam.as_array13(), resx, resy, mode=O.MODE_IEEE)
+    n = sc.primary_slots(resx, resy)
+    assert n % 128 == 0 and n >= ((resx + 15) // 16) * ((resy + 15) // 16)
+    cost = torch_mod.full((n,), -7, dtype=torch_mod.int32, device="cuda")
+    stats = sc.new_stats()
+    frame = sc.trace_primary(cam, resx, resy, stats=stats, slot_cost=cost)
+    order = sc.order_from_cost(cost)
+    torch_mod.cuda.synchronize()
+    compare_frames(frame, ref, "cost pass")
+    c, o = cost.cpu().numpy(), order.cpu().numpy()
+    assert (c >= 0).all() and int(c.sum()) == int(ref[4][1]), (int(c.sum()), ref[4])          # every slot written; sum = TreeStats iters
+    assert np.array_equal(np.sort(o), np.arange(n)), "order is not a permutation"
+    shift = 0
+    while (int(c.max()) >> shift) > 4095: shift += 1
+    cls = np.minimum(c[o] >> shift, 4095)
+    assert (np.diff(cls) <= 0).all(), "cost classes not in descending order"
+    rng = np.random.default_rng(5)
+    for label, perm in (("heaviest first", o), ("lightest first", o[::-1].copy()), ("random", rng.permutation(n).astype(np.int32))):
+        stats2 = sc.new_stats()
+        cost2 = torch_mod.zeros_like(cost)
+        f2 = sc.trace_primary(cam, resx, resy, stats=stats2, order=torch_mod.from_numpy(np.ascontiguousarray(perm)).cuda(), slot_cost=cost2)
+        torch_mod.cuda.synchronize()
+        compare_frames(f2, ref, label)
+        assert np.array_equal(stats2.cpu().numpy().astype(np.uint64), ref[4]), label
+        assert np.array_equal(cost2.cpu().numpy(), c), label
+    # packet-list form
+    plan = R.ShardPlan.make(resx, resy, 1)
+    xy = torch_mod.from_numpy(plan.packets[0]).cuda()
+    m = int(xy.shape[0])
+    pc = torch_mod.zeros(m, dtype=torch_mod.int32, device="cuda")
+    base = sc.trace_packets(cam, resx, resy, xy)
+    sc.trace_packets(cam, resx, resy, xy, slot_cost=pc)
+    po = sc.order_from_cost(pc)
+    stats3 = sc.new_stats()
+    got = sc.trace_packets(cam, resx, resy, xy, stats=stats3, order=po)
+    torch_mod.cuda.synchronize()
+    assert np.array_equal(np.sort(po.cpu().numpy()), np.arange(m))
+    assert int(pc.sum().item()) == int(ref[4][1])
+    for a, b in zip(got, base):
+        assert torch_mod.equal(a.view(torch_mod.int32), b.view(torch_mod.int32))
+    assert np.array_equal(stats3.cpu().numpy().astype(np.uint64), ref[4])
+    with pytest.raises(ValueError):
+        sc.trace_primary(cam, resx, resy, order=torch_mod.zeros(n + 1, dtype=torch_mod.int32, device="cuda"))
+    # the renderer with the feedback on: every frame of a moving camera equals the oracle's
+    rnd = R.DistributedRenderer(sc, resx, resy, feedback_order=True, order_refresh=2)
+    bmin, bmax = osc.nodes[0]["bmin"], osc.nodes[0]["bmax"]
+    ctr, ext = (bmin + bmax) * 0.5, (bmax - bmin)
+    cams = [cam] * 3 + [FPSCamera((ctr + (rng.random(3) - 0.5) * ext * 0.8).astype(np.float32), rng.random() * 6.28, (rng.random() - 0.5) * 1.5).camera()
+                        for _ in range(9)]
+    outs = []
+    for cm in cams:
+        f = rnd.render(cm)
+        outs.append((cm, f))
+        if len(outs) == rnd.nslots:
+            rnd.flush()
+            for cm2, f2 in outs:
+                compare_frames(f2, osc.render_primary(cm2.as_array13(), resx, resy, mode=O.MODE_IEEE), "renderer feedback")
+            outs = []
+    rnd.flush()
+    assert all(rnd.order_valid)
+    sc.close()
