@@ -831,6 +831,19 @@ def test_dispatch_order_feedback_changes_nothing_but_the_order(torch_mod, name, 
     assert np.array_equal(stats3.cpu().numpy().astype(np.uint64), ref[4])
     with pytest.raises(ValueError):
         sc.trace_primary(cam, resx, resy, order=torch_mod.zeros(n + 1, dtype=torch_mod.int32, device="cuda"))
+    # an order with out-of-range entries is refused entry by entry (no out-of-bounds access, the other packets are traced)
+    bad = o.copy(); bad[::7] = n + 5; bad[3] = -1
+    sc.trace_primary(cam, resx, resy, order=torch_mod.from_numpy(bad).cuda())
+    torch_mod.cuda.synchronize()
+    # the sort alone: sizes around the block size, constant / negative / huge costs
+    for m2, gen in ((1, lambda k: np.zeros(k)), (1023, lambda k: rng.integers(0, 50, k)), (1025, lambda k: rng.integers(-5, 3, k)),
+                    (200_003, lambda k: rng.integers(0, 2**31 - 1, k)), (4096, lambda k: np.full(k, 17))):
+        cst = gen(m2).astype(np.int32)
+        od = sc.order_from_cost(torch_mod.from_numpy(cst).cuda()).cpu().numpy()
+        assert np.array_equal(np.sort(od), np.arange(m2)), m2
+        sh = 0
+        while (max(int(cst.max()), 0) >> sh) > 4095: sh += 1
+        assert (np.diff(np.minimum(np.maximum(cst[od], 0) >> sh, 4095)) <= 0).all(), m2
     # the renderer with the feedback on: every frame of a moving camera equals the oracle's
     rnd = R.DistributedRenderer(sc, resx, resy, feedback_order=True, order_refresh=2)
     bmin, bmax = osc.nodes[0]["bmin"], osc.nodes[0]["bmax"]
