@@ -1054,36 +1054,46 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
 // Dispatch order from per-slot costs: slots in (approximately) descending cost -- a counting sort over 4096 cost classes, one
 // workgroup, no scratch.  The hardware dispatcher hands blocks to CUs in index order, so this is longest-processing-time-first
 // scheduling of the packets; ties and the order inside a class are arbitrary (results never depend on the dispatch order).
-__global__ __launch_bounds__(1024) void k_order_from_cost(const int *__restrict__ cost, int n, int *__restrict__ order) {
+// 256 threads = one wave per SIMD, so the workgroup fits beside frames that hold 5 of the 8 wave slots of every SIMD.  Alone it
+// takes 20 us; beside four frames in flight its waves get a sixth of their SIMDs' issue slots and it takes ~110 us (the same with
+// 1024 threads) -- on its slot's stream once every few frames, while the other streams keep the machine full.
+#define ORDER_THREADS 256
+__global__ __launch_bounds__(ORDER_THREADS) void k_order_from_cost(const int *__restrict__ cost, int n, int *__restrict__ order) {
+	constexpr int T = ORDER_THREADS, PER = 4096 / T;
 	__shared__ int bins[4096];
-	__shared__ int part[1024];
+	__shared__ int part[T];
 	__shared__ int maxCost;
 	const int tid = (int)threadIdx.x;
 	if(tid == 0) maxCost = 0;
-	for(int i = tid; i < 4096; i += 1024) bins[i] = 0;
+	for(int i = tid; i < 4096; i += T) bins[i] = 0;
 	__syncthreads();
 	int m = 0;
-	for(int i = tid; i < n; i += 1024) m = max(m, cost[i]);
+	for(int i = tid; i < n; i += T) m = max(m, cost[i]);
 	atomicMax(&maxCost, m);
 	__syncthreads();
 	int shift = 0;
 	while((maxCost >> shift) > 4095) shift++;
-	for(int i = tid; i < n; i += 1024) atomicAdd(&bins[4095 - min(max(cost[i], 0) >> shift, 4095)], 1); // class 0 = heaviest
+	for(int i = tid; i < n; i += T) atomicAdd(&bins[4095 - min(max(cost[i], 0) >> shift, 4095)], 1); // class 0 = heaviest
 	__syncthreads();
-	// exclusive scan of the 4096 class counts: 4 per thread, then a Hillis-Steele scan of the 1024 partial sums
-	const int c0 = bins[tid * 4], c1 = bins[tid * 4 + 1], c2 = bins[tid * 4 + 2], c3 = bins[tid * 4 + 3];
-	part[tid] = c0 + c1 + c2 + c3;
+	// exclusive scan of the 4096 class counts: PER consecutive classes per thread, then a Hillis-Steele scan of the partial sums
+	int sum = 0;
+	for(int k = 0; k < PER; k++) sum += bins[tid * PER + k];
+	part[tid] = sum;
 	__syncthreads();
-	for(int d = 1; d < 1024; d <<= 1) {
+	for(int d = 1; d < T; d <<= 1) {
 		const int add = tid >= d ? part[tid - d] : 0;
 		__syncthreads();
 		part[tid] += add;
 		__syncthreads();
 	}
-	const int base = part[tid] - (c0 + c1 + c2 + c3);
-	bins[tid * 4] = base; bins[tid * 4 + 1] = base + c0; bins[tid * 4 + 2] = base + c0 + c1; bins[tid * 4 + 3] = base + c0 + c1 + c2;
+	int run = part[tid] - sum;
+	for(int k = 0; k < PER; k++) {
+		const int c = bins[tid * PER + k];
+		bins[tid * PER + k] = run;
+		run += c;
+	}
 	__syncthreads();
-	for(int i = tid; i < n; i += 1024) order[atomicAdd(&bins[4095 - min(max(cost[i], 0) >> shift, 4095)], 1)] = i;
+	for(int i = tid; i < n; i += T) order[atomicAdd(&bins[4095 - min(max(cost[i], 0) >> shift, 4095)], 1)] = i;
 }
 
 // the deferred M_EXACT packets (grid-stride over the list; the last block to finish re-arms the list for its next use)
@@ -2258,7 +2268,7 @@ int snail_trace_packets_ordered_dev(SnailScene *s, const float cam[13], int resx
 int snail_order_from_cost_dev(const int32_t *dSlotCost, int nSlots, int32_t *dOrder, void *stream) {
 	if(nSlots <= 0) return 0;
 	if(!dSlotCost || !dOrder) { snail_set_error("snail_order_from_cost_dev: null buffer"); return 1; }
-	hipLaunchKernelGGL(dev::k_order_from_cost, dim3(1), dim3(1024), 0, (hipStream_t)stream, dSlotCost, nSlots, dOrder);
+	hipLaunchKernelGGL(dev::k_order_from_cost, dim3(1), dim3(ORDER_THREADS), 0, (hipStream_t)stream, dSlotCost, nSlots, dOrder);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
