@@ -281,8 +281,14 @@ __device__ __forceinline__ bool boxTestInterval(const Node &n, const Interval &i
 // Branch-free: (det < 0) | (...) has the same truth value as the reference's early return.
 template <int M>
 __device__ __forceinline__ bool triTestInterval(const Tri &t, const Interval &i) {
-	float det = (t.n[0] < 0.0f ? i.minDir[0] : i.maxDir[0]) * t.n[0] + (t.n[1] < 0.0f ? i.minDir[1] : i.maxDir[1]) * t.n[1] +
-				(t.n[2] < 0.0f ? i.minDir[2] : i.maxDir[2]) * t.n[2];
+	float det;
+	if(M == M_EXACT)
+		det = (t.n[0] < 0.0f ? i.minDir[0] : i.maxDir[0]) * t.n[0] + (t.n[1] < 0.0f ? i.minDir[1] : i.maxDir[1]) * t.n[1] +
+			  (t.n[2] < 0.0f ? i.minDir[2] : i.maxDir[2]) * t.n[2];
+	else // finite operands, minDir <= maxDir: the selected product is the larger of the two (n < 0 flips the order; n == 0 gives zeros
+		 // whose sign no comparison below observes) -- two multiplies and a max instead of compare -> SGPR -> select -> multiply
+		det = vmax(i.minDir[0] * t.n[0], i.maxDir[0] * t.n[0]) + vmax(i.minDir[1] * t.n[1], i.maxDir[1] * t.n[1]) +
+			  vmax(i.minDir[2] * t.n[2], i.maxDir[2] * t.n[2]);
 	float tv[3] = {i.minOrg[0] - t.a[0], i.minOrg[1] - t.a[1], i.minOrg[2] - t.a[2]};
 	float c1[3] = {t.ba[1] * tv[2] - t.ba[2] * tv[1], t.ba[2] * tv[0] - t.ba[0] * tv[2], t.ba[0] * tv[1] - t.ba[1] * tv[0]};
 	float c2[3] = {tv[1] * t.ca[2] - tv[2] * t.ca[1], tv[2] * t.ca[0] - tv[0] * t.ca[2], tv[0] * t.ca[1] - tv[1] * t.ca[0]};
@@ -332,7 +338,7 @@ __device__ __forceinline__ bool leafShared(const uint4 *__restrict__ tris, int c
 		const bool mine = lane < chunk;
 		const Tri t = loadTriVector(tris, firstTri + base + (mine ? lane : 0));
 		const TriTerms tt = triTerms(t, org[0][0], org[1][0], org[2][0]);
-		u64 keep = __ballot(mine & triTestInterval<M>(t, iv));
+		u64 keep = __builtin_amdgcn_ballot_w64(mine & triTestInterval<M>(t, iv));
 
 		while(keep) {
 			const int k = __builtin_ctzll(keep);
@@ -373,7 +379,7 @@ __device__ __forceinline__ bool leafShared(const uint4 *__restrict__ tris, int c
 				}
 			}
 			if(SHADOW) {
-				const bool full = width == size && (__ballot(all4) & curRange) == curRange;
+				const bool full = width == size && (__builtin_amdgcn_ballot_w64(all4) & curRange) == curRange;
 				if(full) { st.skips++; return true; }
 			}
 			st.intersects += width;
