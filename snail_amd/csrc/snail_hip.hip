@@ -344,8 +344,14 @@ __device__ __forceinline__ bool leafShared(const uint4 *__restrict__ tris, int c
 			const int k = __builtin_ctzll(keep);
 			keep &= keep - 1;
 			// broadcast of lane k's triangle through the LDS crossbar (ds_bpermute_b32, no LDS memory) into VGPRs: ten v_readlane_b32
-			// into SGPRs cost 4 VALU issue cycles each plus the SGPR-write -> VALU-read hazard; measured +7 % frame rate
+			// into SGPRs cost 4 VALU issue cycles each plus the SGPR-write -> VALU-read hazard.  Same box, tools/exp_leaf.sh: atrium
+			// 23.5 vs 22.1 Grays/s, stress-1M 10.2 vs 10.4 (there the ~100 cycles of crossbar latency per survivor show); issuing the
+			// next survivor's broadcast ahead of the current intersection (two register sets) costs more than it hides: 21.0 / 9.5.
+#ifdef SNAIL_EXP_LEAF_READLANE // experiment hook (tools/exp_leaf.sh)
+#define BCAST(x) readlanef(x, k)
+#else
 #define BCAST(x) __int_as_float(__builtin_amdgcn_ds_bpermute(k * 4, __float_as_int(x)))
+#endif
 			const float nx = BCAST(t.n[0]), ny = BCAST(t.n[1]), nz = BCAST(t.n[2]);
 			const float ax = BCAST(tt.t0v[0]), ay = BCAST(tt.t0v[1]), az = BCAST(tt.t0v[2]);
 			const float bx = BCAST(tt.t1v[0]), by = BCAST(tt.t1v[1]), bz = BCAST(tt.t1v[2]);
