@@ -11,7 +11,7 @@ if [ "${1:-}" = build ]; then
 fi
 cp snail_amd/libsnailhip.so /tmp/lib_base.so
 for round in 1 2; do
-for v in base readlane; do
+for v in base ${VARIANTS:-readlane}; do
   if [ $v = base ]; then cp /tmp/lib_base.so snail_amd/libsnailhip.so; else cp snail_amd/exp/lib_$v.so snail_amd/libsnailhip.so; fi
   for sc in atrium stress; do
     timeout -k 10 300 python bench.py --no-cpu-baseline --scene $sc > gpurun_out/expleaf_${v}_$sc.json 2> gpurun_out/expleaf.err || exit 1
