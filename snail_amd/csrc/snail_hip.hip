@@ -1055,8 +1055,11 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 	}
 }
 
+#ifndef SNAIL_PRIMARY_WAVES
+#define SNAIL_PRIMARY_WAVES 5 // occupancy target of the primary kernel (6 measured equal, 4 slower: profiles/README.md)
+#endif
 template <bool DEEP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_primary(PrimaryArgs A) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SNAIL_PRIMARY_WAVES))) void k_primary(PrimaryArgs A) {
 	__shared__ float lds[LDS_FLOATS_PER_WAVE];
 	int li = interleave16((int)blockIdx.x);
 	if(A.order) { // fed-back dispatch order (snail_order_from_cost_dev): heaviest packets of the previous frame first
