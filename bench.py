@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal only: all ranks share GPU 0 and the per-frame gather is staged through host memory")
-    ap.add_argument("--streams", type=int, default=0, help="frames in flight (HIP streams); 0 = 4 on one GPU, 3 on the multi-GPU route (whose collective adds a fourth active stream); 1 = strictly serial frames")
+    ap.add_argument("--streams", type=int, default=0, help="frames in flight (HIP streams); 0 = the renderer's default (4); 1 = strictly serial frames")
     ap.add_argument("--feedback-order", type=int, default=1, help="1 (default) = dispatch packets heaviest first by the node visits of an earlier frame (DistributedRenderer feedback_order)")
     args = ap.parse_args()
 
@@ -201,7 +201,7 @@ def main():
                        "rays_per_step": total_rays, "packets": "16x16 px = 1 wavefront", "bvh_nodes": hbvh.n_nodes, "bvh_depth": hbvh.depth,
                        "bvh_build_s": round(build_s, 3), "hit_fraction": round(hit_frac, 5), "frames_in_flight": rnd.nslots, "packet_order": "heaviest first (node visits of an earlier frame)" if rnd.feedback else "built-in region interleave",
                        "traversal_stack": "VGPR pair per wave (lane i = slot i), at most bvh_depth+1 = %d slots; LDS 0 B/wave in the main kernel (3328 B/wave only in the deferred M_EXACT pass)" % (hbvh.depth + 1),
-                       "parallelism": "tiles16x64-roundrobin-x%d + depth-shade + async RCCL gather of rgb8 tiles to rank 0" % world if world > 1 else "single-gpu"},
+                       "parallelism": "tiles16x64-roundrobin-x%d + depth-shade + per-frame RCCL gather of rgb8 tiles to rank 0 (overlapped with the next frames)" % world if world > 1 else "single-gpu"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_bytes_per_launch": tr["bytes_per_launch"] if tr else None,
                          "traffic_source": tr["source"] if tr else None, "kernel": "dev::k_primary", "kernel_ms": round(kern_ms, 5),

@@ -11,6 +11,8 @@ xGMI, all 7 peer links of GPU0 in parallel; gloo on CPU for tests) brings them t
 them into the frame.  There is no exchange step inside traversal, hence no other collective."""
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 
 import numpy as np
@@ -133,14 +135,14 @@ class DistributedRenderer:
     (src/node.cpp:336-349: rgb8 per tile) -- and scatters them into the frame.  `payload="hits"` gathers the
     16-B/px hit records instead (5.3x the bytes, synchronous).
 
-    Frames are pipelined over `slots` HIP streams (default 4 frames in flight, 3 when a collective runs beside them; give the process at least as many hardware queues,
+    Frames are pipelined over `slots` HIP streams (default 4 frames in flight; 3 when the gather runs asynchronously on the process group's own stream; give the process at least as many hardware queues,
     GPU_MAX_HW_QUEUES >= 6 in the environment before HIP initialises, or streams share queues and serialise): the traversal of frame i+1 fills the
-    CUs that frame i's heaviest packets leave idle, and the asynchronous gather of frame i (RCCL's own stream)
+    CUs that frame i's heaviest packets leave idle, and the gather of frame i (on its slot's stream, or RCCL's own)
     overlaps both.  flush() completes the frames still in flight."""
 
     def __init__(self, scene, resx: int, resy: int, rank: int = 0, world_size: int = 1, group=None, seed: int = 20090501,
                  payload: str = "rgb8", slots: int | None = None, stage_cpu: bool = False, force_collective: bool = False, lights7=None,
-                 ambient=(0.1, 0.1, 0.1), color=(1.0, 1.0, 1.0), reflections: bool = False, feedback_order: bool = True, order_refresh: int = 4):
+                 ambient=(0.1, 0.1, 0.1), color=(1.0, 1.0, 1.0), reflections: bool = False, feedback_order: bool = True, order_refresh: int = 4, inline_collective: bool | None = None):
         import torch
         self.torch = torch
         self.scene = scene
@@ -156,16 +158,27 @@ class DistributedRenderer:
         # force_collective: run the tile plan + shade + gather + scatter route even with ONE rank (the collective then moves rank 0's
         # buffer to itself) -- lets a single-GPU box exercise the RCCL code path of the multi-GPU bench
         self.multi = world_size > 1 or force_collective
+        # inline_collective: issue the per-frame gather synchronously with respect to the SLOT's stream (torch >= 2.8 runs a
+        # collective with async_op=False on the current stream instead of the process group's own): trace -> gather -> scatter are
+        # then one in-order chain per slot and no fifth stream competes for a hardware queue, so 4 slots can be kept (one rank on one
+        # GPU, tools/collective_overhead.py: 0.093 ms/frame against 0.106 with the asynchronous gather and 3 slots).  RCCL orders the
+        # operations of one communicator across user streams itself, and if a torch build still used the group's own stream the
+        # call would only be a stream-level wait: correct either way.  Default on for the rgb8 payload; SNAIL_INLINE_COLLECTIVE=0 = off.
+        self.inline = (bool(inline_collective) if inline_collective is not None else os.environ.get("SNAIL_INLINE_COLLECTIVE", "1") == "1") and payload == "rgb8" and not stage_cpu
         self.plan = ShardPlan.make(resx, resy, world_size, seed)
         dev = scene._dev()
-        # four ACTIVE streams is the sweet spot on this part (profiles/README.md): 4 frames in flight on one GPU, 3 on the multi-GPU
-        # route, where the collective's own stream is the fourth
-        self.nslots = max(1, slots) if slots is not None else (3 if self.multi else 4)
+        # four ACTIVE streams is the sweet spot on this part (profiles/README.md): 4 frames in flight, or 3 where the collective's own stream
+        # is the fourth (asynchronous gather)
+        self.nslots = max(1, slots) if slots is not None else (3 if self.multi and not self.inline else 4)
         self.streams = _stream_pool(torch, dev, self.nslots)
         self.step = 0
         self.frames = [scene.alloc_frame(resx, resy) for _ in range(self.nslots if not self.multi else (1 if payload == "hits" else 0))] if rank == 0 else []
         self.frame = self.frames[0] if self.frames else None
-        self.frame_rgb8 = torch.zeros((resy, resx, 3), dtype=torch.uint8, device=dev) if (rank == 0 and self.multi and payload == "rgb8") else None
+        # one frame buffer per slot: the scatters of consecutive frames run on different streams and may overlap; frame_rgb8 names the
+        # buffer of the frame enqueued last (complete after flush(), or once the slot's stream has drained)
+        self.frames_rgb8 = ([torch.zeros((resy, resx, 3), dtype=torch.uint8, device=dev) for _ in range(self.nslots)]
+                            if (rank == 0 and self.multi and payload == "rgb8") else [])
+        self.frame_rgb8 = self.frames_rgb8[0] if self.frames_rgb8 else None
         self.pending = [None] * self.nslots
         # feedback_order: dispatch the packets of a frame heaviest first, by the node visits counted in an earlier frame of the same
         # slot (snail_order_from_cost_dev; re-derived every `order_refresh` frames of a slot, on the slot's own stream, so a launch
@@ -213,6 +226,7 @@ class DistributedRenderer:
         self.pending[slot] = None
         work.wait()
         if self.rank == 0:
+            self.frame_rgb8 = self.frames_rgb8[slot]
             self.scene.packets_bgr_to_frame(self.all_xy_cat, self.gathered_all[slot].view(-1, 256, 3), self.frame_rgb8)
 
     def _refresh_order(self, slot, st):
@@ -239,6 +253,7 @@ class DistributedRenderer:
                     out = sc.trace_primary(cam, p.resx, p.resy, out=self.frames[slot], stats=stats, stream=st)
                 if events: events[1].record(st)
                 if self.feedback: self._refresh_order(slot, st)
+                self.frame = out
                 return out
             self._finish(slot)                       # the slot's buffers are free again after this
             if events: events[0].record(st)
@@ -276,6 +291,12 @@ class DistributedRenderer:
                         return True
                 self.pending[slot] = _Done()
                 return self.frame_rgb8
+            if self.inline:
+                dist.gather(self.bgr[slot], self.gathered[slot] if self.rank == 0 else None, dst=0, group=self.group, async_op=False)
+                if self.rank == 0:
+                    self.frame_rgb8 = self.frames_rgb8[slot]
+                    sc.packets_bgr_to_frame(self.all_xy_cat, self.gathered_all[slot].view(-1, 256, 3), self.frame_rgb8)
+                return self.frame_rgb8
             self.pending[slot] = dist.gather(self.bgr[slot], self.gathered[slot] if self.rank == 0 else None, dst=0, group=self.group, async_op=True)
         return self.frame_rgb8
 
@@ -292,7 +313,8 @@ class DistributedRenderer:
     def flush(self):
         """Complete every frame still in flight (call after the last render() of a sequence)."""
         torch = self.torch
-        for slot in range(self.nslots):
+        for k in range(self.nslots):     # oldest frame first, so that frame_rgb8 ends up naming the newest
+            slot = (self.step + k) % self.nslots
             with torch.cuda.stream(self.streams[slot]):
                 self._finish(slot)
         for st in self.streams:

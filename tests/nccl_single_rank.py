@@ -30,8 +30,9 @@ def main():
     osc = O.OracleScene(tv)
     t_ref = osc.render_primary(cam.as_array13(), resx, resy, mode=O.MODE_IEEE)
     out = {}
-    for payload in ("rgb8", "hits"):
-        rnd = DistributedRenderer(sc, resx, resy, 0, 1, payload=payload, force_collective=True)
+    for payload, inline in (("rgb8", True), ("rgb8", False), ("hits", False)):
+        rnd = DistributedRenderer(sc, resx, resy, 0, 1, payload=payload, force_collective=True, inline_collective=inline)
+        assert rnd.inline == inline and rnd.nslots == (4 if inline else 3)
         for _ in range(7):
             rnd.render(cam)
         fr = rnd.flush()
@@ -39,15 +40,26 @@ def main():
         torch.cuda.synchronize()
         if payload == "rgb8":
             want = O.shade_depth(t_ref[0]).reshape(resy, resx, 3)
-            out["rgb8_equal"] = bool(np.array_equal(fr.cpu().numpy(), want))
+            out["rgb8_equal"] = out.get("rgb8_equal", True) and bool(np.array_equal(fr.cpu().numpy(), want))
         else:
             out["hits_equal"] = bool(np.array_equal(fr.t.cpu().numpy().view(np.uint32), t_ref[0].view(np.uint32)) and np.array_equal(fr.tri_id.cpu().numpy(), t_ref[3]))
+        if payload == "rgb8":   # a moving camera: after flush() the renderer's frame is the LAST camera's, whatever the slots did
+            rng = np.random.default_rng(11)
+            bmin, bmax = h.bbox()
+            ctr, ext = (bmin + bmax) * 0.5, (bmax - bmin)
+            cams = [FPSCamera((ctr + (rng.random(3) - 0.5) * ext * 0.6).astype(np.float32), rng.random() * 6.28, (rng.random() - 0.5)).camera() for _ in range(6)]
+            for cm in cams:
+                rnd.render(cm)
+            fr = rnd.flush()
+            torch.cuda.synchronize()
+            want = O.shade_depth(osc.render_primary(cams[-1].as_array13(), resx, resy, mode=O.MODE_IEEE)[0]).reshape(resy, resx, 3)
+            out["moving_equal"] = out.get("moving_equal", True) and bool(np.array_equal(fr.cpu().numpy(), want))
         t0 = time.perf_counter()
         for _ in range(30):
             rnd.render(cam)
         rnd.flush()
         torch.cuda.synchronize()
-        out[payload + "_ms_per_frame"] = round((time.perf_counter() - t0) / 30 * 1e3, 4)
+        out[payload + ("_inline" if inline else "") + "_ms_per_frame"] = round((time.perf_counter() - t0) / 30 * 1e3, 4)
     dist.destroy_process_group()
     print(json.dumps(out), flush=True)
 

@@ -415,8 +415,9 @@ def test_two_rank_bench_rehearsal(torch_mod):
 
 def test_rccl_code_path_single_rank(torch_mod):
     """The same route with the nccl (= RCCL) backend and ONE rank (tests/nccl_single_rank.py, a child process): process-group
-    initialisation on the device, the asynchronous dist.gather into per-rank views of one receive buffer, work.wait() on the slot's
-    stream, barrier -- the calls the 2/4/8-GPU bench makes -- with results checked against the oracle for both payloads."""
+    initialisation on the device, dist.gather into per-rank views of one receive buffer -- on the slot's own stream (the default)
+    and asynchronously with work.wait() on the slot's stream -- barrier: the calls the 2/4/8-GPU bench makes, with results checked
+    against the oracle for both payloads."""
     import json
     import os
     import subprocess
@@ -426,7 +427,7 @@ def test_rccl_code_path_single_rank(torch_mod):
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "nccl_single_rank.py")], capture_output=True, text=True, timeout=300, cwd=root, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert d["rgb8_equal"] and d["hits_equal"], d
+    assert d["rgb8_equal"] and d["hits_equal"] and d["moving_equal"], d
 
 
 @pytest.mark.parametrize("name,resx,resy,nl,refl", [("atrium:0.05", 640, 368, 2, False), ("atrium:0.05", 250, 130, 1, False), ("box", 256, 256, 1, False),
