@@ -1,35 +1,44 @@
 #!/usr/bin/env python3
 """bench.py -- the measurement contract of this repo.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1|3|4|5] [--scaling strong|weak] [--rank0-share F]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is ONE FRAME of primary rays through the hot path (RayGenerator + SafeInv + packet BVH traversal
-+ ray/triangle intersection -> hit records), inputs (SoA BVH, camera) resident in HBM before the timed
-region.  Workload at N=1 = BASELINE.json configs[1]: the sponza stand-in `atrium` (263 K triangles; the
-reference checkout lacks sponza.obj) at 1920x1080, primary rays.  At N>1 the frame has
-N times the pixels (same camera, both axes scaled by sqrt(N) and rounded to the 16x64 tile grid), cut
-into the reference's 16x64 tiles, dealt to the ranks by shuffled round-robin, traced with one launch per
-rank; the hit records stay in each rank's HBM, are shaded to RGB8 with the reference's depth shading
-(gVals[1], src/scene_trace.cpp:128-137 + ConvColor) and the RGB8 tiles are gathered to rank 0 with one RCCL
-collective per frame -- what a render node returns in the reference (src/node.cpp:336-349) -- asynchronously,
-overlapping the next frame's traversal; shading, gather and the rank-0 scatter are inside the timed region
-("scaling": "weak": per-GPU work is fixed as N grows).
+A "step" is ONE FRAME through the hot path (RayGenerator + SafeInv + packet BVH traversal + ray/triangle
+intersection -> hit records), inputs (BVH, camera) resident in HBM before the timed region.
 
-Mrays = rays launched (every lane of every traced packet, hit or miss), as TreeStats::TracingRays counts
-them (src/scene_trace.cpp:116-117): frames are padded to whole 16x16 packets (1920x1080 -> 1920x1088).
+Workloads (BASELINE.json `configs`; the reference checkout lacks sponza.obj, BASELINE.md section 2, so `atrium`
+-- 263 K triangles -- stands in for it and `stress` -- 996 K triangles -- for abrams + lancia):
+  --config 1 (default)  atrium 1920x1080, primary rays                      = the metric's configuration
+  --config 3            atrium 1920x1080, primary + one point light's shadow packets (Scene::RayTrace, simple shading)
+  --config 4            atrium 3840x2160, primary rays
+  --config 5            stress-1M 1920x1080, primary rays
+At N = 1 the frame's hit records (t, u, v, triId) are the output.  At N > 1 the SAME frame (default `--scaling strong`: the
+metric is quoted at 1920x1080 on 1/2/4/8 GPUs, and the reference's server cuts one fixed frame for its n render nodes,
+src/server.cpp:224-265, benchmark.txt:91-99) is cut into the reference's 16x64 tiles, dealt to the ranks by shuffled round-robin,
+every rank traces the packets of its tiles with one launch and shades them to RGB8 (gVals[1] depth shading + ConvColor, fused into
+the traversal kernel; config 3: the staged light pipeline), and ONE RCCL gather per frame returns the RGB8 tiles to rank 0 -- what
+a render node returns in the reference (src/node.cpp:336-349) -- which scatters them into the frame; shading, gather and scatter
+are inside the timed region.  `--rank0-share F` = the fraction of a fair tile share rank 0 renders itself (the reference's server
+renders nothing: 0).  `--scaling weak` = the round-1 mode: N x the pixels at N GPUs (both axes x sqrt N).
 
-roofline: bound "hbm"; achieved = algorithmic bytes per launch / mean kernel duration, where algorithmic
-bytes = sum over the launch's rays of B_alg(ray) = 32*V_n + 64*V_t + 16 (node boxes and
-triangles that ray tests in a single-ray cache-less walk, 16-B hit record) -- V_n, V_t counted once,
-outside the timed region, by the device accounting kernel; kernel duration from HIP events recorded on
-the launch stream around every timed launch.  NOTE: the packet algorithm fetches a node once per 256
-rays (one scalar load per wavefront), so achieved may legitimately EXCEED the HBM peak: the real HBM
-traffic is far below the single-ray algorithmic bytes (profiles/).
+Mrays = rays launched (every lane of every traced packet, hit or miss), as TreeStats::TracingRays counts them
+(src/scene_trace.cpp:116-117): frames are padded to whole 16x16 packets (1920x1080 -> 1920x1088); config 3 adds the shadow
+lanes with N.L > 0 (:554-557).
 
-cpu_baseline: the oracle (kind "port": this repo's CPU restatement of the reference's packet algorithm,
-SSE arithmetic mode = what the reference executes on x86) timed on this box's host cores, rank 0, N=1
-only, on whole frames of the same workload until ~15 CPU-core-seconds are spent."""
+roofline (one denominator everywhere: the step time, i.e. whole-frame throughput with 4 frames in flight -- the per-launch HIP-event
+duration `kernel_ms` is reported too, but with four launches overlapping it is not a stand-alone time):
+  bound "valu_issue": what the profiles show binds this kernel -- the SIMDs' vector issue (one wave64 VALU instruction per 2 cycles
+      per SIMD, 1024 SIMDs, 2.4 GHz = 1228.8 G wave-instructions/s).  achieved = VALU wave-instructions per launch (rocprofv3
+      SQ_INSTS_VALU of this workload, profiles/traffic.json) / step time.  frac <= 1 by construction.
+  hbm_frac_traffic     measured HBM bytes per launch (rocprofv3 FETCH_SIZE x2 (gfx950) + WRITE_SIZE, profiles/traffic.json) / step time / 8 TB/s
+  hbm_frac_packet_alg  PACKET-level algorithmic bytes -- 32 B x node visits + 64 B x triangle records fetched + 16 B x 256 hit records
+                       per packet, counted on the device by the diagnostic build of the kernel -- / step time / 8 TB/s
+  alg_single_ray_*     SURVEY.md section 8(d)'s single-ray, cache-less figure 32*V_n + 64*V_t + 16 per ray: informational only (a packet
+                       fetches a node once per 256 rays, so this is not a lower bound on anything the kernel does and exceeds the peak)
+cpu_baseline: the oracle (kind "port": this repo's CPU restatement of the reference's packet algorithm, one ray lane at a time in
+scalar code -- NOT the reference's 4-wide SSE code, so it understates the reference -- SSE arithmetic mode) timed on this box's host
+cores, rank 0, N=1 only, on whole frames of the same workload until ~15 CPU-core-seconds are spent."""
 from __future__ import annotations
 
 import os
@@ -40,7 +49,6 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import argparse
 import json
 import math
-import os
 import sys
 import time
 
@@ -48,29 +56,35 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+VALU_PEAK_GINST = 1024 * 2.4 / 2.0   # wave64 VALU instructions per ns: 1024 SIMDs x 2.4 GHz / 2 cycles each (MI355X_MICROARCH.md, cycle constants)
 CPU_THREADS_CAP = 16
 
+CONFIGS = {
+    1: dict(scene="atrium", res=(1920, 1080), lights=0, what="primary rays, hit records (t,u,v,triId)"),
+    3: dict(scene="atrium", res=(1920, 1080), lights=1, what="primary + 1 point light's shadow packets (Scene::RayTrace simple shading), rgb8 frame"),
+    4: dict(scene="atrium", res=(3840, 2160), lights=0, what="primary rays, hit records (t,u,v,triId)"),
+    5: dict(scene="stress", res=(1920, 1080), lights=0, what="primary rays, hit records (t,u,v,triId)"),
+}
 
-def pmc_traffic(workload_key: str):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/traffic.json: FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, KB -> bytes)."""
+
+def pmc_counters(workload_key: str):
+    """Per-launch PMC figures of the dominant kernel from the committed rocprofv3 passes of this same command
+    (profiles/traffic.json): HBM bytes = FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, and
+    SQ_INSTS_VALU.  Both are properties of (kernel build, scene, camera), not of the run: they are re-measured whenever the kernel changes."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(path):
         return None
     try:
-        d = json.load(open(path))
-        return d.get(workload_key)
+        return json.load(open(path)).get(workload_key)
     except Exception:
         return None
 
 
-def frame_size_for(n_gpus: int):
-    """N x the pixels of 1920x1080, same aspect, on the 16 x 64 tile grid."""
+def weak_frame_size(n_gpus: int, res):
+    """N x the pixels, same aspect, on the 16 x 64 tile grid (--scaling weak)."""
     s = math.sqrt(n_gpus)
-    resx = int(round(1920 * s / 16.0)) * 16
-    resy = int(round(1080 * s / 8.0)) * 8
-    return resx, resy
+    return int(round(res[0] * s / 16.0)) * 16, int(round(res[1] * s / 8.0)) * 8
 
 
 def cpu_baseline(tv, cam, resx, resy):
@@ -91,7 +105,8 @@ def cpu_baseline(tv, cam, resx, resy):
     med = times[len(times) // 2]
     rays = resx * ((resy + 15) // 16 * 16)
     return {"value": round(rays / med / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "%d full frame(s) of the same workload (%dx%d, %d rays each), oracle SSE mode, median frame time %.3f s, %d threads"
+            "sample": "%d full frame(s) of the same workload (%dx%d, %d primary rays each), median frame time %.3f s, %d threads; the oracle is a scalar, "
+                      "one-lane-at-a-time restatement of the packet algorithm (SSE arithmetic mode), not the reference's 4-wide SSE code: it understates the reference"
                       % (frames, resx, resy, rays, med, cores)}
 
 
@@ -100,13 +115,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--scene", default="atrium")
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="BASELINE.json configs[] entry (1 = the metric's)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: strong = the same frame cut for N ranks (the metric); weak = N x the pixels")
+    ap.add_argument("--rank0-share", type=float, default=1.0, help="N > 1: fraction of a fair tile share that rank 0 (which also gathers and scatters) renders; the reference's server renders nothing = 0")
+    ap.add_argument("--scene", default=None, help="override the config's scene (e.g. an OBJ dropped into scenes/, or atrium:0.05)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal only: all ranks share GPU 0 and the per-frame gather is staged through host memory")
     ap.add_argument("--streams", type=int, default=0, help="frames in flight (HIP streams); 0 = the renderer's default (4); 1 = strictly serial frames")
-    ap.add_argument("--event-every", type=int, default=8, help="bracket every n-th traversal launch with HIP events (kernel time of the roofline object)")
+    ap.add_argument("--event-every", type=int, default=8, help="bracket every n-th traversal launch with HIP events (roofline.kernel_ms)")
     ap.add_argument("--feedback-order", type=int, default=1, help="1 (default) = dispatch packets heaviest first by the node visits of an earlier frame (DistributedRenderer feedback_order)")
+    ap.add_argument("--lone-frames", type=int, default=12, help="N=1: frames traced one at a time after the timed region (lone_frame_ms); 0 = skip")
     args = ap.parse_args()
 
     import numpy as np
@@ -137,43 +156,55 @@ def main():
     from snail_amd.render import DistributedRenderer
     from snail_amd.scene import Scene
 
+    cfg = CONFIGS[args.config]
+    scene_name = args.scene or cfg["scene"]
     # ---- scene (host build, once; replicated into every GPU's HBM) ----
-    tv = scenes.scene_by_name(args.scene, scenes_dir=os.path.join(ROOT, "scenes"))
+    tv = scenes.scene_by_name(scene_name, scenes_dir=os.path.join(ROOT, "scenes"))
     t0 = time.perf_counter()
     hbvh = HostBVH.build(tv)
     build_s = time.perf_counter() - t0
-    if args.scene.startswith("stress"):
+    if scene_name.startswith("stress"):
         cam = FPSCamera(*scenes.stress_camera()).camera()
-    elif args.scene.startswith("atrium"):
+    elif scene_name.startswith("atrium"):
         cam = FPSCamera(*scenes.atrium_camera()).camera()
     else:   # an OBJ dropped into scenes/ (e.g. the real sponza.obj): the survey's far camera looking at the whole model
         from snail_amd import survey_camera
         cam = survey_camera(tv)
     scene = Scene(hbvh, local_rank)
-    resx, resy = frame_size_for(world)
+    resx, resy = cfg["res"] if (world == 1 or args.scaling == "strong") else weak_frame_size(world, cfg["res"])
+    lights7 = None
+    if cfg["lights"]:
+        bmin, bmax = hbvh.bbox()
+        c, e = (bmin + bmax) * 0.5, (bmax - bmin)
+        lights7 = np.array([[c[0], c[1] + 0.35 * e[1], c[2], 1.0, 0.9, 0.8, 2.0 * float(e.max())]], dtype=np.float32)   # one point light above the nave
     rnd = DistributedRenderer(scene, resx, resy, rank, world, slots=args.streams if args.streams > 0 else None, stage_cpu=rehearsal,
-                              feedback_order=bool(args.feedback_order))
-    total_rays = rnd.rays_per_frame() if world > 1 else resx * ((resy + 15) // 16 * 16)
-
-    # ---- algorithmic bytes (outside the timed region) ----
-    acc = scene.account_primary(cam, resx, resy) if rank == 0 else None
-    if rank == 0:
-        b_alg = (32.0 * float(acc[1]) + 64.0 * float(acc[2])) / float(acc[0]) + 16.0
-    else:
-        b_alg = 0.0
-    launch_rays = total_rays if world == 1 else rnd.plan.padded * 256
+                              feedback_order=bool(args.feedback_order), lights7=lights7, rank0_share=args.rank0_share)
+    primary_rays = rnd.rays_per_frame() if world > 1 else resx * ((resy + 15) // 16 * 16)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- rays per step (config 3 counts the shadow lanes too) and the diagnostics, all outside the timed region ----
+    st = scene.new_stats()
+    rnd.render(cam, stats=st)
+    rnd.flush()
+    barrier()
+    tot = rnd.reduce_stats(st) if world > 1 else st
+    total_rays = int(tot.cpu().numpy()[2]) if (rank == 0 and cfg["lights"]) else primary_rays
+    node_visits = int(tot.cpu().numpy()[1]) if rank == 0 else 0
+    acc = pk = None
+    if rank == 0 and world == 1:
+        acc = scene.account_primary(cam, resx, resy)                      # single-ray accounting walk, informational
+        pk = scene.packet_costs(cam, resx, resy)                          # per-packet {visits, ..., triangle records fetched, ...}
+
     for _ in range(args.warmup):
         rnd.render(cam)
     rnd.flush()
     barrier()
 
-    # ---- timed region: EXACTLY K steps (frames are pipelined over args.streams HIP streams, see DistributedRenderer) ----
+    # ---- timed region: EXACTLY K steps (frames are pipelined over the renderer's HIP streams, see DistributedRenderer) ----
     # HIP events bracket every `--event-every`-th launch on the stream it is launched on (an event record is a barrier packet in the
     # stream: bracketing every launch costs ~2 % of the frame rate; the average is taken over steps / event_every launches)
     every = max(1, args.event_every)
@@ -191,31 +222,69 @@ def main():
     timed = [e for e in ev if e is not None]
     kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in timed) / max(1, len(timed))
 
+    # ---- one frame at a time (N = 1): the latency a frame has when nothing else is in flight ----
+    lone_ms = None
+    if rank == 0 and world == 1 and args.lone_frames > 0:
+        ts = []
+        for _ in range(args.lone_frames):
+            torch.cuda.synchronize()
+            e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            rnd.render(cam, events=e)
+            rnd.flush()
+            ts.append(e[0].elapsed_time(e[1]))
+        ts.sort()
+        lone_ms = ts[len(ts) // 2]
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
+        step_s = ms_per_step * 1e-3
         value = total_rays * args.steps / elapsed / 1e6
-        achieved = launch_rays * b_alg / (kern_ms * 1e-3) / 1e9
-        tr = pmc_traffic("%s_%dx%d_n%d" % (args.scene, resx, resy, world))
-        traffic = round(tr["bytes_per_launch"] / (kern_ms * 1e-3) / 1e9, 1) if tr else None
-        hit_frac = float(torch.isfinite(rnd.frame.t).float().mean().item()) if rnd.frame is not None else float((rnd.frame_rgb8.amax(dim=2) > 0).float().mean().item())
+        key = "%s_%dx%d_n%d_c%d" % (scene_name, resx, resy, world, args.config)
+        tr = pmc_counters(key)
+        valu = tr.get("valu_insts_per_launch") if tr else None
+        traffic = tr.get("bytes_per_launch") if tr else None
+        roof = {"bound": "valu_issue", "achieved": round(valu / step_s / 1e9, 1) if valu else None, "peak": round(VALU_PEAK_GINST, 1), "unit": "Gwaveinst/s",
+                "frac": round(valu / step_s / 1e9 / VALU_PEAK_GINST, 4) if valu else None,
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE)",
+                "hbm_peak_GBs": HBM_PEAK_GBS, "hbm_frac_traffic": round(traffic / step_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                "valu_insts_per_launch": valu, "counters_source": tr.get("source") if tr else "no PMC pass committed for workload key %s" % key,
+                "kernel": "dev::k_primary", "kernel_ms": round(kern_ms, 5), "kernel_ms_note": "HIP events around the launch on its own stream while %d frames are in flight: overlapped, not a stand-alone duration; every fraction here uses ms_per_step" % rnd.nslots,
+                "denominator_ms": round(ms_per_step, 5), "lone_frame_ms": round(lone_ms, 5) if lone_ms is not None else None}
+        if pk is not None:
+            visits, fetched = int(pk[:, 0].sum()), int(pk[:, 4].sum())
+            pbytes = 32 * visits + 64 * fetched + 16 * 256 * len(pk)
+            roof.update({"packet_alg_bytes_per_launch": pbytes, "packet_node_visits": visits, "packet_tri_records_fetched": fetched,
+                         "hbm_frac_packet_alg": round(pbytes / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                         "compulsory_bytes_per_launch": 32 * hbvh.n_nodes + 64 * hbvh.n_tris + 16 * primary_rays})
+        if acc is not None:
+            b_alg = (32.0 * float(acc[1]) + 64.0 * float(acc[2])) / float(acc[0]) + 16.0
+            roof.update({"alg_single_ray_bytes_per_ray": round(b_alg, 1),
+                         "alg_single_ray_frac_of_hbm_peak": round(primary_rays * b_alg / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                         "alg_single_ray_note": "SURVEY 8(d)'s single-ray cache-less bytes; the packet kernel fetches a node once per 256 rays, so this is informational and may exceed 1"})
+        if rnd.frame is not None:
+            hit_frac = float(torch.isfinite(rnd.frame.t).float().mean().item())
+        else:
+            hit_frac = float((rnd.frame_rgb8.amax(dim=2) > 0).float().mean().item())
+        if world == 1:
+            par = "single-gpu"
+        else:
+            par = "tiles16x64-roundrobin-x%d (rank-0 share %.2f) + %s + per-frame RCCL gather of rgb8 tiles to rank 0 (overlapped with the next frames)" % (
+                world, args.rank0_share, "light pipeline" if cfg["lights"] else "depth-shade")
         out = {
-            "metric": "Mrays/sec (primary)", "value": round(value, 2), "unit": "Mrays/s",
+            "metric": "Mrays/sec (primary)" if not cfg["lights"] else "Mrays/sec (primary + shadow)", "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: gloo, ranks share one GPU -- not a measurement)",
-            "config": {"workload": "%s (%d tris, sponza.obj stand-in) %dx%d primary rays, hit records (t,u,v,triId)" % (args.scene, hbvh.n_tris, resx, resy),
-                       "rays_per_step": total_rays, "packets": "16x16 px = 1 wavefront", "bvh_nodes": hbvh.n_nodes, "bvh_depth": hbvh.depth,
-                       "bvh_build_s": round(build_s, 3), "hit_fraction": round(hit_frac, 5), "frames_in_flight": rnd.nslots, "packet_order": "heaviest first (node visits of an earlier frame)" if rnd.feedback else "built-in region interleave",
-                       "traversal_stack": "VGPR pair per wave (lane i = slot i), at most bvh_depth+1 = %d slots; LDS 0 B/wave in the main kernel (3328 B/wave only in the deferred M_EXACT pass)" % (hbvh.depth + 1),
-                       "parallelism": "tiles16x64-roundrobin-x%d + depth-shade + per-frame RCCL gather of rgb8 tiles to rank 0 (overlapped with the next frames)" % world if world > 1 else "single-gpu"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "traffic_bytes_per_launch": tr["bytes_per_launch"] if tr else None,
-                         "traffic_source": tr["source"] if tr else None, "kernel": "dev::k_primary", "kernel_ms": round(kern_ms, 5),
-                         "alg_bytes_per_ray": round(b_alg, 1), "rays_per_launch": launch_rays,
-                         "compulsory_bytes_per_ray": round((32.0 * hbvh.n_nodes + 64.0 * hbvh.n_tris) / launch_rays + 16.0, 2),
-                         # what actually bounds this kernel (profiles/README.md): the SIMDs' VALU pipes.  One wave64 VALU instruction per
-                         # 2 cycles per SIMD, 1024 SIMDs, 2.4 GHz; instruction count per launch from the committed PMC pass
-                         "valu_pipe_frac": round(tr["valu_insts_per_launch"] * 2.0 / (1024 * ms_per_step * 1e-3 * 2.4e9), 4) if tr and world == 1 and "valu_insts_per_launch" in tr else None,
-                         "note": "achieved = single-ray algorithmic bytes (32*V_n+64*V_t+16 per ray) / kernel time; the packet kernel fetches a node once per 256 rays, so this can exceed the HBM peak"},
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: gloo, ranks share one GPU -- not a measurement)",
+            "config": {"workload": "BASELINE config %d: %s (%d tris%s) %dx%d %s" % (args.config, scene_name, hbvh.n_tris,
+                                                                                     ", sponza.obj stand-in" if scene_name.startswith("atrium") else "", resx, resy, cfg["what"]),
+                       "baseline_config": args.config, "rays_per_step": total_rays, "primary_rays_per_step": primary_rays, "node_visits_per_step": node_visits,
+                       "packets": "16x16 px = 1 wavefront", "bvh_nodes": hbvh.n_nodes, "bvh_depth": hbvh.depth,
+                       "bvh_build_s": round(build_s, 3), "hit_fraction": round(hit_frac, 5), "frames_in_flight": rnd.nslots,
+                       "packet_order": "heaviest first (node visits of an earlier frame)" if rnd.feedback else "built-in region interleave",
+                       "traversal_stack": "VGPR pair per wave (lane i = slot i), at most bvh_depth = %d slots; LDS 0 B/wave in the main kernel (3328 B/wave only in the deferred M_EXACT pass)" % hbvh.depth,
+                       "packets_per_rank": [len(p) for p in rnd.plan.packets] if world > 1 else None,
+                       "parallelism": par},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(tv, cam, resx, resy)

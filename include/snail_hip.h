@@ -209,10 +209,17 @@ int snail_account_primary(SnailScene *, const float cam[13], int resx, int resy,
  * over `reps` back-to-back launches on the default stream of the current device.  tools/dispatch_rate.py. */
 int snail_debug_dispatch_rate(int blocks, int threads, int reps, float *ms_per_launch);
 
-/* Diagnostic: per-packet cost of one full-frame primary launch, row-major over the packet grid:
- * out4[p*4 + {0,1,2,3}] = {loop iterations, quad x triangle tests, shader-clock cycles of that wavefront,
- * start time >> 6}.  For load-balance studies (tools/packet_costs.py); not on any product path. */
-int snail_debug_packet_costs(SnailScene *, const float cam[13], int resx, int resy, uint32_t *out4);
+/* Diagnostic: per-packet cost of one full-frame primary launch (a diagnostic build of the same packet code, dev::k_primary_diag),
+ * row-major over the packet grid, 8 words per packet:
+ * out8[p*8 + {0..5}] = {loop iterations (node visits), quad x triangle tests, shader-clock cycles of that wavefront, start time >> 6,
+ * triangle records fetched (every triangle of every leaf body entered), leaf bodies entered}; words 6, 7 = 0.
+ * For load-balance studies (tools/packet_costs.py) and for bench.py's packet-level algorithmic bytes
+ * (32 B x node visits + 64 B x triangle records fetched + 16 B x 256 per packet); not on any product path. */
+int snail_debug_packet_costs(SnailScene *, const float cam[13], int resx, int resy, uint32_t *out8);
+
+/* Diagnostic: out = {blocks of dev::k_primary the occupancy API admits per CU, the device's block limit per CU, CUs, waves per block
+ * of this build}.  tools/occupancy.py. */
+int snail_debug_occupancy(int out[4]);
 
 /* Launch geometry of the last primary launch on this scene (for profiles): waves, blocks, VGPR-independent. */
 int snail_last_launch(const SnailScene *, int *blocks, int *threadsPerBlock);

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsnailhip.so")
+# SNAIL_LIB_PATH: load an experimental build of the same C-ABI (tools/variants.sh) without touching the product library
+LIB_PATH = os.environ.get("SNAIL_LIB_PATH") or os.path.join(HERE, "libsnailhip.so")
 
 
 class SnailError(RuntimeError):
@@ -51,6 +52,7 @@ SIGNATURES = {
     "snail_render_whitted_packets_dev": (_I, [_VP, _F13, _I, _I, _VP, _I, _VP, _I, _VP, _VP, _I, _VP, _VP, _VP]),
     "snail_account_primary": (_I, [_VP, _F13, _I, _I, _I, _I, _I, _I, _VP]),
     "snail_debug_packet_costs": (_I, [_VP, _F13, _I, _I, _VP]),
+    "snail_debug_occupancy": (_I, [_VP]),
     "snail_last_launch": (_I, [_VP, _VP, _VP]),
 }
 

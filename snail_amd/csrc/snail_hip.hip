@@ -32,6 +32,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "../../include/snail_hip.h"
@@ -184,6 +185,7 @@ struct Interval {
 
 struct Counters {
 	unsigned intersects, iters, skips;
+	unsigned fetched, leaves; // diagnostic (k_primary<.., DIAG>): triangle records fetched, leaf bodies entered; dead code elsewhere
 };
 
 // per-lane quad state: 4 rays
@@ -333,8 +335,10 @@ __device__ __forceinline__ bool leafShared(const uint4 *__restrict__ tris, int c
 	const bool inRange = lane >= first && lane <= last;
 	const int width = last - first + 1;
 	const u64 curRange = rangeMask(first, last);
+	st.leaves++;
 	for(int base = 0; base < count; base += 64) {
 		const int chunk = count - base < 64 ? count - base : 64;
+		st.fetched += (unsigned)chunk;
 		const bool mine = lane < chunk;
 		const Tri t = loadTriVector(tris, firstTri + base + (mine ? lane : 0));
 		const TriTerms tt = triTerms(t, org[0][0], org[1][0], org[2][0]);
@@ -401,6 +405,7 @@ __device__ __forceinline__ void leafPerRay(const uint4 *__restrict__ tris, int c
 										   Quad &Q, unsigned mask4, int (&tid)[4], float (&bu)[4], float (&bv)[4], Counters &st) {
 	const bool inRange = lane >= first && lane <= last;
 	const int width = last - first + 1;
+	st.leaves++; st.fetched += (unsigned)count;
 	for(int k = 0; k < count; k++) {
 		const Tri t = loadTriScalar(tris, firstTri + k);
 #pragma unroll
@@ -748,6 +753,25 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 	default: SNAIL_DESCEND_ASM_S(POP, PUSH, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s88", "s85", "s89", "s86"); break;                             \
 	}
 
+// Issue priority by work done (wave-uniform, at every leaf): packet costs are heavy-tailed and a frame ends with its heaviest
+// packets; a wave that has already popped more entries than most packets ever do is one of them.  s_setprio makes the SIMD's
+// arbiter prefer it over its co-resident waves (priority, then age: MI355X_MICROARCH.md, "Two waves per SIMD"), so the long
+// packets run at the speed of a lone wave while the short ones fill the gaps -- work-conserving, results untouched.
+#ifndef SNAIL_PRIO_T1
+#define SNAIL_PRIO_T1 0 // pops; 0 = off
+#define SNAIL_PRIO_T2 0
+#define SNAIL_PRIO_T3 0
+#endif
+#if SNAIL_PRIO_T1 > 0
+#define SNAIL_PRIO_BY_WORK(cnt)                                                                                                            \
+	do {                                                                                                                                   \
+		if((cnt) >= SNAIL_PRIO_T3) __builtin_amdgcn_s_setprio(3);                                                                          \
+		else if((cnt) >= SNAIL_PRIO_T2) __builtin_amdgcn_s_setprio(2);                                                                     \
+		else if((cnt) >= SNAIL_PRIO_T1) __builtin_amdgcn_s_setprio(1);                                                                     \
+	} while(0)
+#else
+#define SNAIL_PRIO_BY_WORK(cnt) do { } while(0)
+#endif
 // SHADOW=false: closest hit of a primary packet (distances >= 0; visits = 2 * pops - 1: every chain of visits starts with a pop,
 // the root is pushed here, and every push is popped).  SHADOW=true: any hit of a shadow packet (masked lanes -inf; the walk ends
 // when a triangle occludes the whole packet, so every visit is counted).  COH: one asm statement per sign octant, picked by a
@@ -792,6 +816,7 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes, c
 		else { SNAIL_SHARED_VARIANTS(SNAIL_POP_2W, SNAIL_PUSH_2W) }
 #undef SNAIL_SHARED_VARIANTS
 		if(leafSub == 0) break;
+		SNAIL_PRIO_BY_WORK(cnt);
 		if(leafShared<MASK, SHADOW, COH ? M_COH : M_FAST, BARY>(tris, leafAux, (int)((unsigned)leafSub & 0x7fffffffu), size, lane, first, last, org, Q, mask4,
 																 tid, bu, bv, iv, st))
 			break;
@@ -913,7 +938,7 @@ struct PrimaryArgs {
 	int *id;
 	unsigned char *bgr; // packet-major B,G,R of the gVals[1] depth shading (src/scene_trace.cpp:128-137), 3 B/ray, or null
 	u64 *stats;
-	unsigned *cost; // diagnostic: per packet {iters, intersects, shader cycles, start time low bits}
+	unsigned *cost; // diagnostic (k_primary_diag only): per packet 8 words {iters, intersects, shader cycles, start time >> 6, triangle records fetched, leaf bodies, 0, 0}
 	const int *order; // dispatch order (block -> slot index, a permutation of [0, nSlots)) or null = the built-in interleave
 	int *slotCost;	  // out, per slot: node visits of its packet (0 for a slot without a packet) or null
 	int nSlots;		  // rect mode: nBlocks; list mode: nPackets
@@ -937,7 +962,7 @@ __device__ __forceinline__ int interleave16(int b) { // -> logical index; 16 con
 // a packet that needs M_EXACT (a non-finite reciprocal: practically never for camera rays) is appended to A.defer and
 // left to the second, tiny kernel (EXACTPASS=true).  Keeping the select-based M_EXACT walk out of the main kernel
 // takes its register allocation from 128 to 84-96 VGPRs, i.e. from 4 to 5 waves per SIMD.
-template <bool DEEP, bool EXACTPASS>
+template <bool DEEP, bool EXACTPASS, bool DIAG = false>
 __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li, float *lds) {
 	const int lane = threadIdx.x & 63;
 
@@ -962,7 +987,7 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 		pidx = cy * A.pw + cx;
 	}
 
-	const u64 tStart = A.cost ? __builtin_amdgcn_s_memtime() : 0;
+	const u64 tStart = DIAG ? __builtin_amdgcn_s_memtime() : 0;
 	// ---- RayGenerator::Generate, level 3 (src/ray_generator.cpp:23-47): quad ty*4+k, lane j -> pixel (x+4k+j, y+ty)
 	Quad Q;
 	const int ty = lane >> 2, k4 = lane & 3;
@@ -989,7 +1014,7 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 #pragma unroll
 		for(int l = 0; l < 4; l++) org[c][l] = A.g.org[c];
 
-	Counters st = {0, 0, 0};
+	Counters st = {0, 0, 0, 0, 0};
 	int oct;
 	const int mode = classify(A.fastOK != 0, finite4(Q.id) && finite4(Q.d), true, Q.id, Q.dist, oct);
 	if(EXACTPASS) walk<true, false, false, M_EXACT, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st);
@@ -1008,10 +1033,11 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 
 	flushStats(A.stats, st, 256u, lane);
 	if(A.slotCost && lane == 0) A.slotCost[li] = (int)st.iters;
-	if(A.cost && lane == 0) {
+	if(DIAG && A.cost && lane == 0) {
 		const u64 tEnd = __builtin_amdgcn_s_memtime();
-		A.cost[(size_t)pidx * 4 + 0] = st.iters; A.cost[(size_t)pidx * 4 + 1] = st.intersects;
-		A.cost[(size_t)pidx * 4 + 2] = (unsigned)(tEnd - tStart); A.cost[(size_t)pidx * 4 + 3] = (unsigned)(tStart >> 6);
+		unsigned *c = A.cost + (size_t)pidx * 8;
+		c[0] = st.iters; c[1] = st.intersects; c[2] = (unsigned)(tEnd - tStart); c[3] = (unsigned)(tStart >> 6);
+		c[4] = st.fetched; c[5] = st.leaves; c[6] = 0; c[7] = 0;
 	}
 
 	if(A.bgr) { // fused gVals[1] depth shading + ConvColor: c = Inv(t) * (20, 250, 2), bytes B,G,R (same operations as k_shade_depth)
@@ -1058,16 +1084,38 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 #ifndef SNAIL_PRIMARY_WAVES
 #define SNAIL_PRIMARY_WAVES 5 // occupancy target of the primary kernel (6 measured equal, 4 slower: profiles/README.md)
 #endif
+// SNAIL_BLOCK_WAVES packets per workgroup (one per wave; waves end independently, nothing of the block is shared): the XCD's
+// region turn is kept -- wave w of hardware block B takes entry (B >> 3) * W + w of XCD (B & 7)'s list.
+#ifndef SNAIL_BLOCK_WAVES
+#define SNAIL_BLOCK_WAVES 1
+#endif
 template <bool DEEP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SNAIL_PRIMARY_WAVES))) void k_primary(PrimaryArgs A) {
+__global__ __launch_bounds__(64 * SNAIL_BLOCK_WAVES) __attribute__((amdgpu_waves_per_eu(SNAIL_PRIMARY_WAVES))) void k_primary(PrimaryArgs A) {
 	__shared__ float lds[LDS_FLOATS_PER_WAVE];
-	int li = interleave16((int)blockIdx.x);
+	const int wv = SNAIL_BLOCK_WAVES > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+	const int b = (int)blockIdx.x * SNAIL_BLOCK_WAVES + wv; // dispatch index of this wave's packet
+	int li;
+	if(SNAIL_BLOCK_WAVES > 1) {
+		const int xcd = (int)blockIdx.x & 7, j = ((int)blockIdx.x >> 3) * SNAIL_BLOCK_WAVES + wv;
+		li = (((j >> 4) << 3) + xcd) * 16 + (j & 15);
+	} else li = interleave16(b);
 	if(A.order) { // fed-back dispatch order (snail_order_from_cost_dev): heaviest packets of the previous frame first
-		if((int)blockIdx.x >= A.nSlots) return;
-		li = __builtin_amdgcn_readfirstlane(A.order[blockIdx.x]);
+		if(b >= A.nSlots) return;
+		li = __builtin_amdgcn_readfirstlane(A.order[b]);
 		if((unsigned)li >= (unsigned)A.nSlots) return;
+#ifdef SNAIL_PRIO_RANK // experiment: static priority by rank in the fed-back order (the heaviest SNAIL_PRIO_RANK packets: 3, next: 2, next two: 1)
+		if(b < SNAIL_PRIO_RANK) __builtin_amdgcn_s_setprio(3);
+		else if(b < 2 * SNAIL_PRIO_RANK) __builtin_amdgcn_s_setprio(2);
+		else if(b < 4 * SNAIL_PRIO_RANK) __builtin_amdgcn_s_setprio(1);
+#endif
 	}
 	primaryPacket<DEEP, false>(A, li, lds);
+}
+// the diagnostic build of the same packet code (snail_debug_packet_costs): per-packet cost records; never on a product path
+template <bool DEEP>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SNAIL_PRIMARY_WAVES))) void k_primary_diag(PrimaryArgs A) {
+	__shared__ float lds[LDS_FLOATS_PER_WAVE];
+	primaryPacket<DEEP, false, true>(A, interleave16((int)blockIdx.x), lds);
 }
 
 // Dispatch order from per-slot costs: slots in (approximately) descending cost -- a counting sort over 4096 cost classes, one
@@ -1336,7 +1384,7 @@ __device__ __forceinline__ void lightPacket(const ShadeArgs &A, const int li, co
 	for(int c = 0; c < 3; c++)
 #pragma unroll
 		for(int l = 0; l < 4; l++) lorg[c][l] = lp[c];
-	Counters st = {0, 0, 0};
+	Counters st = {0, 0, 0, 0, 0};
 	int stid[4];
 	float bu[4], bv[4];
 	if(EXACTPASS) walk<true, false, true, M_EXACT, false, DEEP, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st);
@@ -1424,7 +1472,7 @@ __global__ __launch_bounds__(64) void k_final(ShadeArgs A) {
 		unsigned cnt = 0;
 #pragma unroll
 		for(int l = 0; l < 4; l++) cnt += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(S.hit[l]));
-		const Counters none = {0, 0, 0};
+		const Counters none = {0, 0, 0, 0, 0};
 		flushStats(A.stats, none, cnt, lane);
 		return;
 	}
@@ -1561,7 +1609,7 @@ __device__ __forceinline__ void raysPacket(const RaysArgs &A, const int p, float
 	int tid[4] = {ov.x, ov.y, ov.z, ov.w};
 	float bu[4] = {b0.x, b0.y, b0.z, b0.w}, bv[4] = {b1.x, b1.y, b1.z, b1.w};
 
-	Counters st = {0, 0, 0};
+	Counters st = {0, 0, 0, 0, 0};
 	if(EXACTPASS) walk<SHARED, MASK, false, M_EXACT, BARY, DEEP, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, lds, st);
 	else {
 		bool fin = finite4(Q.id) && finite4(Q.d) && finite4(org);
@@ -1632,7 +1680,7 @@ __device__ __forceinline__ void shadowPacket(const RaysArgs &A, const int p, flo
 	int tid[4] = {0, 0, 0, 0};
 	float bu[4] = {0, 0, 0, 0}, bv[4] = {0, 0, 0, 0};
 
-	Counters st = {0, 0, 0};
+	Counters st = {0, 0, 0, 0, 0};
 	if(EXACTPASS) walk<true, false, true, M_EXACT, false, DEEP, false>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, lds, st);
 	else {
 		bool fin = finite4(Q.id) && finite4(Q.d) && finite4(org);
@@ -2013,13 +2061,15 @@ int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0
 	static const int dynLds = getenv("SNAIL_DEBUG_DYNLDS") ? atoi(getenv("SNAIL_DEBUG_DYNLDS")) : 0;
 	// a scene with sane records defers (practically) nothing: a handful of blocks suffices; an unsafe scene defers every packet
 	const int exactBlocks = A.fastOK ? (blocks < 8 ? blocks : 8) : (blocks < 2048 ? blocks : 2048);
-	if(useDeep(s)) {
-		hipLaunchKernelGGL(dev::k_primary<true>, dim3(blocks), dim3(64), dynLds, stream, A);
-		hipLaunchKernelGGL(dev::k_primary_exact<true>, dim3(exactBlocks), dim3(64), 0, stream, A);
-	} else {
-		hipLaunchKernelGGL(dev::k_primary<false>, dim3(blocks), dim3(64), dynLds, stream, A);
-		hipLaunchKernelGGL(dev::k_primary_exact<false>, dim3(exactBlocks), dim3(64), 0, stream, A);
-	}
+	static_assert(128 % SNAIL_BLOCK_WAVES == 0, "the slot count is a multiple of 128");
+	const dim3 grid(blocks / SNAIL_BLOCK_WAVES), block(64 * SNAIL_BLOCK_WAVES);
+	if(dCost) { // diagnostic launch (snail_debug_packet_costs)
+		if(useDeep(s)) hipLaunchKernelGGL(dev::k_primary_diag<true>, dim3(blocks), dim3(64), 0, stream, A);
+		else hipLaunchKernelGGL(dev::k_primary_diag<false>, dim3(blocks), dim3(64), 0, stream, A);
+	} else if(useDeep(s)) hipLaunchKernelGGL(dev::k_primary<true>, grid, block, dynLds, stream, A);
+	else hipLaunchKernelGGL(dev::k_primary<false>, grid, block, dynLds, stream, A);
+	if(useDeep(s)) hipLaunchKernelGGL(dev::k_primary_exact<true>, dim3(exactBlocks), dim3(64), 0, stream, A);
+	else hipLaunchKernelGGL(dev::k_primary_exact<false>, dim3(exactBlocks), dim3(64), 0, stream, A);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(s->deferDone[slot], stream));
 	s->deferUsed[slot] = true;
@@ -2149,7 +2199,7 @@ int snail_device_count(void) {
 
 SnailScene *snail_scene_create(const void *nodes32, int nNodes, const void *tris64, int nTris, int depth, int device) {
 	if(!nodes32 || !tris64 || nNodes <= 0 || nTris <= 0) { snail_set_error("snail_scene_create: empty scene"); return nullptr; }
-	if(depth > SNAIL_MAX_DEPTH) { snail_set_error("snail_scene_create: depth %d exceeds BVH::maxDepth %d", depth, SNAIL_MAX_DEPTH); return nullptr; }
+	if(depth < 0 || depth > SNAIL_MAX_DEPTH) { snail_set_error("snail_scene_create: depth %d outside 0..BVH::maxDepth = %d", depth, SNAIL_MAX_DEPTH); return nullptr; }
 	// validate topology on the host so that no kernel can index out of bounds (a GPU fault resets the node)
 	const uint32_t *nw = (const uint32_t *)nodes32;
 	for(int i = 0; i < nNodes; i++) {
@@ -2160,6 +2210,25 @@ SnailScene *snail_scene_create(const void *nodes32, int nNodes, const void *tris
 		} else {
 			if((uint64_t)sub + 1 >= (uint64_t)nNodes || sub == 0) { snail_set_error("snail_scene_create: node %d has child %u of %d", i, sub, nNodes); return nullptr; }
 			if((aux & 0xffff) > 2 || (aux >> 16) > 1) { snail_set_error("snail_scene_create: node %d has axis/firstNode %u/%u", i, aux & 0xffff, aux >> 16); return nullptr; }
+		}
+	}
+	// ... and that no walk can run away: every node is reached at most once from the root (no cycle, no shared subtree: a back-edge
+	// would keep every wave in its loop for ever) and no leaf lies deeper than the caller says (the traversal stack is sized by
+	// `depth`: lane i of a VGPR pair = slot i, a second pair beyond 62 levels; a deeper tree would wrap the lane select)
+	int realDepth = 0;
+	{
+		std::vector<uint8_t> seen((size_t)nNodes, 0);
+		std::vector<std::pair<int, int>> todo; // (node, level), root = level 0 as BVH::depth counts (src/bvh/tree.cpp:54-59)
+		todo.emplace_back(0, 0);
+		while(!todo.empty()) {
+			const auto [i, level] = todo.back();
+			todo.pop_back();
+			if(seen[i]) { snail_set_error("snail_scene_create: node %d is reachable twice from the root (cycle or shared subtree)", i); return nullptr; }
+			seen[i] = 1;
+			if(level > realDepth) realDepth = level;
+			if(level > depth) { snail_set_error("snail_scene_create: node %d lies at level %d, deeper than the declared depth %d", i, level, depth); return nullptr; }
+			const uint32_t sub = nw[(size_t)i * 8 + 6];
+			if(!(sub & 0x80000000u)) { todo.emplace_back((int)sub + 1, level + 1); todo.emplace_back((int)sub, level + 1); }
 		}
 	}
 	int fastOK = 1;
@@ -2179,7 +2248,7 @@ SnailScene *snail_scene_create(const void *nodes32, int nNodes, const void *tris
 	DeviceGuard guard(device);
 	if(!guard.ok) { snail_set_error("snail_scene_create: hipSetDevice(%d) failed", device); return nullptr; }
 	SnailScene *s = new SnailScene();
-	s->device = device; s->nNodes = nNodes; s->nTris = nTris; s->depth = depth; s->fastOK = fastOK;
+	s->device = device; s->nNodes = nNodes; s->nTris = nTris; s->depth = realDepth; s->fastOK = fastOK; // the measured depth (<= declared) picks the stack form
 	hipError_t e;
 	if((e = hipMalloc((void **)&s->dNodes, (size_t)nNodes * 32)) != hipSuccess || (e = hipMalloc((void **)&s->dTris, (size_t)nTris * 64)) != hipSuccess ||
 	   (e = hipMalloc((void **)&s->dStats, 4 * sizeof(unsigned long long))) != hipSuccess ||
@@ -2280,6 +2349,7 @@ int snail_trace_packets_ordered_dev(SnailScene *s, const float cam[13], int resx
 									float *u, float *v, int32_t *id, uint64_t *dStats, const int32_t *dOrder, int32_t *dSlotCost, void *stream) {
 	if(int rc = checkScene(s, "snail_trace_packets_ordered_dev")) return rc;
 	if(!dPacketXY && nPackets > 0) { snail_set_error("snail_trace_packets_ordered_dev: null packet list"); return 1; }
+	if(nPackets <= 0) return 0; // a rank without tiles (the reference's server renders nothing)
 	DeviceGuard guard(s->device);
 	return launchPrimary(s, cam, resx, resy, 0, 0, 0, 0, dPacketXY, nPackets, t, u, v, id, dStats, (hipStream_t)stream, nullptr, false, nullptr, dOrder, dSlotCost);
 }
@@ -2296,6 +2366,7 @@ int snail_trace_packets_dev(SnailScene *s, const float cam[13], int resx, int re
 							float *u, float *v, int32_t *id, uint64_t *dStats, void *stream) {
 	if(int rc = checkScene(s, "snail_trace_packets_dev")) return rc;
 	if(!dPacketXY && nPackets > 0) { snail_set_error("snail_trace_packets_dev: null packet list"); return 1; }
+	if(nPackets <= 0) return 0; // a rank without tiles (the reference's server renders nothing)
 	DeviceGuard guard(s->device);
 	return launchPrimary(s, cam, resx, resy, 0, 0, 0, 0, dPacketXY, nPackets, t, u, v, id, dStats, (hipStream_t)stream);
 }
@@ -2304,6 +2375,7 @@ int snail_trace_packets_shaded_dev(SnailScene *s, const float cam[13], int resx,
 								   uint64_t *dStats, void *stream) {
 	if(int rc = checkScene(s, "snail_trace_packets_shaded_dev")) return rc;
 	if((!dPacketXY || !bgr) && nPackets > 0) { snail_set_error("snail_trace_packets_shaded_dev: null buffer"); return 1; }
+	if(nPackets <= 0) return 0;
 	if((unsigned long long)bgr & 3) { snail_set_error("snail_trace_packets_shaded_dev: d_bgr must be 4-byte aligned"); return 1; }
 	DeviceGuard guard(s->device);
 	return launchPrimary(s, cam, resx, resy, 0, 0, 0, 0, dPacketXY, nPackets, nullptr, nullptr, nullptr, nullptr, dStats, (hipStream_t)stream, nullptr, false, bgr);
@@ -2566,18 +2638,30 @@ int snail_debug_dispatch_rate(int blocks, int threads, int reps, float *ms_per_l
 	return 0;
 }
 
-int snail_debug_packet_costs(SnailScene *s, const float cam[13], int resx, int resy, uint32_t *out4) {
+int snail_debug_occupancy(int out[4]) {
+	if(!out) { snail_set_error("snail_debug_occupancy: null output"); return 1; }
+	int dev = 0;
+	HIP_TRY(hipGetDevice(&dev));
+	int perCU = 0, maxBlocks = 0, cus = 0;
+	HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void *)dev::k_primary<false>, 64 * SNAIL_BLOCK_WAVES, 0));
+	HIP_TRY(hipDeviceGetAttribute(&maxBlocks, hipDeviceAttributeMaxBlocksPerMultiProcessor, dev));
+	HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+	out[0] = perCU; out[1] = maxBlocks; out[2] = cus; out[3] = SNAIL_BLOCK_WAVES;
+	return 0;
+}
+
+int snail_debug_packet_costs(SnailScene *s, const float cam[13], int resx, int resy, uint32_t *out8) {
 	if(int rc = checkScene(s, "snail_debug_packet_costs")) return rc;
-	if(!out4) { snail_set_error("snail_debug_packet_costs: null output"); return 1; }
+	if(!out8) { snail_set_error("snail_debug_packet_costs: null output"); return 1; }
 	DeviceGuard guard(s->device);
 	const int np = ((resx + 15) / 16) * ((resy + 15) / 16);
 	DevBuf c;
-	if(c.upload(nullptr, (size_t)np * 16)) { snail_set_error("snail_debug_packet_costs: allocation failed"); return 2; }
-	HIP_TRY(hipMemset(c.p, 0, (size_t)np * 16));
+	if(c.upload(nullptr, (size_t)np * 32)) { snail_set_error("snail_debug_packet_costs: allocation failed"); return 2; }
+	HIP_TRY(hipMemset(c.p, 0, (size_t)np * 32));
 	int rc = launchPrimary(s, cam, resx, resy, 0, 0, resx, resy, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, (unsigned *)c.p);
 	if(rc) return rc;
 	HIP_TRY(hipDeviceSynchronize());
-	if(c.download(out4, (size_t)np * 16)) { snail_set_error("snail_debug_packet_costs: download failed"); return 2; }
+	if(c.download(out8, (size_t)np * 32)) { snail_set_error("snail_debug_packet_costs: download failed"); return 2; }
 	return 0;
 }
 

@@ -33,18 +33,27 @@ def divide_image(resx: int, resy: int, bw: int = BLOCK_WIDTH, bh: int = BLOCK_HE
     return np.asarray(tiles, dtype=np.int32).reshape(-1, 4)
 
 
-def assign_tiles(n_tiles: int, n_ranks: int, seed: int = 20090501) -> np.ndarray:
-    """Shuffled round-robin of src/server.cpp:239-248: every group of n_ranks consecutive tiles gets a
-    fresh permutation of the ranks.  (The reference uses std::random_shuffle with the C library's unseeded
-    rand(); any permutation sequence balances equally well, so a seeded numpy generator is used and
-    the map is reproducible on every rank without communication.)"""
+def assign_tiles(n_tiles: int, n_ranks: int, seed: int = 20090501, rank0_share: float = 1.0) -> np.ndarray:
+    """Shuffled round-robin of src/server.cpp:239-248: every group of consecutive tiles gets a fresh permutation of the ranks
+    that take part in that round.  (The reference uses std::random_shuffle with the C library's unseeded rand(); any permutation
+    sequence balances equally well, so a seeded numpy generator is used and the map is reproducible on every rank without
+    communication.)
+
+    rank0_share: the fraction of a fair share that rank 0 renders.  In the reference the server renders nothing -- it receives,
+    decompresses and displays (src/server.cpp:233-265, :389-414) -- which is rank0_share = 0; 1.0 deals rank 0 in like everybody
+    else.  Rank 0 sits out of round g unless floor((g + 1) * share) > floor(g * share) (an even spread of its rounds)."""
     rng = np.random.RandomState(seed)
     owner = np.empty(n_tiles, dtype=np.int32)
-    order = np.arange(n_ranks)
-    for n in range(n_tiles):
-        if n % n_ranks == 0:
-            order = rng.permutation(n_ranks)
-        owner[n] = order[n % n_ranks]
+    share = 1.0 if n_ranks == 1 else min(1.0, max(0.0, float(rank0_share)))
+    n, g = 0, 0
+    while n < n_tiles:
+        takes_part = int(np.floor((g + 1) * share + 1e-9)) > int(np.floor(g * share + 1e-9))
+        ranks = np.arange(0 if takes_part else 1, n_ranks)
+        g += 1
+        order = ranks[rng.permutation(len(ranks))]
+        k = min(len(order), n_tiles - n)
+        owner[n:n + k] = order[:k]
+        n += k
     return owner
 
 
@@ -59,6 +68,10 @@ def tile_packets(tiles: np.ndarray) -> np.ndarray:
     return np.asarray(out, dtype=np.int32).reshape(-1, 2)
 
 
+# y of a pad entry of a padded packet list: below every image, so the scatter kernels (which clip to the image) skip it
+PAD_Y = 1 << 24
+
+
 @dataclass
 class ShardPlan:
     """Everything a rank needs, computed identically everywhere."""
@@ -68,25 +81,27 @@ class ShardPlan:
     tiles: np.ndarray            # [nTiles,4]
     owner: np.ndarray            # [nTiles]
     packets: list                # per rank: int32 [n_r,2]
-    padded: int                  # packets per rank after padding to equal size
+    padded: int                  # packets per rank after padding to equal size (the collective wants equal shards)
 
     @staticmethod
-    def make(resx: int, resy: int, n_ranks: int, seed: int = 20090501) -> "ShardPlan":
+    def make(resx: int, resy: int, n_ranks: int, seed: int = 20090501, rank0_share: float = 1.0) -> "ShardPlan":
         tiles = divide_image(resx, resy)
-        owner = assign_tiles(len(tiles), n_ranks, seed)
+        owner = assign_tiles(len(tiles), n_ranks, seed, rank0_share)
         packets = [tile_packets(tiles[owner == r]) for r in range(n_ranks)]
-        padded = max(len(p) for p in packets)
+        padded = max(1, max(len(p) for p in packets))
         return ShardPlan(resx, resy, n_ranks, tiles, owner, packets, padded)
 
     def padded_packets(self, rank: int) -> np.ndarray:
-        """Equal-sized shards for the collective: short ranks repeat their last packet (idempotent)."""
+        """The rank's packet list at the collective's shard size.  Pad entries lie outside every image (y = PAD_Y): a rank TRACES
+        only its len(packets[rank]) real packets (each packet once, so the ranks' TreeStats add up to the frame's), the pad region of
+        its payload buffer stays zero, and rank 0's scatter skips it."""
         p = self.packets[rank]
         if len(p) == self.padded:
             return p
-        if len(p) == 0:
-            return np.zeros((self.padded, 2), dtype=np.int32)
-        pad = np.repeat(p[-1:], self.padded - len(p), axis=0)
-        return np.concatenate([p, pad], axis=0)
+        pad = np.empty((self.padded - len(p), 2), dtype=np.int32)
+        pad[:, 0] = 0
+        pad[:, 1] = PAD_Y
+        return np.concatenate([p.reshape(-1, 2), pad], axis=0)
 
     def total_rays(self) -> int:
         return sum(len(p) for p in self.packets) * 256
@@ -138,11 +153,17 @@ class DistributedRenderer:
     Frames are pipelined over `slots` HIP streams (default 4 frames in flight; 3 when the gather runs asynchronously on the process group's own stream; give the process at least as many hardware queues,
     GPU_MAX_HW_QUEUES >= 6 in the environment before HIP initialises, or streams share queues and serialise): the traversal of frame i+1 fills the
     CUs that frame i's heaviest packets leave idle, and the gather of frame i (on its slot's stream, or RCCL's own)
-    overlaps both.  flush() completes the frames still in flight."""
+    overlaps both.  flush() completes the frames still in flight.
+
+    rank0_share: rank 0's fraction of a fair tile share (assign_tiles; the reference's server renders nothing = 0).
+    plan_ranks: cut the frame for this many ranks although the process group has `world_size` (default: world_size) -- with
+    force_collective and one rank this runs ONE share (`plan_rank`, default 0) of an N-rank frame through the whole route on a
+    single-GPU box (tools/host_rate.py: what the host can issue per second, the bound of the strong-scaling points)."""
 
     def __init__(self, scene, resx: int, resy: int, rank: int = 0, world_size: int = 1, group=None, seed: int = 20090501,
                  payload: str = "rgb8", slots: int | None = None, stage_cpu: bool = False, force_collective: bool = False, lights7=None,
-                 ambient=(0.1, 0.1, 0.1), color=(1.0, 1.0, 1.0), reflections: bool = False, feedback_order: bool = True, order_refresh: int = 4, inline_collective: bool | None = None):
+                 ambient=(0.1, 0.1, 0.1), color=(1.0, 1.0, 1.0), reflections: bool = False, feedback_order: bool = True, order_refresh: int = 16,
+                 inline_collective: bool | None = None, rank0_share: float = 1.0, plan_ranks: int | None = None, plan_rank: int | None = None):
         import torch
         self.torch = torch
         self.scene = scene
@@ -165,49 +186,71 @@ class DistributedRenderer:
         # operations of one communicator across user streams itself, and if a torch build still used the group's own stream the
         # call would only be a stream-level wait: correct either way.  Default on for the rgb8 payload; SNAIL_INLINE_COLLECTIVE=0 = off.
         self.inline = (bool(inline_collective) if inline_collective is not None else os.environ.get("SNAIL_INLINE_COLLECTIVE", "1") == "1") and payload == "rgb8" and not stage_cpu
-        self.plan = ShardPlan.make(resx, resy, world_size, seed)
+        n_plan = int(plan_ranks) if plan_ranks is not None else world_size
+        if n_plan != world_size and not (force_collective and world_size == 1):
+            raise ValueError("plan_ranks differs from world_size: only with force_collective and one rank (a one-rank rehearsal of an N-rank share)")
+        self.plan = ShardPlan.make(resx, resy, n_plan, seed, rank0_share)
+        share = rank if plan_rank is None else int(plan_rank)      # which share of the plan this process renders (rehearsals: any of them)
+        self.share = share
         dev = scene._dev()
         # four ACTIVE streams is the sweet spot on this part (profiles/README.md): 4 frames in flight, or 3 where the collective's own stream
         # is the fourth (asynchronous gather)
         self.nslots = max(1, slots) if slots is not None else (3 if self.multi and not self.inline else 4)
         self.streams = _stream_pool(torch, dev, self.nslots)
         self.step = 0
-        self.frames = [scene.alloc_frame(resx, resy) for _ in range(self.nslots if not self.multi else (1 if payload == "hits" else 0))] if rank == 0 else []
+        # one frame buffer per slot, for both payloads: the scatters of consecutive frames run on different streams and may overlap;
+        # frame / frame_rgb8 name the buffer of the frame enqueued last (complete after flush(), or once the slot's stream has drained)
+        # one rank with lights7: the staged config-3 pipeline writes the rgb8 frame directly (Scene.render_whitted), no hit-record frame
+        self.whitted_single = (not self.multi) and lights7 is not None
+        want_hits = rank == 0 and ((not self.multi and not self.whitted_single) or (self.multi and payload == "hits"))
+        self.frames = [scene.alloc_frame(resx, resy) for _ in range(self.nslots)] if want_hits else []
         self.frame = self.frames[0] if self.frames else None
-        # one frame buffer per slot: the scatters of consecutive frames run on different streams and may overlap; frame_rgb8 names the
-        # buffer of the frame enqueued last (complete after flush(), or once the slot's stream has drained)
         self.frames_rgb8 = ([torch.zeros((resy, resx, 3), dtype=torch.uint8, device=dev) for _ in range(self.nslots)]
-                            if (rank == 0 and self.multi and payload == "rgb8") else [])
+                            if (rank == 0 and ((self.multi and payload == "rgb8") or self.whitted_single)) else [])
         self.frame_rgb8 = self.frames_rgb8[0] if self.frames_rgb8 else None
         self.pending = [None] * self.nslots
         # feedback_order: dispatch the packets of a frame heaviest first, by the node visits counted in an earlier frame of the same
-        # slot (snail_order_from_cost_dev; re-derived every `order_refresh` frames of a slot, on the slot's own stream, so a launch
-        # never reads an order that is being rewritten).  Worth 10-12 % on heavy-tailed scenes (stress-1M 9.76 -> 10.79 Grays/s), neutral on the atrium (profiles/README.md).
+        # slot (snail_order_from_cost_dev, on the slot's own stream, so a launch never reads an order that is being rewritten).  The
+        # order of a slot is derived after its first frame and re-derived only when the camera has moved since AND `order_refresh`
+        # frames of the slot have passed: node visits of a nearby view predict the heavy packets just as well, and the one-workgroup
+        # sort (20 us alone, ~100 us beside four frames in flight) then never sits in a short timed region of a fixed view.
+        # Worth 10-12 % on heavy-tailed scenes (stress-1M 9.76 -> 10.79 Grays/s), neutral on the atrium (profiles/README.md).
         # On the tile-sharded rgb8 route a rank's packets all start at once (fewer packets than wave slots): the order cannot matter there.
-        self.feedback = bool(feedback_order) and (not self.multi or payload == "hits")
+        self.feedback = bool(feedback_order) and (not self.multi or payload == "hits") and not self.whitted_single
         self.order_refresh = max(1, int(order_refresh))
+        n_real = len(self.plan.packets[share]) if self.multi else 0
+        self.n_real = n_real
         if self.feedback:
-            n = scene.primary_slots(resx, resy) if not self.multi else self.plan.padded
-            self.slot_cost = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(self.nslots)]
-            self.order_buf = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(self.nslots)]
+            n = scene.primary_slots(resx, resy) if not self.multi else n_real
+            self.slot_cost = [torch.zeros(max(1, n), dtype=torch.int32, device=dev)[:n] for _ in range(self.nslots)]
+            self.order_buf = [torch.empty(max(1, n), dtype=torch.int32, device=dev)[:n] for _ in range(self.nslots)]
             self.order_valid = [False] * self.nslots
+            self.order_cam = [None] * self.nslots       # camera the slot's order was derived from
+            self.order_age = [0] * self.nslots          # frames of the slot since then
+            if n == 0:
+                self.feedback = False
         if self.multi:
             n = self.plan.padded
-            self.packet_xy = torch.from_numpy(self.plan.padded_packets(rank)).to(dev)
+            # the launch list holds the rank's REAL packets only (every packet traced and counted once); buffers have the shard size
+            self.packet_xy = torch.from_numpy(np.ascontiguousarray(self.plan.packets[share].reshape(-1, 2))).to(dev)
             if payload == "hits":
                 # per slot one buffer [4, n, 256] (t, u, v, triId) so that the four planes can travel in ONE collective
-                self.local = [torch.empty((4, n, 256), dtype=torch.float32, device=dev) for _ in range(self.nslots)]
-                self.planes = [(b[0], b[1], b[2], b[3].view(torch.int32)) for b in self.local]
-            self.bgr = [torch.empty((n, 256, 3), dtype=torch.uint8, device=dev) for _ in range(self.nslots)]
+                self.local = [torch.zeros((4, n, 256), dtype=torch.float32, device=dev) for _ in range(self.nslots)]
+                self.planes = [(b[0][:n_real], b[1][:n_real], b[2][:n_real], b[3][:n_real].view(torch.int32)) for b in self.local]
+            self.bgr = [torch.zeros((n, 256, 3), dtype=torch.uint8, device=dev) for _ in range(self.nslots)]
+            self.bgr_real = [b[:n_real] for b in self.bgr]
             if rank == 0:
-                self.all_xy = [torch.from_numpy(self.plan.padded_packets(r)).to(dev) for r in range(world_size)]
+                nw = world_size
+                # rank r's shard of the receive buffer is scattered with ITS padded list; pad entries (y = PAD_Y) are skipped
+                ranks_in_group = list(range(nw)) if n_plan == nw else [share]
+                self.all_xy = [torch.from_numpy(self.plan.padded_packets(r)).to(dev) for r in ranks_in_group]
                 if payload == "hits":
-                    self.gathered = [[torch.empty_like(self.local[0]) for _ in range(world_size)] for _ in range(self.nslots)]
+                    self.gathered = [[torch.empty_like(self.local[0]) for _ in range(nw)] for _ in range(self.nslots)]
                 else:
                     # ONE contiguous receive buffer per slot, handed to the collective as per-rank views, so that rank 0
                     # scatters all ranks' tiles with a single launch over the concatenated packet list
-                    self.gathered_all = [torch.empty((world_size, n, 256, 3), dtype=torch.uint8, device=dev) for _ in range(self.nslots)]
-                    self.gathered = [[g[r] for r in range(world_size)] for g in self.gathered_all]
+                    self.gathered_all = [torch.empty((nw, n, 256, 3), dtype=torch.uint8, device=dev) for _ in range(self.nslots)]
+                    self.gathered = [[g[r] for r in range(nw)] for g in self.gathered_all]
                     self.all_xy_cat = torch.cat(self.all_xy, dim=0).contiguous()
             else:
                 self.gathered = [None] * self.nslots
@@ -216,7 +259,7 @@ class DistributedRenderer:
         return self.plan.total_rays()
 
     def local_rays(self) -> int:
-        return len(self.plan.packets[self.rank]) * 256
+        return len(self.plan.packets[self.share]) * 256
 
     def _finish(self, slot):
         """complete the gather issued from `slot` and (rank 0) scatter it; runs on the slot's stream"""
@@ -229,53 +272,68 @@ class DistributedRenderer:
             self.frame_rgb8 = self.frames_rgb8[slot]
             self.scene.packets_bgr_to_frame(self.all_xy_cat, self.gathered_all[slot].view(-1, 256, 3), self.frame_rgb8)
 
-    def _refresh_order(self, slot, st):
-        if ((self.step - 1) // self.nslots) % self.order_refresh == 0:
-            self.scene.order_from_cost(self.slot_cost[slot], self.order_buf[slot], stream=st)
-            self.order_valid[slot] = True
+    def _order_for(self, slot, cam):
+        """the dispatch order this frame uses (or None), and whether to re-derive the slot's order from this frame's costs"""
+        key = cam.as_array13().tobytes()
+        if not self.order_valid[slot]:
+            return None, key
+        self.order_age[slot] += 1
+        refresh = self.order_cam[slot] != key and self.order_age[slot] >= self.order_refresh
+        return self.order_buf[slot], (key if refresh else None)
+
+    def _refresh_order(self, slot, st, key):
+        self.scene.order_from_cost(self.slot_cost[slot], self.order_buf[slot], stream=st)
+        self.order_valid[slot], self.order_cam[slot], self.order_age[slot] = True, key, 0
 
     def render(self, cam, stats=None, events=None):
         """Enqueue one frame; returns immediately.  `events` = optional (start, end) torch events recorded around the
         traversal launch on the stream it is launched on (bench.py)."""
         torch = self.torch
-        import torch.distributed as dist
         sc, p = self.scene, self.plan
         slot = self.step % self.nslots
         self.step += 1
         st = self.streams[slot]
-        with torch.cuda.stream(st):
-            if not self.multi:
-                if events: events[0].record(st)
-                if self.feedback:
-                    out = sc.trace_primary(cam, p.resx, p.resy, out=self.frames[slot], stats=stats, stream=st,
-                                           order=self.order_buf[slot] if self.order_valid[slot] else None, slot_cost=self.slot_cost[slot])
-                else:
-                    out = sc.trace_primary(cam, p.resx, p.resy, out=self.frames[slot], stats=stats, stream=st)
+        if not self.multi:      # every call below takes the stream explicitly: no stream context to enter (host time per frame matters)
+            if events: events[0].record(st)
+            if self.whitted_single:
+                self.frame_rgb8 = sc.render_whitted(cam, p.resx, p.resy, self.lights7, self.ambient, self.color, out=self.frames_rgb8[slot], stats=stats, stream=st,
+                                                    reflections=self.reflections)
                 if events: events[1].record(st)
-                if self.feedback: self._refresh_order(slot, st)
-                self.frame = out
-                return out
+                return self.frame_rgb8
+            if self.feedback:
+                order, key = self._order_for(slot, cam)
+                out = sc.trace_primary(cam, p.resx, p.resy, out=self.frames[slot], stats=stats, stream=st, order=order, slot_cost=self.slot_cost[slot])
+                if events: events[1].record(st)
+                if key is not None: self._refresh_order(slot, st, key)
+            else:
+                out = sc.trace_primary(cam, p.resx, p.resy, out=self.frames[slot], stats=stats, stream=st)
+                if events: events[1].record(st)
+            self.frame = out
+            return out
+        import torch.distributed as dist
+        with torch.cuda.stream(st):
             self._finish(slot)                       # the slot's buffers are free again after this
             if events: events[0].record(st)
             if self.payload == "hits":
                 if self.feedback:
-                    sc.trace_packets(cam, p.resx, p.resy, self.packet_xy, out=self.planes[slot], stats=stats, stream=st,
-                                     order=self.order_buf[slot] if self.order_valid[slot] else None, slot_cost=self.slot_cost[slot])
-                    self._refresh_order(slot, st)
+                    order, key = self._order_for(slot, cam)
+                    sc.trace_packets(cam, p.resx, p.resy, self.packet_xy, out=self.planes[slot], stats=stats, stream=st, order=order, slot_cost=self.slot_cost[slot])
+                    if key is not None: self._refresh_order(slot, st, key)
                 else:
                     sc.trace_packets(cam, p.resx, p.resy, self.packet_xy, out=self.planes[slot], stats=stats, stream=st)
             elif self.lights7 is not None:   # rgb8 payload, config-3 shading
-                sc.render_whitted_packets(cam, p.resx, p.resy, self.packet_xy, self.lights7, self.ambient, self.color, out=self.bgr[slot], stats=stats,
+                sc.render_whitted_packets(cam, p.resx, p.resy, self.packet_xy, self.lights7, self.ambient, self.color, out=self.bgr_real[slot], stats=stats,
                                           stream=st, reflections=self.reflections)
             else:   # rgb8 payload: the depth shading is fused into the traversal kernel's epilogue
-                sc.trace_packets_shaded(cam, p.resx, p.resy, self.packet_xy, out=self.bgr[slot], stats=stats, stream=st)
+                sc.trace_packets_shaded(cam, p.resx, p.resy, self.packet_xy, out=self.bgr_real[slot], stats=stats, stream=st)
             if events: events[1].record(st)
             if self.payload == "hits":
                 gather_planes(self.local[slot], self.rank, self.world, self.group, self.gathered[slot] if self.rank == 0 else None)
                 if self.rank == 0:
-                    for r in range(self.world):
-                        g = self.gathered[slot][r]
-                        sc.packets_to_frame(self.all_xy[r], (g[0], g[1], g[2], g[3].view(torch.int32)), self.frame, stream=st)
+                    self.frame = self.frames[slot]
+                    for k, xy in enumerate(self.all_xy):
+                        g = self.gathered[slot][k]
+                        sc.packets_to_frame(xy, (g[0], g[1], g[2], g[3].view(torch.int32)), self.frame, stream=st)
                 return self.frame
             if self.stage_cpu:
                 # rehearsal transport: same buffers and the same completion path as the RCCL route, bytes moved through the host

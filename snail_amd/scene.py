@@ -381,6 +381,16 @@ class Scene:
         _lib.check(_lib.lib().snail_account_primary(self._h, _lib.ptr(cam13), resx, resy, x0, y0, w, h, _lib.ptr(out)), "snail_account_primary")
         return out
 
+    def packet_costs(self, cam: Camera, resx: int, resy: int) -> np.ndarray:
+        """Per-packet diagnostics of one full-frame primary launch (snail_debug_packet_costs; a diagnostic build of the packet code,
+        never a product path): uint32 [packets, 8] = {node visits, quad x triangle tests, shader cycles, start >> 6, triangle records
+        fetched, leaf bodies, 0, 0}, row-major over the packet grid."""
+        np_ = ((resx + 15) // 16) * ((resy + 15) // 16)
+        out = np.zeros((np_, 8), dtype=np.uint32)
+        cam13 = np.ascontiguousarray(cam.as_array13(), dtype=np.float32)
+        _lib.check(_lib.lib().snail_debug_packet_costs(self._h, _lib.ptr(cam13), resx, resy, _lib.ptr(out)), "snail_debug_packet_costs")
+        return out
+
     def last_launch(self):
         b, t = C.c_int(0), C.c_int(0)
         _lib.check(_lib.lib().snail_last_launch(self._h, C.addressof(b), C.addressof(t)), "snail_last_launch")

@@ -43,7 +43,7 @@ def main():
             out["rgb8_equal"] = out.get("rgb8_equal", True) and bool(np.array_equal(fr.cpu().numpy(), want))
         else:
             out["hits_equal"] = bool(np.array_equal(fr.t.cpu().numpy().view(np.uint32), t_ref[0].view(np.uint32)) and np.array_equal(fr.tri_id.cpu().numpy(), t_ref[3]))
-        if payload == "rgb8":   # a moving camera: after flush() the renderer's frame is the LAST camera's, whatever the slots did
+        if True:   # a moving camera: after flush() the renderer's frame is the LAST camera's, whatever the slots did (both payloads: one frame buffer per slot)
             rng = np.random.default_rng(11)
             bmin, bmax = h.bbox()
             ctr, ext = (bmin + bmax) * 0.5, (bmax - bmin)
@@ -52,14 +52,39 @@ def main():
                 rnd.render(cm)
             fr = rnd.flush()
             torch.cuda.synchronize()
-            want = O.shade_depth(osc.render_primary(cams[-1].as_array13(), resx, resy, mode=O.MODE_IEEE)[0]).reshape(resy, resx, 3)
-            out["moving_equal"] = out.get("moving_equal", True) and bool(np.array_equal(fr.cpu().numpy(), want))
+            last = osc.render_primary(cams[-1].as_array13(), resx, resy, mode=O.MODE_IEEE)
+            if payload == "rgb8":
+                want = O.shade_depth(last[0]).reshape(resy, resx, 3)
+                out["moving_equal"] = out.get("moving_equal", True) and bool(np.array_equal(fr.cpu().numpy(), want))
+            else:
+                out["moving_hits_equal"] = bool(np.array_equal(fr.t.cpu().numpy().view(np.uint32), last[0].view(np.uint32)) and np.array_equal(fr.tri_id.cpu().numpy(), last[3]))
         t0 = time.perf_counter()
         for _ in range(30):
             rnd.render(cam)
         rnd.flush()
         torch.cuda.synchronize()
         out[payload + ("_inline" if inline else "") + "_ms_per_frame"] = round((time.perf_counter() - t0) / 30 * 1e3, 4)
+    # an UNEVEN 3-rank plan rendered share by share through the product route (real packets traced once each, pad entries skipped by
+    # the scatter): the shares' frames add up to the oracle's frame, and their TreeStats -- reduce_stats() over this one-rank group
+    # is the identity -- add up to the oracle's counters (src/node.cpp:358-359)
+    resx2, resy2 = 250, 130
+    ref2 = osc.render_primary(cam.as_array13(), resx2, resy2, mode=O.MODE_IEEE)
+    want2 = O.shade_depth(ref2[0]).reshape(resy2, resx2, 3)
+    total = np.zeros(4, dtype=np.int64)
+    union = np.zeros((resy2, resx2, 3), dtype=np.uint8)
+    sizes = []
+    for share in range(3):
+        rnd = DistributedRenderer(sc, resx2, resy2, 0, 1, force_collective=True, plan_ranks=3, plan_rank=share, rank0_share=0.5)
+        sizes.append(len(rnd.plan.packets[share]))
+        st = sc.new_stats()
+        rnd.render(cam, stats=st)
+        fr = rnd.flush()
+        torch.cuda.synchronize()
+        total += rnd.reduce_stats(st).cpu().numpy()
+        union |= fr.cpu().numpy()
+    out["uneven_sizes"] = sizes
+    out["uneven_frame_equal"] = bool(len(set(sizes)) > 1 and np.array_equal(union, want2))
+    out["uneven_stats_equal"] = bool(np.array_equal(total.astype(np.uint64), ref2[4]))
     dist.destroy_process_group()
     print(json.dumps(out), flush=True)
 

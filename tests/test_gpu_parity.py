@@ -282,6 +282,27 @@ def test_invalid_arguments_fail_loudly(torch_mod):
     with pytest.raises(SnailError):
         sc.trace_primary(cam, 0, 256)
     sc.close()
+    # snail_scene_create validates what it is handed: a walk must not be able to run away on a shared GPU
+    from snail_amd import HostBVH
+    from snail_amd.scene import Scene
+    tv2, hb, _ = util.scene_pair("atrium:0.02")
+    assert hb.depth >= 3
+    inner = [i for i in range(hb.n_nodes) if not (int(hb.nodes["sub"][i]) & 0x80000000)]
+    deep_inner = inner[-1]
+    def broken(mutate, depth=None):
+        nodes = hb.nodes.copy()
+        mutate(nodes)
+        return HostBVH(hb.tris, nodes, hb.depth if depth is None else depth, hb.perm)
+    def cyc(nodes):     # a back-edge: an inner node's children are the root's children again
+        nodes["sub"][deep_inner] = nodes["sub"][0]
+    def shared(nodes):  # two parents share one subtree (no cycle, but a node reachable twice)
+        a, b = inner[1], inner[2]
+        nodes["sub"][b] = nodes["sub"][a]
+    for bad in (broken(cyc), broken(shared), broken(lambda n: None, depth=hb.depth - 1)):
+        with pytest.raises(SnailError, match="reachable twice|deeper than the declared depth"):
+            Scene(bad, 0)
+    ok = Scene(broken(lambda n: None, depth=hb.depth + 5), 0)     # an over-stated depth is harmless
+    ok.close()
 
 
 def test_gpu_against_committed_fixtures(torch_mod):
@@ -393,23 +414,33 @@ def test_depth_shading_and_tile_pipeline(torch_mod):
     sc.close()
 
 
-def test_two_rank_bench_rehearsal(torch_mod):
+@pytest.mark.parametrize("extra,scaling,res", [([], "strong", (1920, 1080)), (["--rank0-share", "0.25"], "strong", (1920, 1080)),
+                                               (["--scaling", "weak"], "weak", (2720, 1528)), (["--config", "3"], "strong", (1920, 1080))])
+def test_two_rank_bench_rehearsal(torch_mod, extra, scaling, res):
     """The N>1 flow of bench.py end to end with two ranks sharing this GPU (gloo, payload staged through the host --
     NCCL refuses two ranks on one device): plan, packet-list launches, shading, per-frame gather, rank-0 scatter,
-    JSON contract.  The RCCL transport itself is the only part not exercised."""
+    JSON contract -- in BASELINE's strong-scaling mode (the same 1920x1080 frame cut for 2 ranks; also with rank 0 taking a
+    quarter share, and with config 3's light pipeline) and in the weak mode.  The RCCL transport itself is the only part not exercised."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--backend", "gloo", "--scene", "atrium:0.05"]
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--backend", "gloo", "--scene", "atrium:0.05"] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and d["scaling"] == "weak"
-    assert d["config"]["rays_per_step"] == (2720 // 16) * ((1528 + 15) // 16) * 256
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and d["scaling"] == scaling
+    assert d["config"]["primary_rays_per_step"] == (res[0] // 16) * ((res[1] + 15) // 16) * 256
+    assert sum(d["config"]["packets_per_rank"]) * 256 == d["config"]["primary_rays_per_step"]
+    if "--rank0-share" in extra:
+        assert d["config"]["packets_per_rank"][0] * 3 < d["config"]["packets_per_rank"][1]
+    if "--config" in extra:
+        assert d["config"]["rays_per_step"] > d["config"]["primary_rays_per_step"]      # + shadow lanes with N.L > 0
+    else:
+        assert d["config"]["rays_per_step"] == d["config"]["primary_rays_per_step"]
     assert d["config"]["hit_fraction"] > 0.5
 
 
@@ -427,7 +458,8 @@ def test_rccl_code_path_single_rank(torch_mod):
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "nccl_single_rank.py")], capture_output=True, text=True, timeout=300, cwd=root, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert d["rgb8_equal"] and d["hits_equal"] and d["moving_equal"], d
+    assert d["rgb8_equal"] and d["hits_equal"] and d["moving_equal"] and d["moving_hits_equal"], d
+    assert d["uneven_frame_equal"] and d["uneven_stats_equal"], d
 
 
 @pytest.mark.parametrize("name,resx,resy,nl,refl", [("atrium:0.05", 640, 368, 2, False), ("atrium:0.05", 250, 130, 1, False), ("box", 256, 256, 1, False),

@@ -162,6 +162,50 @@ def test_tile_plan_partitions_the_frame():
     assert all(sorted(own[i:i + 8].tolist()) == list(range(8)) for i in range(0, 64, 8))
 
 
+def test_tile_plan_rank0_share_and_pad_entries():
+    """rank0_share (the reference's server renders nothing, src/server.cpp:233-265): every packet still exactly once, rank 0 gets about
+    that fraction of a fair share, the others stay balanced; pad entries of a short rank lie outside the image (y = PAD_Y), so that
+    nothing is traced or counted twice and the scatter skips them."""
+    for share, n in ((0.0, 8), (0.25, 8), (0.5, 4), (1.0, 4), (0.0, 2)):
+        plan = R.ShardPlan.make(1920, 1080, n, rank0_share=share)
+        got = [tuple(p) for p in np.concatenate([p.reshape(-1, 2) for p in plan.packets], axis=0).tolist()]
+        assert len(got) == len(set(got)) == 120 * 68
+        sizes = [len(p) for p in plan.packets]
+        fair = 8160 / (n - 1 + share)
+        assert abs(sizes[0] - share * fair) <= 8 + 0.05 * fair, (share, n, sizes)
+        assert max(sizes[1:]) - min(sizes[1:]) <= 8
+        assert plan.padded == max(sizes)
+        for r in range(n):
+            pp = plan.padded_packets(r)
+            assert pp.shape == (plan.padded, 2) and np.array_equal(pp[:sizes[r]], plan.packets[r].reshape(-1, 2))
+            assert (pp[sizes[r]:, 1] == R.PAD_Y).all() and R.PAD_Y > 1 << 20
+    assert np.array_equal(R.assign_tiles(64, 8, rank0_share=1.0), R.assign_tiles(64, 8))      # the default is the reference's round-robin
+
+
+def test_scene_create_rejects_runaway_trees():
+    """snail_scene_create's host-side validation needs no GPU: a tree with a back-edge or a shared subtree (every wave would loop for
+    ever) or deeper than declared (the VGPR-lane stack would wrap) is refused before anything touches a device."""
+    from snail_amd import _lib
+    from tests import util
+    tv, hb, _ = util.scene_pair("atrium:0.02")
+    L = _lib.lib()
+    inner = [i for i in range(hb.n_nodes) if not (int(hb.nodes["sub"][i]) & 0x80000000)]
+    def create(nodes, depth):
+        h = L.snail_scene_create(_lib.ptr(nodes), len(nodes), _lib.ptr(hb.tris), hb.n_tris, depth, 0)
+        msg = L.snail_last_error().decode()
+        if h:
+            L.snail_scene_destroy(h)
+        return h, msg
+    cyc = hb.nodes.copy(); cyc["sub"][inner[-1]] = cyc["sub"][0]
+    h, msg = create(cyc, hb.depth); assert not h and "reachable twice" in msg, msg
+    sh = hb.nodes.copy(); sh["sub"][inner[2]] = sh["sub"][inner[1]]
+    h, msg = create(sh, hb.depth); assert not h and "reachable twice" in msg, msg
+    h, msg = create(hb.nodes, hb.depth - 1); assert not h and "deeper than the declared depth" in msg, msg
+    h, msg = create(hb.nodes, 65); assert not h and "depth" in msg, msg
+    oob = hb.nodes.copy(); oob["sub"][inner[0]] = hb.n_nodes
+    h, msg = create(oob, hb.depth); assert not h and "child" in msg, msg
+
+
 def build_adapter_mock(tmp_path):
     import subprocess
     exe = str(tmp_path / "adapter_mock")

@@ -1,7 +1,7 @@
 #!/bin/bash
 # experiment: broadcast of a leaf's surviving triangle by ds_bpermute (product) vs v_readlane (-DSNAIL_EXP_LEAF_READLANE).
 # Build first, on the build host: tools/exp_leaf.sh build (-> snail_amd/exp/lib_readlane.so, travels with the snapshot); then on the GPU box:
-# tools/exp_leaf.sh.  Overwrites the box's copy of libsnailhip.so while it runs.
+# tools/exp_leaf.sh.  Variants are loaded through SNAIL_LIB_PATH (snail_amd/_lib.py): the product library is never overwritten.
 set -u
 if [ "${1:-}" = build ]; then
   cd "$(dirname "$0")/../snail_amd/csrc" && mkdir -p ../exp
@@ -9,10 +9,9 @@ if [ "${1:-}" = build ]; then
   /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS -DSNAIL_EXP_LEAF_READLANE -shared snail_hip.hip bvh_build.cpp -o ../exp/lib_readlane.so && echo built
   exit
 fi
-cp snail_amd/libsnailhip.so /tmp/lib_base.so
 for round in 1 2; do
 for v in base ${VARIANTS:-readlane}; do
-  if [ $v = base ]; then cp /tmp/lib_base.so snail_amd/libsnailhip.so; else cp snail_amd/exp/lib_$v.so snail_amd/libsnailhip.so; fi
+  if [ $v = base ]; then unset SNAIL_LIB_PATH; else export SNAIL_LIB_PATH=$PWD/snail_amd/exp/lib_$v.so; fi
   for sc in atrium stress; do
     timeout -k 10 300 python bench.py --no-cpu-baseline --scene $sc > gpurun_out/expleaf_${v}_$sc.json 2> gpurun_out/expleaf.err || exit 1
     python - $v $sc <<'PY'
@@ -22,4 +21,3 @@ PY
   done
 done
 done
-cp /tmp/lib_base.so snail_amd/libsnailhip.so

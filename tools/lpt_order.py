@@ -13,7 +13,7 @@ pos, ang, pitch = scenes.atrium_camera() if name.startswith("atrium") else scene
 cam = FPSCamera(pos, ang, pitch).camera()
 sc = Scene(h, 0)
 pw, ph = (resx + 15) // 16, (resy + 15) // 16
-out = np.zeros((ph * pw, 4), dtype=np.uint32)
+out = np.zeros((ph * pw, 8), dtype=np.uint32)
 cam13 = np.ascontiguousarray(cam.as_array13(), dtype=np.float32)
 for rep in range(2):
     _lib.check(_lib.lib().snail_debug_packet_costs(sc._h, _lib.ptr(cam13), resx, resy, _lib.ptr(out)), "costs")
