@@ -10,6 +10,14 @@
 //                                     GetBBox, isctFlags, CElement/SElement.
 //   snail::TraceFrame(...)         -- frame-granular primary tracing into packet-major hit records, the
 //                                     accelerator seam the Cell port uses (`TaskInfo`, src/spu/trace.h:34-63).
+//   snail::RenderTiles / RenderImage -- the tile API of src/render.h:16-27 on the device pipeline (snail_render_tiles /
+//                                     snail_render_image): tile list -> planar R, G-R, B-R bytes at data + offsets[k]; image -> rgb8.
+//                                     With SNAIL_ADAPTER_RENDER_OVERLOADS defined before this header is included (in a translation
+//                                     unit of the reference, after "render.h"), `Render(...)` overloads with EXACTLY the reference's two
+//                                     signatures are declared for Scene<snail::HipBVH<...>>: more specialised than the reference's
+//                                     templates, so existing call sites (src/node.cpp:336-338, src/rtracer.cpp:385-386) pick them.
+//   snail::ShadowBatch / RayBatch  -- the batched form of the immediate path: collect the shadow / secondary packets of a tile,
+//                                     trace them with ONE snail_trace_shadow / snail_trace_rays call (nPackets), results copied back.
 //
 // Why two levels: one TraversePrimary(Context&) call carries 256 rays; a GPU launch per packet would be
 // launch-latency bound.  HipBVH therefore works in two modes:
@@ -28,6 +36,7 @@
 // them), so that this repository does not need -- and does not contain -- any reference header.
 #pragma once
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -108,7 +117,11 @@ public:
 	}
 
 	// ---- frame prefetch ----
-	template <class CameraT> void BeginFrame(const CameraT &cam, int resx, int resy) { TraceFrame(scene, cam, resx, resy, frame); haveFrame = true; }
+	template <class CameraT> void BeginFrame(const CameraT &cam, int resx, int resy) {
+		TraceFrame(scene, cam, resx, resy, frame);
+		haveFrame = true;
+		statsPending.store(true);   // the frame's TreeStats (one launch = one total) go to the first packet that is copied out
+	}
 	void EndFrame() { haveFrame = false; }
 	// the host's packet loop (RenderTask::Work, src/render.cpp:67-68) announces the packet it is about to trace
 	void SetPacket(int x, int y) const { curPacket = haveFrame ? (long)frame.packetIndex(x, y) : -1; }
@@ -131,6 +144,10 @@ public:
 			float *b = (float *)c.barycentric; // Vec2q = {u[4], v[4]} per quad
 			for(int q = 0; q < 64; q++) { std::memcpy(b + q * 8, &frame.u[o + q * 4], 16); std::memcpy(b + q * 8 + 4, &frame.v[o + q * 4], 16); }
 			curPacket = -1; // one primary traversal per announced packet; later calls are secondary packets
+			// the reference only ever SUMS per-packet TreeStats (src/render.cpp:236-238); the launch counted the whole frame at once
+			if(c.stats && statsPending.exchange(false)) {
+				c.stats->Intersection((unsigned)frame.stats[0]); c.stats->LoopIteration((unsigned)frame.stats[1]); c.stats->Skip((unsigned)frame.stats[3]);
+			}
 			return;
 		}
 		uint64_t st[4] = {0, 0, 0, 0};
@@ -156,7 +173,173 @@ private:
 	SnailScene *scene = nullptr;
 	FrameHits frame;
 	bool haveFrame = false;
+	mutable std::atomic<bool> statsPending{false};
 	static inline thread_local long curPacket = -1;   // per render thread (thread_pool workers, src/thread_pool.cpp)
 };
 
+// ---- batched immediate path --------------------------------------------------------------------------------------------------
+// One synchronous launch per 256-ray packet is launch-latency bound (and slower than the CPU the moment a light is on): a host
+// collects the shadow packets of a tile (one per primary packet and light, src/scene_trace.cpp:560-563) and traces them at once.
+// Add() copies the packet's inputs; Flush() makes ONE snail_trace_shadow call over all of them and writes every packet's
+// distances back through the pointer its context held (the contexts' arrays must stay alive until Flush()).
+class ShadowBatch {
+public:
+	explicit ShadowBatch(int packetQuads = SNAIL_PACKET_QUADS) : size(packetQuads) {}
+	template <class ShadowContextT> void Add(ShadowContextT &c) {
+		if(c.Size() != size) { std::fprintf(stderr, "FATAL: ShadowBatch: packet of %d quads in a batch of %d-quad packets\n", c.Size(), size); std::abort(); }
+		const float *o = (const float *)c.rays.OriginPtr();
+		origin.insert(origin.end(), {o[0], o[4], o[8]});
+		append(dir, (const float *)c.rays.DirPtr(), (size_t)size * 12);
+		append(idir, (const float *)c.rays.IDirPtr(), (size_t)size * 12);
+		append(dist, (const float *)c.distance, (size_t)size * 4);
+		out.push_back((float *)c.distance);
+	}
+	// returns {intersects, iterations, 0, skips} of the batch
+	template <class AccT, class StatsT> void Flush(const AccT &acc, StatsT *stats) {
+		if(out.empty()) return;
+		uint64_t st[4] = {0, 0, 0, 0};
+		SNAIL_CHECK(snail_trace_shadow(acc.Handle(), (int)out.size(), size, origin.data(), dir.data(), idir.data(), dist.data(), st));
+		for(size_t p = 0; p < out.size(); p++) std::memcpy(out[p], &dist[p * (size_t)size * 4], (size_t)size * 16);
+		if(stats) { stats->Intersection((unsigned)st[0]); stats->LoopIteration((unsigned)st[1]); stats->Skip((unsigned)st[3]); }
+		origin.clear(); dir.clear(); idir.clear(); dist.clear(); out.clear();
+	}
+	size_t Packets() const { return out.size(); }
+
+private:
+	static void append(std::vector<float> &v, const float *p, size_t n) { v.insert(v.end(), p, p + n); }
+	int size;
+	std::vector<float> origin, dir, idir, dist;
+	std::vector<float *> out;
+};
+
+// The same for secondary packets with per-ray origins and lane masks -- RayGroup<0,1>: reflections and transparency
+// (src/scene_trace.cpp:615-617, :631-633) -- or any other <sharedOrigin, hasMask> combination (one combination per batch).
+class RayBatch {
+public:
+	RayBatch(bool sharedOrigin, bool hasMask, int packetQuads = SNAIL_PACKET_QUADS) : shared(sharedOrigin), masked(hasMask), size(packetQuads) {}
+	template <class ContextT> void Add(ContextT &c) {
+		using RayGroupT = decltype(c.rays);
+		if((RayGroupT::sharedOrigin != 0) != shared || (RayGroupT::hasMask != 0) != masked || c.Size() != size) {
+			std::fprintf(stderr, "FATAL: RayBatch: context does not match the batch's <sharedOrigin, hasMask, size>\n"); std::abort();
+		}
+		append(origin, (const float *)c.rays.OriginPtr(), shared ? 12 : (size_t)size * 12);
+		append(dir, (const float *)c.rays.DirPtr(), (size_t)size * 12);
+		append(idir, (const float *)c.rays.IDirPtr(), (size_t)size * 12);
+		if(masked) { const uint8_t *m = (const uint8_t *)c.MaskPtr(); mask.insert(mask.end(), m, m + size); }
+		append(dist, (const float *)c.distance, (size_t)size * 4);
+		const int32_t *ob = (const int32_t *)c.object; obj.insert(obj.end(), ob, ob + (size_t)size * 4);
+		append(bary, (const float *)c.barycentric, (size_t)size * 8);
+		outDist.push_back((float *)c.distance); outObj.push_back((int32_t *)c.object); outBary.push_back((float *)c.barycentric);
+	}
+	template <class AccT, class StatsT> void Flush(const AccT &acc, StatsT *stats) {
+		if(outDist.empty()) return;
+		uint64_t st[4] = {0, 0, 0, 0};
+		SNAIL_CHECK(snail_trace_rays(acc.Handle(), (int)outDist.size(), size, shared ? 1 : 0, origin.data(), dir.data(), idir.data(), masked ? mask.data() : nullptr,
+									 dist.data(), obj.data(), bary.data(), st));
+		for(size_t p = 0; p < outDist.size(); p++) {
+			std::memcpy(outDist[p], &dist[p * (size_t)size * 4], (size_t)size * 16);
+			std::memcpy(outObj[p], &obj[p * (size_t)size * 4], (size_t)size * 16);
+			std::memcpy(outBary[p], &bary[p * (size_t)size * 8], (size_t)size * 32);
+		}
+		if(stats) { stats->Intersection((unsigned)st[0]); stats->LoopIteration((unsigned)st[1]); stats->Skip((unsigned)st[3]); }
+		origin.clear(); dir.clear(); idir.clear(); mask.clear(); dist.clear(); obj.clear(); bary.clear(); outDist.clear(); outObj.clear(); outBary.clear();
+	}
+	size_t Packets() const { return outDist.size(); }
+
+private:
+	static void append(std::vector<float> &v, const float *p, size_t n) { v.insert(v.end(), p, p + n); }
+	bool shared, masked;
+	int size;
+	std::vector<float> origin, dir, idir, dist, bary;
+	std::vector<uint8_t> mask;
+	std::vector<int32_t> obj;
+	std::vector<float *> outDist, outBary;
+	std::vector<int32_t *> outObj;
+};
+
+// ---- the tile API of src/render.h:16-27 on the device pipeline -----------------------------------------------------------------
+// What of Scene<AccStruct> / the global switches the device pipeline honours: scene.lights (pos, color, radius: src/light.h:5-16),
+// scene.ambientLight, the default material's colour (Scene::Scene sets (1,1,1), src/scene.cpp:6-10; SimpleMaterial::color is private,
+// hence a parameter), gVals[1] (depth shading) and gVals[7] (one mirrored bounce).  Textured materials / full shading data (gVals[6])
+// stay with the host path (HipBVH under the reference's own Render).
+struct RenderMode {
+	bool depthShading = false;  // gVals[1]
+	bool reflections = false;   // gVals[7]
+	float color[3] = {1.0f, 1.0f, 1.0f};
+};
+
+namespace detail {
+template <class CameraT> inline void cam13(const CameraT &cam, float (&c)[13]) {
+	const float v[13] = {cam.pos.x, cam.pos.y, cam.pos.z, cam.right.x, cam.right.y, cam.right.z, cam.up.x, cam.up.y, cam.up.z,
+						 cam.front.x, cam.front.y, cam.front.z, cam.plane_dist};
+	std::memcpy(c, v, sizeof(v));
+}
+template <class SceneT> inline std::vector<float> lights7(const SceneT &scene) {
+	std::vector<float> l;
+	for(const auto &li : scene.lights) l.insert(l.end(), {li.pos.x, li.pos.y, li.pos.z, li.color.x, li.color.y, li.color.z, li.radius});
+	if(l.size() > (size_t)SNAIL_MAX_LIGHTS * 7) { std::fprintf(stderr, "FATAL: snail::Render: %zu lights, the device pipeline takes %d\n", l.size() / 7, SNAIL_MAX_LIGHTS); std::abort(); }
+	return l;
+}
+template <class StatsT> inline StatsT toStats(const uint64_t (&st)[4]) {
+	StatsT s;
+	s.Intersection((unsigned)st[0]); s.LoopIteration((unsigned)st[1]); s.TracingRays((unsigned)st[2]); s.Skip((unsigned)st[3]);
+	return s;
+}
+} // namespace detail
+
+// Render(scene, camera, resx, resy, data, coords, offsets, ...) of src/render.h:16-19: coords = x, y, w, h per tile, offsets = byte
+// offset of each tile's three planes (R, G-R, B-R; 3*w*h bytes) in `data`.  Returns the summed TreeStats.
+template <class StatsT, class SceneT, class CameraT>
+inline StatsT RenderTiles(const SceneT &scene, const CameraT &camera, unsigned resx, unsigned resy, unsigned char *data, const std::vector<int> &coords,
+						  const std::vector<int> &offsets, const RenderMode &mode = RenderMode()) {
+	float c[13];
+	detail::cam13(camera, c);
+	const std::vector<float> l = detail::lights7(scene);
+	std::vector<int64_t> off(offsets.begin(), offsets.end());
+	const float amb[3] = {scene.ambientLight.x, scene.ambientLight.y, scene.ambientLight.z};
+	uint64_t st[4] = {0, 0, 0, 0};
+	SNAIL_CHECK(snail_render_tiles(scene.geometry.Handle(), c, (int)resx, (int)resy, coords.data(), off.data(), (int)(coords.size() / 4), l.data(), (int)(l.size() / 7), amb,
+								   mode.color, (mode.depthShading ? SNAIL_RENDER_DEPTH : 0) | (mode.reflections ? SNAIL_RENDER_REFLECTIONS : 0), data, st));
+	return detail::toStats<StatsT>(st);
+}
+
+// Render(scene, camera, image, ...) of src/render.h:21-23; ImageT = MipmapTexture (Width, Height, Pitch, DataPointer; rgb8).
+template <class StatsT, class SceneT, class CameraT, class ImageT>
+inline StatsT RenderImage(const SceneT &scene, const CameraT &camera, ImageT &image, const RenderMode &mode = RenderMode()) {
+	float c[13];
+	detail::cam13(camera, c);
+	const std::vector<float> l = detail::lights7(scene);
+	const float amb[3] = {scene.ambientLight.x, scene.ambientLight.y, scene.ambientLight.z};
+	uint64_t st[4] = {0, 0, 0, 0};
+	SNAIL_CHECK(snail_render_image(scene.geometry.Handle(), c, (int)image.Width(), (int)image.Height(), l.data(), (int)(l.size() / 7), amb, mode.color,
+								   (mode.depthShading ? SNAIL_RENDER_DEPTH : 0) | (mode.reflections ? SNAIL_RENDER_REFLECTIONS : 0),
+								   (unsigned char *)image.DataPointer(), (int)image.Pitch(), st));
+	return detail::toStats<StatsT>(st);
+}
+
 } // namespace snail
+
+// ---- overloads with the reference's own signatures (src/render.h:16-23) ---------------------------------------------------------
+// Define SNAIL_ADAPTER_RENDER_OVERLOADS before including this header in a translation unit that has seen the reference's "render.h"
+// (Scene, Camera, TreeStats, Options, MipmapTexture, vector, uint, gVals are the reference's names).  Both are more specialised than
+// the reference's `template <class AccStruct> TreeStats Render(const Scene<AccStruct>&, ...)`, so a call with a
+// Scene<snail::HipBVH<BVH>> resolves here and the whole tile list / image is rendered by the device pipeline.
+#ifdef SNAIL_ADAPTER_RENDER_OVERLOADS
+template <class RefBVH>
+inline TreeStats Render(const Scene<snail::HipBVH<RefBVH>> &scene, const Camera &camera, uint resx, uint resy, unsigned char *data, const vector<int> &coords,
+						const vector<int> &offsets, const Options options, uint rank, uint threads) {
+	(void)rank; (void)threads; // debug tint (gVals[8]) and the host thread pool have no device counterpart
+	snail::RenderMode mode;
+	mode.depthShading = gVals[1] != 0;
+	mode.reflections = gVals[7] != 0 || options.reflections;
+	return snail::RenderTiles<TreeStats>(scene, camera, resx, resy, data, coords, offsets, mode);
+}
+template <class RefBVH>
+inline TreeStats Render(const Scene<snail::HipBVH<RefBVH>> &scene, const Camera &camera, MipmapTexture &image, const Options options, uint threads) {
+	(void)threads;
+	snail::RenderMode mode;
+	mode.depthShading = gVals[1] != 0;
+	mode.reflections = gVals[7] != 0 || options.reflections;
+	return snail::RenderImage<TreeStats>(scene, camera, image, mode);
+}
+#endif

@@ -198,6 +198,29 @@ int snail_render_whitted_packets_dev(SnailScene *, const float cam[13], int resx
                                      const float *lights7, int nLights, const float ambient[3], const float color[3], int flags,
                                      uint8_t *d_bgr_packets, uint64_t *d_stats, void *stream);
 
+/* ---- the tile API (src/render.h:16-27) with host buffers ------------------------------------------------------------------ */
+/* The two Render(...) shapes of the reference as plain-pointer entry points; include/snail_adapter.hpp wraps them in overloads with
+ * the reference's exact signatures.  One call renders the WHOLE tile list / image on the device (same kernels as the *_dev entry
+ * points) and returns after the bytes are in the caller's host buffer.
+ *   snail_render_tiles = Render(scene, camera, resx, resy, data, coords, offsets, options, rank, threads) (src/render.h:16-19): per
+ *     tile k = (x, y, w, h) = coords[4k..4k+3] every 16x16 packet (RenderTask::Work order, src/render.cpp:67-68) through
+ *     Scene::RayTrace, stored as the three w*h byte planes R, G-R, B-R (mod 256) at data + offsets[k] (the `compress` store,
+ *     src/render.cpp:140-163; the reference leaves tiles other than 16x64 unwritten -- a TODO at :142-145 -- here every tile is
+ *     written).  `rank` (debug tint, gVals[8]) and `threads` have no device counterpart.
+ *   snail_render_image = Render(scene, camera, image, options, threads) (src/render.h:21-23): the interleaved B,G,R store into an
+ *     rgb8 image of `pitch` bytes per row (src/render.cpp:165-190, 214-240).
+ * Shading: flags & SNAIL_RENDER_DEPTH = gVals[1] "very simple shading" (src/scene_trace.cpp:128-137; lights ignored); otherwise the
+ * simple-shading configuration of snail_render_whitted_dev with the given lights (0..8), SNAIL_RENDER_REFLECTIONS = gVals[7].
+ * stats (optional) += {intersects, iterations, traced rays, skips} of the call -- the TreeStats the reference's Render returns.
+ * The device-side packet / tile lists are cached in the scene handle and rebuilt only when the tile list changes. */
+#define SNAIL_RENDER_REFLECTIONS 1
+#define SNAIL_RENDER_DEPTH       2
+int snail_render_tiles(SnailScene *, const float cam[13], int resx, int resy, const int32_t *coords, const int64_t *offsets, int nTiles,
+                       const float *lights7, int nLights, const float ambient[3], const float color[3], int flags, uint8_t *data,
+                       uint64_t stats[4]);
+int snail_render_image(SnailScene *, const float cam[13], int resx, int resy, const float *lights7, int nLights, const float ambient[3],
+                       const float color[3], int flags, uint8_t *image_bgr, int pitch, uint64_t stats[4]);
+
 /* ---- measurement support ------------------------------------------------------------------------- */
 /* Single-ray, cache-less accounting walk of SURVEY.md section 8(d) over the same padded packet set as
  * snail_trace_primary: d_out[0] += rays, [1] += sum V_n (node boxes tested), [2] += sum V_t

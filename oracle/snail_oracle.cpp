@@ -57,6 +57,26 @@ inline V3 cross(V3 b, V3 c) { return V3{b.y * c.z - b.z * c.y, b.z * c.x - b.x *
 inline V3 VMin(V3 a, V3 b) { return V3{Min(a.x, b.x), Min(a.y, b.y), Min(a.z, b.z)}; }
 inline V3 VMax(V3 a, V3 b) { return V3{Max(a.x, b.x), Max(a.y, b.y), Max(a.z, b.z)}; }
 
+// ---- small expressions of the shading path, named so that tests/test_oracle_pins.py can pin each of them against the SAME expression
+// written with the reference's own veclib types (oracle/veclib_probe.cpp `exprs`, built from /root/reference/veclib) ----
+// Abs(f32x4) clears the sign bit (veclib/sse/f32.h:105): -0 -> +0, NaN stays NaN
+inline float AbsQ(float v) { return fabsf(v); }
+// Reflect (src/rtbase_math.h:54-58): dot = nrm | ray; ray - nrm * (dot + dot)
+inline V3 reflect(V3 ray, V3 nrm) { const float dt = dot(nrm, ray); return ray - nrm * (dt + dt); }
+// SafeInv (src/rtbase.h:117-120): Inv(v + 1e-8) per component
+template <int MODE> inline float safeInv(float d) { return Inv<MODE>(d + 0.00000001f); }
+// FastInv(f32x4) = raw rcpps (veclib/sse/f32.h:101); the scalar definition is Inv (veclib/vecbase.h:57)
+template <int MODE> inline float FastInv(float x) { return MODE == ORC_MODE_SSE ? _mm_cvtss_f32(_mm_rcp_ps(_mm_set1_ps(x))) : 1.0f / x; }
+// the light's attenuation (src/scene_trace.cpp:585-587): Max(0, ((1 - a) * 0.2 + FastInv(16 * a * a)) - 0.0625), a = distance * iRadius
+template <int MODE> inline float attenuation(float distance, float iRadius) {
+	const float atten = distance * iRadius;
+	return Max(0.0f, ((1.0f - atten) * 0.2f + FastInv<MODE>(16.0f * atten * atten)) - 0.0625f);
+}
+// one channel of ConvColor (src/render.cpp:11-17): Trunc(Clamp(c * 255, 0, 255)), Clamp(o, lo, hi) = Min(Max(o, lo), hi) (veclib/vecbase.h:77)
+inline int convChannel(float c) { return (int)Min(Max(c * 255.0f, 0.0f), 255.0f); }
+// ForWhich(a < b) (veclib/sse/f32.h:84): bit l = lane l of the ordered compare
+inline int forWhichLess(const float (&a)[4], const float (&b)[4]) { int m = 0; for(int l = 0; l < 4; l++) m |= (a[l] < b[l] ? 1 : 0) << l; return m; }
+
 struct Box { V3 mn, mx; };
 // src/triangle.h:35-37,62-70: P2 = ba + a, P3 = ca + a; BoundMin = VMin(P1, VMin(P2, P3))
 inline Box triBox(const OrcTri &t) {
@@ -468,7 +488,7 @@ void genPacket(const RayGen &g, int x, int y, float *dir, float *idir) {
 				float d[3] = {px * rs, py * rs, pz * rs};
 				for(int c = 0; c < 3; c++) {
 					dir[q * 12 + c * 4 + l] = d[c];
-					idir[q * 12 + c * 4 + l] = Inv<MODE>(d[c] + 0.00000001f); // SafeInv, src/rtbase.h:117-120
+					idir[q * 12 + c * 4 + l] = safeInv<MODE>(d[c]); // SafeInv, src/rtbase.h:117-120
 				}
 			}
 		}
@@ -630,8 +650,7 @@ void rayTracePacket(const OrcNode *nodes, const OrcTri *tris, const Rays &r, con
 			const OrcTri &t = tris[obj[i]];
 			for(int c = 0; c < 3; c++) nrm[i][c] = t.plane[c];
 			V3 d{r.D(q, 0, l), r.D(q, 1, l), r.D(q, 2, l)};
-			float dn = dot(d, mk(nrm[i]));
-			dn = dn < 0.0f ? -dn : dn;                        // Abs(rays.Dir | normal)
+			const float dn = AbsQ(dot(d, mk(nrm[i])));        // Abs(rays.Dir | normal)
 			for(int c = 0; c < 3; c++) sdiff[i][c] = sspec[i][c] = L.color[c] * dn;
 		} else for(int c = 0; c < 3; c++) { nrm[i][c] = 0.0f; sdiff[i][c] = sspec[i][c] = 0.0f; }
 	}
@@ -648,16 +667,15 @@ void rayTracePacket(const OrcNode *nodes, const OrcTri *tris, const Rays &r, con
 				if(!hit[i]) continue;
 				sel[q] |= (uint8_t)(1 << l);
 				V3 d{r.D(q, 0, l), r.D(q, 1, l), r.D(q, 2, l)}, n = mk(nrm[i]);
-				const float dt = dot(n, d);
-				const V3 rd = d - n * (dt + dt);
+				const V3 rd = reflect(d, n);
 				const float f[3] = {rd.x, rd.y, rd.z};
 				for(int c = 0; c < 3; c++) {
 					rdir[q * 12 + c * 4 + l] = f[c];
 					rorg[q * 12 + c * 4 + l] = pos[i][c] + f[c] * 0.001f;
-					ridir[q * 12 + c * 4 + l] = Inv<MODE>(f[c] + 0.00000001f);
+					ridir[q * 12 + c * 4 + l] = safeInv<MODE>(f[c]);
 				}
 			}
-			for(int l = 0; l < 4; l++) if(!hit[q * 4 + l]) for(int c = 0; c < 3; c++) ridir[q * 12 + c * 4 + l] = Inv<MODE>(0.0f + 0.00000001f);
+			for(int l = 0; l < 4; l++) if(!hit[q * 4 + l]) for(int c = 0; c < 3; c++) ridir[q * 12 + c * 4 + l] = safeInv<MODE>(0.0f);
 			all = all && sel[q] == 15;
 		}
 		// selector.All() ? RayGroup<0,0> : RayGroup<0,1> -- the same walk either way; a full mask selects nothing away
@@ -698,7 +716,7 @@ void rayTracePacket(const OrcNode *nodes, const OrcTri *tris, const Rays &r, con
 				const float inv = Inv<MODE>(distance[i]);
 				V3 fl = lv * inv;
 				const float f[3] = {fl.x, fl.y, fl.z};
-				for(int c = 0; c < 3; c++) { sdir[q * 12 + c * 4 + l] = f[c]; sidir[q * 12 + c * 4 + l] = Inv<MODE>(f[c] + 0.00000001f); }
+				for(int c = 0; c < 3; c++) { sdir[q * 12 + c * 4 + l] = f[c]; sidir[q * 12 + c * 4 + l] = safeInv<MODE>(f[c]); }
 				dotv[i] = dot(mk(nrm[i]), fl);
 				if(dotv[i] > 0.0f) { sdist[i] = distance[i] * 0.9999f; st.rays++; }
 			}
@@ -710,9 +728,7 @@ void rayTracePacket(const OrcNode *nodes, const OrcTri *tris, const Rays &r, con
 
 		for(int i = 0; i < 256; i++) {
 			if(!(sdist[i] > 0.0f)) continue;          // += Condition(msk, ...) adds +0 otherwise
-			float atten = distance[i] * iRadius;
-			const float finv = MODE == ORC_MODE_SSE ? _mm_cvtss_f32(_mm_rcp_ps(_mm_set1_ps(16.0f * atten * atten))) : 1.0f / (16.0f * atten * atten);
-			atten = Max(0.0f, ((1.0f - atten) * 0.2f + finv) - 0.0625f);
+			const float atten = attenuation<MODE>(distance[i], iRadius);
 			const float diffMul = dotv[i] * atten;
 			float specMul = dotv[i];
 			specMul *= specMul; specMul *= specMul; specMul *= specMul; specMul *= specMul;
@@ -755,7 +771,7 @@ void renderWhitted(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *ca
 				int xx = px + (q & 3) * 4 + l;
 				if(xx >= resx) continue;
 				uint8_t *d = frame + (size_t)yy * pitch + (size_t)xx * 3;
-				for(int c = 0; c < 3; c++) d[2 - c] = (uint8_t)(int)Min(Max(col[q * 4 + l][c] * 255.0f, 0.0f), 255.0f); // r,g,b -> B,G,R
+				for(int c = 0; c < 3; c++) d[2 - c] = (uint8_t)convChannel(col[q * 4 + l][c]); // r,g,b -> B,G,R
 			}
 		}
 	});
@@ -865,7 +881,7 @@ void orc_shade_depth(const float *t, int n, uint8_t *bgr, int mode) {
 		float dist = mode == ORC_MODE_SSE ? Inv<ORC_MODE_SSE>(t[i]) : Inv<ORC_MODE_IEEE>(t[i]);
 		float c[3] = {dist * 20.0f, dist * 250.0f, dist * 2.0f}; // r, g, b
 		int q[3];
-		for(int k = 0; k < 3; k++) q[k] = (int)Min(Max(c[k] * 255.0f, 0.0f), 255.0f); // Trunc(Clamp(..)), src/render.cpp:11-17
+		for(int k = 0; k < 3; k++) q[k] = convChannel(c[k]); // Trunc(Clamp(..)), src/render.cpp:11-17
 		bgr[i * 3 + 0] = (uint8_t)q[2]; bgr[i * 3 + 1] = (uint8_t)q[1]; bgr[i * 3 + 2] = (uint8_t)q[0];
 	}
 }
@@ -899,6 +915,41 @@ void orc_planar_decode_tile(const uint8_t *planes, int x, int y, int w, int h, u
 	}
 }
 void orc_debug_range_hist(uint64_t *hist) { g_rangeHist = hist; }
+// The named shading expressions on one row of eight floats (qa = in[0..3], qb = in[4..7] as two SSE quads; v1 = (qa, qa<<<1, qa<<<2),
+// v2 = (qb, qb<<<1, qb<<<2) as two Vec3q, <<< = lane rotation) -- the same row the reference's veclib evaluates in
+// oracle/veclib_probe.cpp `exprs`; word layout documented there.  Words 45.. use the approximate operations (mode).
+void orc_veclib_exprs(const float *in, uint32_t *out, int mode) {
+	auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+	float qa[4], qb[4];
+	V3 v1[4], v2[4];
+	for(int l = 0; l < 4; l++) { qa[l] = in[l]; qb[l] = in[4 + l]; }
+	for(int l = 0; l < 4; l++) {
+		v1[l] = V3{qa[l], qa[(l + 1) & 3], qa[(l + 2) & 3]};
+		v2[l] = V3{qb[l], qb[(l + 1) & 3], qb[(l + 2) & 3]};
+	}
+	const int m = forWhichLess(qa, qb);
+	out[0] = (uint32_t)m | (m ? 16u : 0u) | (m == 15 ? 32u : 0u);       // ForWhich | ForAny << 4 | ForAll << 5
+	for(int l = 0; l < 4; l++) {
+		out[1 + l] = bits(sqrtf(qa[l]));
+		out[5 + l] = bits(AbsQ(qa[l]));
+		out[9 + l] = bits(dot(v1[l], v2[l]));
+		const V3 cr = cross(v1[l], v2[l]), rf = reflect(v1[l], v2[l]);
+		out[13 + l] = bits(cr.x); out[17 + l] = bits(cr.y); out[21 + l] = bits(cr.z);
+		out[25 + l] = bits(rf.x); out[29 + l] = bits(rf.y); out[33 + l] = bits(rf.z);
+		out[37 + l] = bits(((m >> l) & 1) ? v1[l].x : v2[l].x);             // Condition(qa < qb, v1, v2).x
+		out[41 + l] = (uint32_t)convChannel(qa[l]);
+		if(mode == ORC_MODE_SSE) {
+			out[45 + l] = bits(FastInv<ORC_MODE_SSE>(qa[l]));
+			out[49 + l] = bits(attenuation<ORC_MODE_SSE>(qa[l], qb[l]));
+			out[53 + l] = bits(safeInv<ORC_MODE_SSE>(qa[l]));
+		} else {
+			out[45 + l] = bits(FastInv<ORC_MODE_IEEE>(qa[l]));
+			out[49 + l] = bits(attenuation<ORC_MODE_IEEE>(qa[l], qb[l]));
+			out[53 + l] = bits(safeInv<ORC_MODE_IEEE>(qa[l]));
+		}
+	}
+}
+
 float orc_inv(float x, int mode) { return mode == ORC_MODE_SSE ? Inv<ORC_MODE_SSE>(x) : Inv<ORC_MODE_IEEE>(x); }
 float orc_rsqrt(float x, int mode) { return mode == ORC_MODE_SSE ? RSqrt<ORC_MODE_SSE>(x) : RSqrt<ORC_MODE_IEEE>(x); }
 float orc_min(float a, float b) { return Min(a, b); }

@@ -123,6 +123,12 @@ void orc_planar_decode_tile(const uint8_t *planes, int x, int y, int w, int h, u
 /* instrumentation for tests/range_hist.py: hist[192] (see snail_oracle.cpp); NULL switches it off. Single-threaded only. */
 void orc_debug_range_hist(uint64_t *hist);
 
+/* The shading path's small expressions (Abs, Reflect, SafeInv, FastInv, the light attenuation, ConvColor's channel, ForWhich / ForAny /
+ * ForAll of a compare, Condition on a Vec3q, Vec3q dot / cross, Sqrt) evaluated by the SAME inline helpers the oracle's hot path calls, on
+ * one row of eight floats; out = 57 words, laid out as oracle/veclib_probe.cpp `exprs` prints them.  tests/test_oracle_pins.py compares
+ * this with the reference's veclib evaluating the same expressions. */
+void orc_veclib_exprs(const float *in8, uint32_t *out57, int mode);
+
 /* arithmetic primitives exposed for the veclib pin test */
 float orc_inv(float x, int mode);
 float orc_rsqrt(float x, int mode);

@@ -1913,8 +1913,10 @@ __global__ __launch_bounds__(256) void k_account(AccountArgs A) {
 // ---------------------------------------------------------------------------------------------------
 // host side of the C-ABI
 // ---------------------------------------------------------------------------------------------------
+namespace { struct TileJob; void freeTileJobs(SnailScene *); } // render_host.inc: cached lists of snail_render_tiles / snail_render_image
 struct SnailScene {
 	int device = 0;
+	TileJob *tileJob = nullptr, *frameJob = nullptr;
 	int nNodes = 0, nTris = 0, depth = 0;
 	uint4 *dNodes = nullptr, *dTris = nullptr;
 	int fastOK = 0; // every triangle record finite and of sane magnitude (see file header)
@@ -2295,6 +2297,7 @@ int snail_scene_download(const SnailScene *s, void *nodes32, void *tris64) {
 void snail_scene_destroy(SnailScene *s) {
 	if(!s) return;
 	DeviceGuard guard(s->device);
+	freeTileJobs(s);
 	if(s->dNodes) (void)hipFree(s->dNodes);
 	if(s->dTris) (void)hipFree(s->dTris);
 	if(s->dStats) (void)hipFree(s->dStats);
@@ -2686,3 +2689,5 @@ int snail_account_primary(SnailScene *s, const float cam[13], int resx, int resy
 }
 
 } // extern "C"
+
+#include "render_host.inc"

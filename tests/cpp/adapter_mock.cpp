@@ -1,21 +1,42 @@
-// Compile-and-run check of include/snail_adapter.hpp against MOCK types that expose the same member names
-// as the reference's BVH / Context / ShadowContext / Camera / TreeStats (src/bvh/tree.h, src/ray_group.h,
-// src/camera.h, src/tree_stats.h).  This is a test of the adapter template, not a build of the reference.
-//   adapter_mock <nodes.bin> <tris.bin> <depth> <resx> <resy> <cam13.bin> <out.bin>
-// traces a frame through HipBVH::BeginFrame + per-packet TraversePrimary(Context<1,0>) copies, then one shadow
-// packet and one <0,1> packet through the immediate path, and dumps the results for the Python side to compare.
-#include <cstdio>
-#include <vector>
+// Compile-and-run check of include/snail_adapter.hpp against MOCK types that expose the same member names as the reference's
+// BVH / Scene / Context / ShadowContext / Camera / TreeStats / Options / MipmapTexture / Light (src/bvh/tree.h, src/scene.h,
+// src/ray_group.h, src/camera.h, src/tree_stats.h, src/render.h, src/mipmap_texture.h, src/light.h).  This is a test of the adapter
+// templates, not a build of the reference.
+//   adapter_mock <dir>
+// reads its inputs from <dir> (written by tests/test_gpu_parity.py::test_cpp_adapter_end_to_end) and writes, for the Python side to
+// compare with the oracle:
+//   out_primary.bin   a frame through HipBVH::BeginFrame + per-packet TraversePrimary(Context<1,0>) copies (prefetched path)
+//   out_sh_imm.bin    shadow packet 0 through HipBVH::TraverseShadow (immediate path: one synchronous call per packet)
+//   out_sh_batch.bin  all shadow packets through snail::ShadowBatch (one call)
+//   out_ry_imm.bin    secondary packet 0 through HipBVH::TraversePrimary(Context<0,1>) (immediate path)
+//   out_ry_batch.bin  all secondary packets through snail::RayBatch (one call)
+//   out_tiles.bin     Render(scene, camera, resx, resy, data, coords, offsets, options, rank, threads)   -- the reference's signature
+//   out_image.bin     Render(scene, camera, image, options, threads)                                      -- the reference's signature
+//   stats.txt         the TreeStats each of them returned / accumulated
 #include <cstdint>
-#include "../../include/snail_adapter.hpp"
+#include <cstdio>
+#include <string>
+#include <vector>
 
+// ---- mock reference types (names and members as in the reference) ----
+using std::vector;
+typedef unsigned int uint;
+int gVals[16] = {0};
 struct Vec3f { float x, y, z; };
 struct Camera { float plane_dist; Vec3f pos, right, up, front; };
 struct TreeStats {
-	unsigned in = 0, it = 0, sk = 0;
-	void Intersection(unsigned v) { in += v; }
-	void LoopIteration(unsigned v) { it += v; }
-	void Skip(unsigned v) { sk += v; }
+	unsigned in = 0, it = 0, sk = 0, rays = 0;
+	void Intersection(unsigned v = 1) { in += v; }
+	void LoopIteration(unsigned v = 1) { it += v; }
+	void Skip(unsigned v = 1) { sk += v; }
+	void TracingRays(unsigned v = 1) { rays += v; }
+};
+struct Options { bool reflections = false, rdtscShader = false; };
+struct Light { Vec3f pos, color; float radius, radSq, iRadius; };
+struct MipmapTexture {
+	int w = 0, h = 0, pitch = 0; std::vector<unsigned char> bytes;
+	int Width() const { return w; } int Height() const { return h; } int Pitch() const { return pitch; }
+	void *DataPointer() { return bytes.data(); }
 };
 struct Vec3q { float x[4], y[4], z[4]; };
 struct floatq { float v[4]; };
@@ -51,40 +72,123 @@ struct MockBVH {
 	int GetMaterialId(int, int) const { return 0; }
 	BBox GetBBox() const { return BBox{{nodes[0].b[0], nodes[0].b[1], nodes[0].b[2]}, {nodes[0].b[3], nodes[0].b[4], nodes[0].b[5]}}; }
 };
-
-template <class T> static std::vector<T> slurp(const char *path) {
-	FILE *f = std::fopen(path, "rb"); if(!f) { std::perror(path); std::exit(2); }
-	std::fseek(f, 0, SEEK_END); long n = std::ftell(f); std::fseek(f, 0, SEEK_SET);
-	std::vector<T> v(n / sizeof(T)); if(std::fread(v.data(), 1, n, f) != (size_t)n) std::exit(2); std::fclose(f); return v;
+template <class AccStruct> struct Scene {       // src/scene.h:26-58: the members the device pipeline reads
+	AccStruct geometry;
+	Vec3f ambientLight{0.1f, 0.1f, 0.1f};
+	vector<Light> lights;
+};
+// the reference's own generic Render templates (src/render.h:16-23): must LOSE overload resolution against the adapter's
+template <class AccStruct>
+TreeStats Render(const Scene<AccStruct> &, const Camera &, uint, uint, unsigned char *, const vector<int> &, const vector<int> &, const Options, uint, uint) {
+	std::puts("generic tile Render called"); std::exit(3);
+}
+template <class AccStruct> TreeStats Render(const Scene<AccStruct> &, const Camera &, MipmapTexture &, const Options, uint) {
+	std::puts("generic image Render called"); std::exit(3);
 }
 
+#define SNAIL_ADAPTER_RENDER_OVERLOADS
+#include "../../include/snail_adapter.hpp"
+
+template <class T> static std::vector<T> slurp(const std::string &path, bool optional = false) {
+	FILE *f = std::fopen(path.c_str(), "rb");
+	if(!f) { if(optional) return {}; std::perror(path.c_str()); std::exit(2); }
+	std::fseek(f, 0, SEEK_END); long n = std::ftell(f); std::fseek(f, 0, SEEK_SET);
+	std::vector<T> v(n / sizeof(T)); if(n && std::fread(v.data(), 1, n, f) != (size_t)n) std::exit(2); std::fclose(f); return v;
+}
+template <class T> static void dump(FILE *f, const std::vector<T> &v) { std::fwrite(v.data(), sizeof(T), v.size(), f); }
+
 int main(int argc, char **argv) {
-	if(argc < 8) { std::puts("compiled and linked"); return 0; }
+	if(argc < 2) { std::puts("compiled and linked"); return 0; }
+	const std::string d = std::string(argv[1]) + "/";
+	const std::vector<int> meta = slurp<int>(d + "meta.bin");   // depth, resx, resy, nShadow, nRays, reflections, depthShading
+	const int depth = meta[0], resx = meta[1], resy = meta[2], nSh = meta[3], nRy = meta[4];
+	Scene<snail::HipBVH<MockBVH>> scene;
 	MockBVH bvh;
-	bvh.nodes = slurp<Node>(argv[1]); bvh.tris = slurp<Triangle>(argv[2]); bvh.depth = std::atoi(argv[3]);
-	const int resx = std::atoi(argv[4]), resy = std::atoi(argv[5]);
-	std::vector<float> c = slurp<float>(argv[6]);
-	Camera cam{c[12], {c[0], c[1], c[2]}, {c[3], c[4], c[5]}, {c[6], c[7], c[8]}, {c[9], c[10], c[11]}};
-	snail::HipBVH<MockBVH> acc;
-	acc.Upload(bvh, 0);
-	acc.BeginFrame(cam, resx, resy);
-	std::vector<float> t((size_t)resx * resy);
-	std::vector<int> id((size_t)resx * resy);
-	Vec3q origin; for(int l = 0; l < 4; l++) { origin.x[l] = cam.pos.x; origin.y[l] = cam.pos.y; origin.z[l] = cam.pos.z; }
-	for(int y = 0; y < resy; y += 16) for(int x = 0; x < resx; x += 16) {
-		floatq dist[64]; i32x4 obj[64]; Vec2q bary[64]; TreeStats st;
-		Context<1, 0> ctx{{&origin, nullptr, nullptr, 64, nullptr}, dist, obj, nullptr, bary, &st};
-		acc.SetPacket(x, y);
-		acc.TraversePrimary(ctx);
-		for(int q = 0; q < 64; q++) for(int l = 0; l < 4; l++) {
-			int xx = x + (q & 3) * 4 + l, yy = y + (q >> 2);
-			if(xx < resx && yy < resy) { t[(size_t)yy * resx + xx] = dist[q].v[l]; id[(size_t)yy * resx + xx] = obj[q].v[l]; }
-		}
+	bvh.nodes = slurp<Node>(d + "nodes.bin"); bvh.tris = slurp<Triangle>(d + "tris.bin"); bvh.depth = depth;
+	const std::vector<float> c = slurp<float>(d + "cam.bin");
+	const Camera cam{c[12], {c[0], c[1], c[2]}, {c[3], c[4], c[5]}, {c[6], c[7], c[8]}, {c[9], c[10], c[11]}};
+	{
+		const std::vector<float> L = slurp<float>(d + "lights.bin", true);
+		for(size_t k = 0; k + 6 < L.size(); k += 7) scene.lights.push_back(Light{{L[k], L[k + 1], L[k + 2]}, {L[k + 3], L[k + 4], L[k + 5]}, L[k + 6], L[k + 6] * L[k + 6], 1.0f / L[k + 6]});
 	}
-	acc.EndFrame();
-	FILE *f = std::fopen(argv[7], "wb");
-	std::fwrite(t.data(), 4, t.size(), f); std::fwrite(id.data(), 4, id.size(), f);
-	std::fclose(f);
+	snail::HipBVH<MockBVH> &acc = scene.geometry;
+	acc.Upload(bvh, 0);
+	FILE *fs = std::fopen((d + "stats.txt").c_str(), "w");
+
+	{ // ---- prefetched primary path ----
+		acc.BeginFrame(cam, resx, resy);
+		std::vector<float> t((size_t)resx * resy);
+		std::vector<int> id((size_t)resx * resy);
+		Vec3q origin; for(int l = 0; l < 4; l++) { origin.x[l] = cam.pos.x; origin.y[l] = cam.pos.y; origin.z[l] = cam.pos.z; }
+		TreeStats total;
+		for(int y = 0; y < resy; y += 16) for(int x = 0; x < resx; x += 16) {
+			floatq dist[64]; i32x4 obj[64]; Vec2q bary[64]; TreeStats st;
+			Context<1, 0> ctx{{&origin, nullptr, nullptr, 64, nullptr}, dist, obj, nullptr, bary, &st};
+			acc.SetPacket(x, y);
+			acc.TraversePrimary(ctx);
+			total.in += st.in; total.it += st.it; total.sk += st.sk;
+			for(int q = 0; q < 64; q++) for(int l = 0; l < 4; l++) {
+				int xx = x + (q & 3) * 4 + l, yy = y + (q >> 2);
+				if(xx < resx && yy < resy) { t[(size_t)yy * resx + xx] = dist[q].v[l]; id[(size_t)yy * resx + xx] = obj[q].v[l]; }
+			}
+		}
+		acc.EndFrame();
+		FILE *f = std::fopen((d + "out_primary.bin").c_str(), "wb"); dump(f, t); dump(f, id); std::fclose(f);
+		std::fprintf(fs, "primary %u %u %u %u\n", total.in, total.it, 0u, total.sk);
+	}
+	if(nSh > 0) { // ---- shadow packets: immediate (packet 0) and batched (all) ----
+		const std::vector<float> o3 = slurp<float>(d + "sh_origin.bin");
+		const std::vector<Vec3q> dir = slurp<Vec3q>(d + "sh_dir.bin"), idir = slurp<Vec3q>(d + "sh_idir.bin");
+		std::vector<floatq> dist = slurp<floatq>(d + "sh_dist.bin");
+		std::vector<floatq> imm(dist.begin(), dist.begin() + 64);
+		std::vector<Vec3q> org((size_t)nSh);
+		for(int p = 0; p < nSh; p++) for(int l = 0; l < 4; l++) { org[p].x[l] = o3[p * 3]; org[p].y[l] = o3[p * 3 + 1]; org[p].z[l] = o3[p * 3 + 2]; }
+		TreeStats st0, st1;
+		ShadowContext c0{{&org[0], dir.data(), idir.data(), 64, nullptr}, imm.data(), &st0};
+		acc.TraverseShadow(c0);
+		FILE *f = std::fopen((d + "out_sh_imm.bin").c_str(), "wb"); dump(f, imm); std::fclose(f);
+		snail::ShadowBatch batch;
+		for(int p = 0; p < nSh; p++) { ShadowContext cp{{&org[p], dir.data() + p * 64, idir.data() + p * 64, 64, nullptr}, dist.data() + p * 64, nullptr}; batch.Add(cp); }
+		batch.Flush(acc, &st1);
+		f = std::fopen((d + "out_sh_batch.bin").c_str(), "wb"); dump(f, dist); std::fclose(f);
+		std::fprintf(fs, "shadow_imm %u %u %u %u\nshadow_batch %u %u %u %u\n", st0.in, st0.it, 0u, st0.sk, st1.in, st1.it, 0u, st1.sk);
+	}
+	if(nRy > 0) { // ---- secondary packets RayGroup<0,1>: immediate (packet 0) and batched (all) ----
+		const std::vector<Vec3q> org = slurp<Vec3q>(d + "ry_origin.bin"), dir = slurp<Vec3q>(d + "ry_dir.bin"), idir = slurp<Vec3q>(d + "ry_idir.bin");
+		std::vector<char> mask = slurp<char>(d + "ry_mask.bin");
+		std::vector<floatq> dist = slurp<floatq>(d + "ry_dist.bin");
+		std::vector<i32x4> obj((size_t)nRy * 64, i32x4{{0, 0, 0, 0}});
+		std::vector<Vec2q> bary((size_t)nRy * 64, Vec2q{{0, 0, 0, 0}, {0, 0, 0, 0}});
+		std::vector<floatq> d0(dist.begin(), dist.begin() + 64); std::vector<i32x4> o0(64, i32x4{{0, 0, 0, 0}}); std::vector<Vec2q> b0(64, Vec2q{{0, 0, 0, 0}, {0, 0, 0, 0}});
+		TreeStats st0, st1;
+		Context<0, 1> c0{{org.data(), dir.data(), idir.data(), 64, mask.data()}, d0.data(), o0.data(), nullptr, b0.data(), &st0};
+		acc.TraversePrimary(c0);
+		FILE *f = std::fopen((d + "out_ry_imm.bin").c_str(), "wb"); dump(f, d0); dump(f, o0); dump(f, b0); std::fclose(f);
+		snail::RayBatch batch(false, true);
+		for(int p = 0; p < nRy; p++) {
+			Context<0, 1> cp{{org.data() + p * 64, dir.data() + p * 64, idir.data() + p * 64, 64, mask.data() + p * 64}, dist.data() + p * 64, obj.data() + p * 64, nullptr,
+							 bary.data() + p * 64, nullptr};
+			batch.Add(cp);
+		}
+		batch.Flush(acc, &st1);
+		f = std::fopen((d + "out_ry_batch.bin").c_str(), "wb"); dump(f, dist); dump(f, obj); dump(f, bary); std::fclose(f);
+		std::fprintf(fs, "rays_imm %u %u %u %u\nrays_batch %u %u %u %u\n", st0.in, st0.it, 0u, st0.sk, st1.in, st1.it, 0u, st1.sk);
+	}
+	{ // ---- the tile API with the reference's signatures ----
+		gVals[7] = meta[5]; gVals[1] = meta[6];
+		const std::vector<int> coords = slurp<int>(d + "tiles.bin"), offsets = slurp<int>(d + "offsets.bin");
+		size_t total = 0;
+		for(size_t k = 0; k < offsets.size(); k++) total = std::max(total, (size_t)offsets[k] + (size_t)3 * coords[k * 4 + 2] * coords[k * 4 + 3]);
+		std::vector<unsigned char> data(total, 0xAB);
+		const TreeStats st = Render(scene, cam, (uint)resx, (uint)resy, data.data(), coords, offsets, Options(), 0u, 4u);
+		FILE *f = std::fopen((d + "out_tiles.bin").c_str(), "wb"); dump(f, data); std::fclose(f);
+		std::fprintf(fs, "tiles %u %u %u %u\n", st.in, st.it, st.rays, st.sk);
+		MipmapTexture img; img.w = resx; img.h = resy; img.pitch = (resx * 3 + 63) / 64 * 64; img.bytes.assign((size_t)img.pitch * resy, 0xCD);
+		const TreeStats si = Render(scene, cam, img, Options(), 4u);
+		f = std::fopen((d + "out_image.bin").c_str(), "wb"); dump(f, img.bytes); std::fclose(f);
+		std::fprintf(fs, "image %u %u %u %u %d\n", si.in, si.it, si.rays, si.sk, img.pitch);
+	}
+	std::fclose(fs);
 	std::printf("adapter ok: %d x %d, normal of tri 0 = %g %g %g\n", resx, resy, acc.GetNormal(0, 0).x, acc.GetNormal(0, 0).y, acc.GetNormal(0, 0).z);
 	return 0;
 }

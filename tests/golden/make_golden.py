@@ -26,6 +26,46 @@ from tests import oracle_lib as O   # noqa: E402
 from tests import util              # noqa: E402
 
 
+def expr_rows():
+    """seeded rows of eight bit patterns for `veclib_probe exprs`: specials (zeros, infinities, NaNs, denormals, the SafeInv
+    singularity -1e-8) in every lane position, unit-ish direction vectors, and values of wildly different magnitude"""
+    rng = np.random.RandomState(4321)
+    special = [0x00000000, 0x80000000, 0x7f800000, 0xff800000, 0x7fc00000, 0xffc00000, 0x3f800000, 0xbf800000,
+               0x00000001, 0x80000001, 0x007fffff, 0x7f7fffff, 0x322bcc77, 0xb22bcc77, 0x437f0000, 0x3b808081]
+    rows = []
+    for i in range(len(special)):
+        for j in range(0, len(special), 3):
+            rows.append([special[(i + k) % len(special)] for k in range(4)] + [special[(j + 2 * k) % len(special)] for k in range(4)])
+    f = (rng.randn(300, 8) * np.exp(rng.uniform(-12, 12, size=(300, 8)))).astype(np.float32)
+    rows += f.view(np.uint32).tolist()
+    d = rng.randn(300, 8).astype(np.float32)          # direction-like and colour-like values
+    d[:, 4:] = np.abs(d[:, 4:]) * np.float32(0.6)
+    rows += d.view(np.uint32).tolist()
+    return rows
+
+
+def run_exprs(probe, rows):
+    text = "\n".join(" ".join("%08x" % v for v in r) for r in rows) + "\n"
+    out = subprocess.run([probe, "exprs"], input=text, capture_output=True, text=True, check=True).stdout.split("\n")
+    res = [[int(x, 16) for x in line.split()] for line in out if line.strip()]
+    assert len(res) == len(rows) and all(len(r) == 57 for r in res)
+    return res
+
+
+def veclib_exprs():
+    probe = os.path.join(ROOT, "oracle", "_ref", "veclib_probe")
+    if not os.path.exists(probe):
+        print("veclib_probe not built (reference checkout absent?) -- keeping existing veclib_exprs.json")
+        return
+    rows = expr_rows()
+    res = run_exprs(probe, rows)
+    json.dump({"layout": "words 0..44 of `veclib_probe exprs` (oracle/veclib_probe.cpp): ForWhich|ForAny<<4|ForAll<<5, Sqrt x4, Abs x4, dot x4, cross xyz x4, "
+                         "Reflect xyz x4, Condition(Vec3q).x x4, Trunc(Clamp(*255)) x4; words 45..56 (FastInv, attenuation, SafeInv) are rcpps-based, "
+                         "CPU specific, and compared live against the probe instead",
+               "inputs": rows, "outputs": [r[:45] for r in res]}, open(os.path.join(HERE, "veclib_exprs.json"), "w"))
+    print("veclib_exprs.json: %d rows" % len(rows))
+
+
 def sha(*arrays):
     h = hashlib.sha256()
     for a in arrays:
@@ -142,6 +182,7 @@ def oracle_whitted():
 
 if __name__ == "__main__":
     veclib_prims()
+    veclib_exprs()
     survey_digests()
     oracle_frames()
     oracle_packets()

@@ -49,6 +49,7 @@ def lib():
         L.orc_planar_encode_tile.argtypes = [vp, i32, i32, i32, i32, i32, vp]
         L.orc_planar_decode_tile.argtypes = [vp, i32, i32, i32, i32, vp, i32]
         L.orc_render_whitted.argtypes = [vp, vp, vp, i32, i32, vp, i32, vp, vp, i32, vp, i32, u64p, i32, i32]
+        L.orc_veclib_exprs.argtypes = [vp, vp, i32]
         for f in (L.orc_inv, L.orc_rsqrt):
             f.argtypes = [C.c_float, i32]
             f.restype = C.c_float

@@ -343,26 +343,93 @@ def test_gpu_against_committed_fixtures(torch_mod):
     sc.close()
 
 
-def test_cpp_adapter_end_to_end(torch_mod, tmp_path):
-    """A C++ host in the reference's shape (AccStruct-conforming class from include/snail_adapter.hpp, packets
-    announced in RenderTask::Work order, Context arrays filled per packet) gets the oracle's frame."""
+@pytest.mark.parametrize("refl,depth_mode", [(False, False), (True, False), (False, True)])
+def test_cpp_adapter_end_to_end(torch_mod, tmp_path, refl, depth_mode):
+    """A C++ host in the reference's shape (tests/cpp/adapter_mock.cpp over include/snail_adapter.hpp, mock types with the reference's
+    member names) gets the oracle's bytes from every path of the adapter: the prefetched primary path (HipBVH::BeginFrame + per-packet
+    TraversePrimary(Context<1,0>) copies, frame TreeStats delivered), the immediate path (TraverseShadow, TraversePrimary(Context<0,1>)),
+    the batched path (ShadowBatch, RayBatch), and the two Render(...) overloads with the reference's signatures (src/render.h:16-23):
+    tile list -> planar R, G-R, B-R bytes at data + offsets[k] and image -> rgb8, with the TreeStats they return."""
     import subprocess
+    from snail_amd import render as R
     from tests.test_host_side import build_adapter_mock
     name = "atrium:0.05"
     tv, hb, osc = util.scene_pair(name)
     cam = util.camera_for(name, tv)
-    resx, resy = 328, 200
-    hb.nodes.tofile(str(tmp_path / "nodes.bin")); hb.tris.tofile(str(tmp_path / "tris.bin"))
-    cam.as_array13().astype(np.float32).tofile(str(tmp_path / "cam.bin"))
+    resx, resy = 320, 192                       # the reference's server demands resx % 16 == 0, resy % 64 == 0 (src/server.cpp:227-231)
+    d = tmp_path
+    hb.nodes.tofile(str(d / "nodes.bin")); hb.tris.tofile(str(d / "tris.bin"))
+    cam13 = np.ascontiguousarray(cam.as_array13(), dtype=np.float32); cam13.tofile(str(d / "cam.bin"))
+    bmin, bmax = osc.nodes[0]["bmin"], osc.nodes[0]["bmax"]
+    c, e = (bmin + bmax) * 0.5, (bmax - bmin)
+    lights = np.array([[c[0], c[1] + 0.35 * e[1], c[2], 1.0, 0.9, 0.8, 2.0 * float(e.max())],
+                       [c[0] - 0.3 * e[0], c[1] + 0.1 * e[1], c[2] + 0.2 * e[2], 0.3, 0.5, 1.0, 0.6 * float(e.max())]], dtype=np.float32)
+    lights.tofile(str(d / "lights.bin"))
+    n_sh, n_ry = 5, 4
+    so, sd, si, sdist = util.shadow_packets(osc, n_sh, 71)
+    for nm, a in (("sh_origin", so), ("sh_dir", sd), ("sh_idir", si), ("sh_dist", sdist)):
+        a.tofile(str(d / (nm + ".bin")))
+    ro, rd, ri, rmask, rdist, robj, rbary = util.secondary_packets(osc, cam, resx, resy, n_ry, 72, shared=False, masked=True)
+    for nm, a in (("ry_origin", ro), ("ry_dir", rd), ("ry_idir", ri), ("ry_mask", rmask), ("ry_dist", rdist)):
+        a.tofile(str(d / (nm + ".bin")))
+    plan = R.ShardPlan.make(resx, resy, 2)
+    tiles = plan.tiles[plan.owner == 1]                      # one rank's tiles, as a render node receives them
+    offsets = (np.arange(len(tiles), dtype=np.int32)[::-1].copy()) * (3 * 16 * 64)      # any layout of the per-tile buffers: here reversed
+    tiles.astype(np.int32).tofile(str(d / "tiles.bin")); offsets.tofile(str(d / "offsets.bin"))
+    np.array([hb.depth, resx, resy, n_sh, n_ry, int(refl), int(depth_mode)], dtype=np.int32).tofile(str(d / "meta.bin"))
     exe = build_adapter_mock(tmp_path)
-    r = subprocess.run([exe, str(tmp_path / "nodes.bin"), str(tmp_path / "tris.bin"), str(hb.depth), str(resx), str(resy), str(tmp_path / "cam.bin"),
-                        str(tmp_path / "out.bin")], capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout + r.stderr
-    raw = np.fromfile(str(tmp_path / "out.bin"), dtype=np.uint8)
+    r = subprocess.run([exe, str(d)], capture_output=True, text=True)
+    assert r.returncode == 0 and "adapter ok" in r.stdout, r.stdout + r.stderr
+    stats = {l.split()[0]: [int(x) for x in l.split()[1:]] for l in open(str(d / "stats.txt")).read().splitlines()}
+    # prefetched primary frame
+    raw = np.fromfile(str(d / "out_primary.bin"), dtype=np.uint8)
     t = raw[:resx * resy * 4].view(np.float32).reshape(resy, resx)
     tid = raw[resx * resy * 4:].view(np.int32).reshape(resy, resx)
     ref = osc.render_primary(cam.as_array13(), resx, resy, mode=O.MODE_IEEE)
     util.assert_bit_equal(t, ref[0], "adapter t"); util.assert_bit_equal(tid, ref[3], "adapter triId")
+    assert stats["primary"][:2] == [int(ref[4][0]), int(ref[4][1])]
+    # shadow packets: immediate (packet 0) and batched (all)
+    want = sdist.copy()
+    wst = osc.trace_shadow(so, sd, si, want, n_sh, 64)
+    util.assert_bit_equal(np.fromfile(str(d / "out_sh_batch.bin"), dtype=np.float32).reshape(-1, 4), want, "shadow batch")
+    util.assert_bit_equal(np.fromfile(str(d / "out_sh_imm.bin"), dtype=np.float32).reshape(-1, 4), want[:64], "shadow immediate")
+    assert stats["shadow_batch"] == [int(wst[0]), int(wst[1]), 0, int(wst[3])]
+    w0 = sdist[:64].copy(); st0 = osc.trace_shadow(so[:1], sd[:64], si[:64], w0, 1, 64)
+    assert stats["shadow_imm"] == [int(st0[0]), int(st0[1]), 0, int(st0[3])]
+    # secondary packets RayGroup<0,1>
+    wd, wo, wb = rdist.copy(), robj.copy(), rbary.copy()
+    wst = osc.trace_rays(ro, rd, ri, rmask, wd, wo, wb, n_ry, 64, False)
+    raw = np.fromfile(str(d / "out_ry_batch.bin"), dtype=np.uint8)
+    nq = n_ry * 64
+    util.assert_bit_equal(raw[:nq * 16].view(np.float32).reshape(-1, 4), wd, "rays batch dist")
+    util.assert_bit_equal(raw[nq * 16:nq * 32].view(np.int32).reshape(-1, 4), wo, "rays batch obj")
+    util.assert_bit_equal(raw[nq * 32:].view(np.float32).reshape(-1, 8), wb, "rays batch bary")
+    assert stats["rays_batch"][:2] == [int(wst[0]), int(wst[1])]
+    raw = np.fromfile(str(d / "out_ry_imm.bin"), dtype=np.uint8)
+    util.assert_bit_equal(raw[:64 * 16].view(np.float32).reshape(-1, 4), wd[:64], "rays immediate dist")
+    util.assert_bit_equal(raw[64 * 16:64 * 32].view(np.int32).reshape(-1, 4), wo[:64], "rays immediate obj")
+    # the tile API: planar bytes per tile and the rgb8 image, against the oracle's frame
+    if depth_mode:
+        want_frame = O.shade_depth(ref[0]).reshape(resy, resx, 3)
+        wst = ref[4]
+    else:
+        want_frame, wst = osc.render_whitted(cam.as_array13(), resx, resy, lights, mode=O.MODE_IEEE, reflections=refl)
+    data = np.fromfile(str(d / "out_tiles.bin"), dtype=np.uint8)
+    for k, wp in enumerate(O.planar_encode(want_frame, tiles)):
+        assert np.array_equal(data[offsets[k]:offsets[k] + len(wp)], wp), ("tile", k)
+    pitch = stats["image"][4]
+    img = np.fromfile(str(d / "out_image.bin"), dtype=np.uint8).reshape(resy, pitch)
+    assert np.array_equal(img[:, :resx * 3].reshape(resy, resx, 3), want_frame)
+    assert (img[:, resx * 3:] == 0xCD).all()                 # row padding untouched
+    assert stats["image"][:4] == [int(wst[0]), int(wst[1]), int(wst[2]), int(wst[3])], (stats["image"], wst)
+    # the tile call traced this rank's tiles only: its counters are the oracle's over exactly those tiles
+    if depth_mode:
+        mine = np.zeros(4, dtype=np.uint64)
+        for x, y, w, h in tiles.tolist():
+            mine += osc.render_primary(cam.as_array13(), resx, resy, rect=(x, y, w, h), mode=O.MODE_IEEE, threads=1)[4]
+        assert stats["tiles"] == [int(mine[0]), int(mine[1]), int(mine[2]), int(mine[3])]
+    else:
+        assert 0 < stats["tiles"][1] < int(wst[1]) and stats["tiles"][2] >= len(R.tile_packets(tiles)) * 256
 
 
 def test_depth_shading_and_tile_pipeline(torch_mod):

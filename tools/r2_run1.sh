@@ -14,6 +14,10 @@ import json,glob
 for f in sorted(glob.glob('gpurun_out/r2a/base_*.json')):
     d=json.load(open(f)); r=d['roofline']; print(f, d['value'], d['ms_per_step'], 'lone', r['lone_frame_ms'], 'frac', r['frac'], 'hbm', r['hbm_frac_traffic'], r.get('hbm_frac_packet_alg'))
 PY
+echo "== timeline"
+timeout -k 10 200 python tools/timeline.py 20 5 4 > $O/timeline.txt 2>&1 || exit 1
+tail -24 $O/timeline.txt
+for v in prio priorank; do SNAIL_LIB_PATH=$PWD/snail_amd/exp/lib_$v.so timeout -k 10 200 python tools/timeline.py 20 5 4 2>&1 | grep "^rep" ; done
 echo "== variants"
 for v in bw2 bw4 prio priorank; do
   export SNAIL_LIB_PATH=$PWD/snail_amd/exp/lib_$v.so
