@@ -739,6 +739,101 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 	asm volatile("" ::"s"(sp), "s"(first), "s"(last), "s"(cnt), "v"(stkN), "v"(stkF), "s"(leafSub), "s"(leafAux), "s"(sCur), "s"(sFl), "s"(sOff),    \
 				 "s"(sWidth), "s"(sRng), "s"(sAlive), "v"(vt[0]), "v"(vt[1]), "v"(vt[2]), "v"(vt[3]), "v"(vt[4]), "v"(vt[5]), "v"(vt[6]), "v"(vt[7]), \
 				 "v"(vt[8]), "v"(vt[9]), "v"(vt[10]), "v"(vt[11]), "v"(vt[12]), "v"(vt[13]), "v"(vt[14]), "v"(vt[15]), "v"(vt[16]))
+// ---- the same loop with the node records fetched AHEAD of their use (one-word stack entries only) -------------------------------
+// A packet's walk is a chain of dependent record fetches: visit -> (slab test) -> fetch the child -> visit ..., and a pop fetches the
+// popped node.  Beside four other waves per SIMD that latency is hidden; in a frame's tail -- its heaviest packets, alone on the
+// machine -- it is the frame time: the heaviest packet of the atrium frame traced ALONE takes 0.18 ms = ~1000 cycles per visit of which
+// ~390 issue (tools/heavy_alone.py).  Here three records are resident or in flight:
+//   C = s[84:91]  the node being tested
+//   N = s[76:83]  its near child, requested as soon as C has arrived (for a leaf: the root, a harmless touch), i.e. BEFORE the slab test
+//   T = s[68:75]  the record of the stack's top entry: requested when that entry becomes the top (at a push: the far child, the same
+//                 64-B line as the near one; at a pop: the entry below), so that a pop finds its node already here
+// A register set never has two requests in flight (scalar loads return out of order): every request into N or T follows an
+// s_waitcnt lgkmcnt(0) that covers the previous one, and the statement is left with nothing in flight.  T does not survive the C++
+// leaf code between two statements: L_entry requests it again (its line was fetched a leaf body ago).
+//   topw = the stack word (node | first << 20 | last << 26) of the top entry, kept in an SGPR: one lane read per pop as before
+#define SNAIL_MOV_REC(D0, D1, D2, D3, S0, S1, S2, S3)                                                                                       \
+	" s_mov_b64 " D0 ", " S0 "\n s_mov_b64 " D1 ", " S1 "\n s_mov_b64 " D2 ", " S2 "\n s_mov_b64 " D3 ", " S3 "\n"
+#define SNAIL_C_FROM_T SNAIL_MOV_REC("s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]", "s[68:69]", "s[70:71]", "s[72:73]", "s[74:75]")
+#define SNAIL_C_FROM_N SNAIL_MOV_REC("s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]", "s[76:77]", "s[78:79]", "s[80:81]", "s[82:83]")
+#define SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, NX, FX, NY, FY, NZ, FZ)                                                   \
+	asm volatile("L_entry_%=:\n"                                                                                                           \
+				 " s_cmp_eq_u32 %[sp], 0\n s_cbranch_scc1 L_done_%=\n"                                                                     \
+				 " s_sub_u32 %[off], %[sp], 1\n"                                                                                           \
+				 " v_readlane_b32 %[topw], %[stkN], %[off]\n"                                                                              \
+				 " s_and_b32 %[cur], %[topw], 0xfffff\n s_lshl_b32 %[off], %[cur], 5\n"                                                    \
+				 " s_load_dwordx8 s[68:75], %[base], %[off]\n"                                                                             \
+				 "L_pop_%=:\n" /* sp > 0, topw = the top entry, T = its record (requested) */                                              \
+				 " s_sub_u32 %[sp], %[sp], 1\n" CNTPOP                                                                                     \
+				 " s_bfe_u32 %[first], %[topw], 0x60014\n s_lshr_b32 %[last], %[topw], 26\n"                                               \
+				 " s_sub_u32 %[width], %[last], %[first]\n"                                                                                \
+				 " s_bfm_b64 exec, %[width], %[first]\n s_bitset1_b64 exec, %[last]\n"                                                     \
+				 " s_cmp_eq_u32 %[sp], 0\n s_cbranch_scc1 L_last_%=\n"                                                                     \
+				 " s_sub_u32 %[off], %[sp], 1\n"                                                                                           \
+				 " v_readlane_b32 %[topw], %[stkN], %[off]\n"                                                                              \
+				 " s_and_b32 %[cur], %[topw], 0xfffff\n s_lshl_b32 %[off], %[cur], 5\n"                                                    \
+				 " s_waitcnt lgkmcnt(0)\n" SNAIL_C_FROM_T                                                                                  \
+				 " s_load_dwordx8 s[68:75], %[base], %[off]\n" /* the new top entry's record */                                            \
+				 " s_branch L_visit_%=\n"                                                                                                  \
+				 "L_last_%=:\n"                                                                                                            \
+				 " s_waitcnt lgkmcnt(0)\n" SNAIL_C_FROM_T                                                                                  \
+				 "L_visit_%=:\n" CNTVISIT                                                                                                  \
+				 " s_lshr_b32 %[cur], %[sign16], s91\n s_xor_b32 %[cur], %[cur], s91\n s_bfe_u32 %[cur], %[cur], 0x10010\n"                \
+				 " s_add_u32 %[fl], s90, 1\n s_sub_u32 %[fl], %[fl], %[cur]\n" /* far child */                                             \
+				 " s_add_u32 %[cur], s90, %[cur]\n" /* near child */                                                                       \
+				 " s_cmp_lt_i32 s90, 0\n s_cselect_b32 %[cur], 0, %[cur]\n s_lshl_b32 %[off], %[cur], 5\n"                                 \
+				 " s_load_dwordx8 s[76:83], %[base], %[off]\n"                                                                             \
+				 PRE(NX, FX, NY, FY, NZ, FZ)                                                                                               \
+				 SLAB("0", NX, FX, NY, FY, NZ, FZ) TAIL("0", "s0") SLAB("1", NX, FX, NY, FY, NZ, FZ) TAIL("1", "s1")                       \
+				 SLAB("2", NX, FX, NY, FY, NZ, FZ) TAIL("2", "s2") SLAB("3", NX, FX, NY, FY, NZ, FZ) TAIL("3", "s3")                       \
+				 " v_max_f32 %[s2], %[s2], %[s3]\n v_max3_f32 %[s0], %[s0], %[s1], %[s2]\n"                                                \
+				 " v_cmp_le_f32 vcc, 0, %[s0]\n"                                                                                           \
+				 " s_and_b64 %[alive], vcc, exec\n s_cbranch_scc0 L_fail_%=\n"                                                             \
+				 " s_ff1_i32_b64 %[first], %[alive]\n s_flbit_i32_b64 %[last], %[alive]\n s_xor_b32 %[last], %[last], 63\n"                \
+				 " s_sub_u32 %[width], %[last], %[first]\n"                                                                                \
+				 " s_bfm_b64 exec, %[width], %[first]\n s_bitset1_b64 exec, %[last]\n"                                                     \
+				 " s_cmp_lt_i32 s90, 0\n s_cbranch_scc1 L_leaf_%=\n"                                                                       \
+				 " s_lshl_b32 %[off], %[last], 6\n s_or_b32 %[off], %[off], %[first]\n s_lshl_b32 %[off], %[off], 20\n"                    \
+				 " s_or_b32 %[topw], %[off], %[fl]\n"                                                                                      \
+				 " s_mov_b32 m0, %[sp]\n v_writelane_b32 %[stkN], %[topw], m0\n"                                                           \
+				 " s_add_u32 %[sp], %[sp], 1\n"                                                                                            \
+				 " s_lshl_b32 %[off], %[fl], 5\n"                                                                                          \
+				 " s_waitcnt lgkmcnt(0)\n" SNAIL_C_FROM_N                                                                                  \
+				 " s_load_dwordx8 s[68:75], %[base], %[off]\n" /* the far child is the new top entry */                                    \
+				 " s_branch L_visit_%=\n"                                                                                                  \
+				 "L_fail_%=:\n"                                                                                                            \
+				 " s_cmp_eq_u32 %[sp], 0\n s_cbranch_scc0 L_pop_%=\n"                                                                      \
+				 " s_branch L_done_%=\n"                                                                                                   \
+				 "L_leaf_%=:\n s_mov_b32 %[leafSub], s90\n s_mov_b32 %[leafAux], s91\n s_waitcnt lgkmcnt(0)\n s_branch L_end_%=\n"        \
+				 "L_done_%=:\n s_mov_b32 %[leafSub], 0\n s_mov_b32 %[leafAux], 0\n s_waitcnt lgkmcnt(0)\n"                                \
+				 "L_end_%=:\n s_mov_b64 exec, -1\n"                                                                                        \
+				 : [sp] "+s"(sp), [first] "+s"(first), [last] "+s"(last), [cnt] "+s"(cnt), [stkN] "+v"(stkN), [stkF] "+v"(stkF),           \
+				   [leafSub] "=&s"(leafSub), [leafAux] "=&s"(leafAux), [cur] "=&s"(sCur), [fl] "=&s"(sFl), [off] "=&s"(sOff),              \
+				   [width] "=&s"(sWidth), [topw] "=&s"(sTopw), [alive] "=&s"(sAlive), [pnx] "=&v"(vt[0]), [pny] "=&v"(vt[1]),              \
+				   [pnz] "=&v"(vt[2]), [pfx] "=&v"(vt[3]), [pfy] "=&v"(vt[4]), [pfz] "=&v"(vt[5]), [t0] "=&v"(vt[6]), [t1] "=&v"(vt[7]),   \
+				   [t2] "=&v"(vt[8]), [t3] "=&v"(vt[9]), [t4] "=&v"(vt[10]), [t5] "=&v"(vt[11]), [s0] "=&v"(vt[12]), [s1] "=&v"(vt[13]),   \
+				   [s2] "=&v"(vt[14]), [s3] "=&v"(vt[15]), [u0] "=&v"(vt[16])                                                              \
+				 : [base] "s"(nodeBase), [sign16] "s"(sign16), [lane] "v"(lane), ORGOPS(), [ix0] "v"(Q.id[0][0]), [ix1] "v"(Q.id[0][1]), [ix2] "v"(Q.id[0][2]), [ix3] "v"(Q.id[0][3]),        \
+				   [iy0] "v"(Q.id[1][0]), [iy1] "v"(Q.id[1][1]), [iy2] "v"(Q.id[1][2]), [iy3] "v"(Q.id[1][3]), [iz0] "v"(Q.id[2][0]),      \
+				   [iz1] "v"(Q.id[2][1]), [iz2] "v"(Q.id[2][2]), [iz3] "v"(Q.id[2][3]), [d0] "v"(Q.dist[0]), [d1] "v"(Q.dist[1]),          \
+				   [d2] "v"(Q.dist[2]), [d3] "v"(Q.dist[3])                                                                                \
+				 : "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", \
+				   "s88", "s89", "s90", "s91", "vcc", "scc", "m0");                                                                        \
+	asm volatile("" ::"s"(sp), "s"(first), "s"(last), "s"(cnt), "v"(stkN), "v"(stkF), "s"(leafSub), "s"(leafAux), "s"(sCur), "s"(sFl), "s"(sOff),    \
+				 "s"(sWidth), "s"(sTopw), "s"(sAlive), "v"(vt[0]), "v"(vt[1]), "v"(vt[2]), "v"(vt[3]), "v"(vt[4]), "v"(vt[5]), "v"(vt[6]), "v"(vt[7]), \
+				 "v"(vt[8]), "v"(vt[9]), "v"(vt[10]), "v"(vt[11]), "v"(vt[12]), "v"(vt[13]), "v"(vt[14]), "v"(vt[15]), "v"(vt[16]))
+#define SNAIL_DESCEND_PF_OCT(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, OCT)                                                                \
+	switch(OCT) {                                                                                                                          \
+	case 0: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s85", "s88", "s86", "s89"); break;                  \
+	case 1: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s85", "s88", "s86", "s89"); break;                  \
+	case 2: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s88", "s85", "s86", "s89"); break;                  \
+	case 3: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s88", "s85", "s86", "s89"); break;                  \
+	case 4: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s85", "s88", "s89", "s86"); break;                  \
+	case 5: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s85", "s88", "s89", "s86"); break;                  \
+	case 6: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s88", "s85", "s89", "s86"); break;                  \
+	default: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s88", "s85", "s89", "s86"); break;                 \
+	}
+
 // near/far plane registers by sign octant (bit k set = idir negative on axis k: near plane = bmax[k]); s[84:86] = bmin, s[87:89] = bmax
 #define SNAIL_DESCEND_OCT(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, OCT) SNAIL_DESCEND_OCT_S(SNAIL_POP_2W, SNAIL_PUSH_2W, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, OCT)
 #define SNAIL_DESCEND_OCT_S(POP, PUSH, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, OCT)                                                                               \
@@ -812,7 +907,21 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes, c
 			else if(POSDIST) { SNAIL_DESCEND_ASM_S(POP, PUSH, SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_POS, SNAIL_COUNT, "", "s84", "s87", "s85", "s88", "s86", "s89"); } \
 			else { SNAIL_DESCEND_ASM_S(POP, PUSH, SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, "", "s84", "s87", "s85", "s88", "s86", "s89"); } \
 		}
-		if(PACK) { SNAIL_SHARED_VARIANTS(SNAIL_POP_1W, SNAIL_PUSH_1W) }
+#ifndef SNAIL_NODE_PREFETCH
+#define SNAIL_NODE_PREFETCH 1 // 0 = the loop without record prefetch for one-word stacks too (A/B measurements)
+#endif
+		if(PACK && SNAIL_NODE_PREFETCH) {
+			int sTopw;
+			if(COH) {
+				if(SHADOW) { SNAIL_DESCEND_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_ANY, "", SNAIL_COUNT, oct) }
+				else if(POSDIST) { SNAIL_DESCEND_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_POS, SNAIL_COUNT, "", oct) }
+				else { SNAIL_DESCEND_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_ANY, SNAIL_COUNT, "", oct) }
+			} else {
+				if(SHADOW) { SNAIL_DESCEND_PF(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, "", SNAIL_COUNT, "s84", "s87", "s85", "s88", "s86", "s89"); }
+				else if(POSDIST) { SNAIL_DESCEND_PF(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_POS, SNAIL_COUNT, "", "s84", "s87", "s85", "s88", "s86", "s89"); }
+				else { SNAIL_DESCEND_PF(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, "", "s84", "s87", "s85", "s88", "s86", "s89"); }
+			}
+		} else if(PACK) { SNAIL_SHARED_VARIANTS(SNAIL_POP_1W, SNAIL_PUSH_1W) }
 		else { SNAIL_SHARED_VARIANTS(SNAIL_POP_2W, SNAIL_PUSH_2W) }
 #undef SNAIL_SHARED_VARIANTS
 		if(leafSub == 0) break;
