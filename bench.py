@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="frames in flight (HIP streams); 0 = the renderer's default (4); 1 = strictly serial frames")
     ap.add_argument("--event-every", type=int, default=8, help="bracket every n-th traversal launch with HIP events (roofline.kernel_ms)")
     ap.add_argument("--feedback-order", type=int, default=1, help="1 (default) = dispatch packets heaviest first by the node visits of an earlier frame (DistributedRenderer feedback_order)")
+    ap.add_argument("--stagger", type=int, default=1, help="1 (default) = de-phase the frame streams when the pipeline starts from idle (DistributedRenderer stagger)")
     ap.add_argument("--lone-frames", type=int, default=12, help="N=1: frames traced one at a time after the timed region (lone_frame_ms); 0 = skip")
     args = ap.parse_args()
 
@@ -178,7 +179,7 @@ def main():
         c, e = (bmin + bmax) * 0.5, (bmax - bmin)
         lights7 = np.array([[c[0], c[1] + 0.35 * e[1], c[2], 1.0, 0.9, 0.8, 2.0 * float(e.max())]], dtype=np.float32)   # one point light above the nave
     rnd = DistributedRenderer(scene, resx, resy, rank, world, slots=args.streams if args.streams > 0 else None, stage_cpu=rehearsal,
-                              feedback_order=bool(args.feedback_order), lights7=lights7, rank0_share=args.rank0_share)
+                              feedback_order=bool(args.feedback_order), lights7=lights7, rank0_share=args.rank0_share, stagger=bool(args.stagger))
     primary_rays = rnd.rays_per_frame() if world > 1 else resx * ((resy + 15) // 16 * 16)
 
     def barrier():

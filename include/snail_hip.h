@@ -221,6 +221,14 @@ int snail_render_tiles(SnailScene *, const float cam[13], int resx, int resy, co
 int snail_render_image(SnailScene *, const float cam[13], int resx, int resy, const float *lights7, int nLights, const float ambient[3],
                        const float color[3], int flags, uint8_t *image_bgr, int pitch, uint64_t stats[4]);
 
+/* ---- pipelining support ------------------------------------------------------------------------------------------------------ */
+/* A stream-ordered pause (one sleeping wave; 0..10000 us) on the current device.  Frames pipelined over several HIP streams run best
+ * when the streams are OUT of phase -- a frame's tail (its heaviest packets) then overlaps the other frames' bulk.  Streams that all
+ * start from idle at the same moment stay in phase for many frames (their grids are dispatched one after the other, so the later
+ * frames' heavy packets start late: 0.43 ms per round of four frames instead of 0.356, tools/timeline.py); a host staggers the first
+ * launch of stream k by k x (frame time / streams), as snail_amd.render.DistributedRenderer does. */
+int snail_delay_dev(float microseconds, void *stream);
+
 /* ---- measurement support ------------------------------------------------------------------------- */
 /* Single-ray, cache-less accounting walk of SURVEY.md section 8(d) over the same padded packet set as
  * snail_trace_primary: d_out[0] += rays, [1] += sum V_n (node boxes tested), [2] += sum V_t
@@ -239,6 +247,10 @@ int snail_debug_dispatch_rate(int blocks, int threads, int reps, float *ms_per_l
  * For load-balance studies (tools/packet_costs.py) and for bench.py's packet-level algorithmic bytes
  * (32 B x node visits + 64 B x triangle records fetched + 16 B x 256 per packet); not on any product path. */
 int snail_debug_packet_costs(SnailScene *, const float cam[13], int resx, int resy, uint32_t *out8);
+
+/* Experiment (tools/anyorder.py): `frames` full-frame primary launches back to back on one fresh stream with launch flags `flags`
+ * (0, or hipExtAnyOrderLaunch = 1); *ms_total = HIP-event time around all of them.  No outputs are stored. */
+int snail_debug_anyorder(SnailScene *, const float cam[13], int resx, int resy, int frames, int flags, float *ms_total);
 
 /* Diagnostic: out = {blocks of dev::k_primary the occupancy API admits per CU, the device's block limit per CU, CUs, waves per block
  * of this build}.  tools/occupancy.py. */

@@ -30,6 +30,7 @@ SIGNATURES = {
     "snail_scene_info": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "snail_scene_create_lbvh": (_VP, [_VP, _I, _I, _I, _VP, _VP]),
     "snail_scene_download": (_I, [_VP, _VP, _VP]),
+    "snail_delay_dev": (_I, [C.c_float, _VP]),
     "snail_debug_dispatch_rate": (_I, [_I, _I, _I, _VP]),
     "snail_trace_primary": (_I, [_VP, _F13, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "snail_trace_primary_dev": (_I, [_VP, _F13, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
@@ -55,6 +56,7 @@ SIGNATURES = {
     "snail_account_primary": (_I, [_VP, _F13, _I, _I, _I, _I, _I, _I, _VP]),
     "snail_debug_packet_costs": (_I, [_VP, _F13, _I, _I, _VP]),
     "snail_debug_occupancy": (_I, [_VP]),
+    "snail_debug_anyorder": (_I, [_VP, _F13, _I, _I, _I, _I, _VP]),
     "snail_last_launch": (_I, [_VP, _VP, _VP]),
 }
 

@@ -27,6 +27,7 @@
 //   EXACT : select-based Min/Max in the reference's operand order + the interval culls, for packets
 //           containing non-finite reciprocals (e.g. dir == -1e-8 exactly, src/rtbase.h:117-120).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -1196,7 +1197,10 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 // SNAIL_BLOCK_WAVES packets per workgroup (one per wave; waves end independently, nothing of the block is shared): the XCD's
 // region turn is kept -- wave w of hardware block B takes entry (B >> 3) * W + w of XCD (B & 7)'s list.
 #ifndef SNAIL_BLOCK_WAVES
-#define SNAIL_BLOCK_WAVES 1
+#define SNAIL_BLOCK_WAVES 1 // 2 and 4 measured slower (22.65 / 21.80 vs 23.40 Grays/s): residency is not limited by workgroup slots
+#endif
+#ifndef SNAIL_PRIO_RANK
+#define SNAIL_PRIO_RANK 1024
 #endif
 template <bool DEEP>
 __global__ __launch_bounds__(64 * SNAIL_BLOCK_WAVES) __attribute__((amdgpu_waves_per_eu(SNAIL_PRIMARY_WAVES))) void k_primary(PrimaryArgs A) {
@@ -1212,7 +1216,11 @@ __global__ __launch_bounds__(64 * SNAIL_BLOCK_WAVES) __attribute__((amdgpu_waves
 		if(b >= A.nSlots) return;
 		li = __builtin_amdgcn_readfirstlane(A.order[b]);
 		if((unsigned)li >= (unsigned)A.nSlots) return;
-#ifdef SNAIL_PRIO_RANK // experiment: static priority by rank in the fed-back order (the heaviest SNAIL_PRIO_RANK packets: 3, next: 2, next two: 1)
+		// issue priority by rank in the fed-back order: the heaviest 1024 packets (one per SIMD) outrank whatever shares their SIMD, the
+		// next 1024 come second, the next 2048 third -- the frame ends with its heaviest packets, so they should never wait for an issue
+		// slot (priority, then age: MI355X_MICROARCH.md "Two waves per SIMD").  Same box, 4 frames in flight: 23.64 vs 23.10 Grays/s,
+		// lone frame 0.231 vs 0.234 ms (profiles/README.md, round 2); 0 = off
+#if SNAIL_PRIO_RANK > 0
 		if(b < SNAIL_PRIO_RANK) __builtin_amdgcn_s_setprio(3);
 		else if(b < 2 * SNAIL_PRIO_RANK) __builtin_amdgcn_s_setprio(2);
 		else if(b < 4 * SNAIL_PRIO_RANK) __builtin_amdgcn_s_setprio(1);
@@ -1934,6 +1942,13 @@ __global__ __launch_bounds__(256) void k_planar_to_frame(const int4 *tiles, cons
 		unsigned char *d = frame + (size_t)yy * pitch + (size_t)xx * 3;
 		d[2] = red; d[1] = (unsigned char)(p[(size_t)n + i] + red); d[0] = (unsigned char)(p[(size_t)2 * n + i] + red);
 	}
+}
+
+// A stream-ordered pause of `ticks` periods of the 100 MHz constant clock (s_memrealtime): one wave that sleeps in 64-cycle naps.
+// Used to de-phase the frame streams when a pipeline starts from idle (snail_delay_dev).  Ends after `ticks` whatever happens.
+__global__ __launch_bounds__(64) void k_delay(unsigned ticks) {
+	const u64 t0 = __builtin_amdgcn_s_memrealtime();
+	while((unsigned)(__builtin_amdgcn_s_memrealtime() - t0) < ticks) __builtin_amdgcn_s_sleep(1);
 }
 
 // diagnostic: what the workgroup dispatcher alone sustains (tools/dispatch_rate.py)
@@ -2733,6 +2748,15 @@ int snail_planar_to_frame_dev(const int32_t *dTiles, const int64_t *dInOffsets, 
 	return 0;
 }
 
+int snail_delay_dev(float microseconds, void *stream) {
+	if(!(microseconds >= 0.0f) || microseconds > 10000.0f) { snail_set_error("snail_delay_dev: delay outside 0..10000 us"); return 1; }
+	const unsigned ticks = (unsigned)(microseconds * 100.0f);
+	if(ticks == 0) return 0;
+	hipLaunchKernelGGL(dev::k_delay, dim3(1), dim3(64), 0, (hipStream_t)stream, ticks);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
 int snail_debug_dispatch_rate(int blocks, int threads, int reps, float *ms_per_launch) {
 	if(blocks <= 0 || threads <= 0 || threads > 1024 || reps <= 0 || !ms_per_launch) { snail_set_error("snail_debug_dispatch_rate: bad arguments"); return 1; }
 	hipEvent_t e0, e1;
@@ -2747,6 +2771,42 @@ int snail_debug_dispatch_rate(int blocks, int threads, int reps, float *ms_per_l
 	HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
 	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 	*ms_per_launch = ms / reps;
+	return 0;
+}
+
+// Experiment: `frames` full-frame primary launches back to back on ONE stream, with or without hipExtAnyOrderLaunch (which clears the
+// AQL barrier bit so that consecutive dispatches of a queue may overlap -- hip_ext.h says "not supported on GFX9xx"; measured, not
+// assumed).  No outputs are stored (null planes), nothing is deferred on a sane scene.  tools/anyorder.py.
+int snail_debug_anyorder(SnailScene *s, const float cam[13], int resx, int resy, int frames, int flags, float *ms_total) {
+	if(int rc = checkScene(s, "snail_debug_anyorder")) return rc;
+	if(frames <= 0 || !ms_total || useDeep(s)) { snail_set_error("snail_debug_anyorder: bad arguments"); return 1; }
+	DeviceGuard guard(s->device);
+	dev::PrimaryArgs A;
+	memset(&A, 0, sizeof(A));
+	A.nodes = s->dNodes; A.tris = s->dTris;
+	A.g = makeGen(cam, resx, resy);
+	A.resx = resx; A.resy = resy; A.w = resx; A.h = resy;
+	A.fastOK = s->fastOK && originSane(cam);
+	A.pack = stackPack(s);
+	A.pw = (resx + 15) / 16; A.ph = (resy + 15) / 16; A.nPackets = A.pw * A.ph;
+	const int nRegions = ((A.pw + 3) / 4) * ((A.ph + 3) / 4);
+	const int blocks = ((nRegions + 7) / 8) * 8 * 16;
+	A.nBlocks = blocks; A.nSlots = blocks;
+	if(blocks + 2 > s->deferCap) { snail_set_error("snail_debug_anyorder: trace one ordinary frame of this size first"); return 1; }
+	A.defer = s->dDefer[0];
+	hipStream_t st;
+	HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+	hipEvent_t e0, e1;
+	HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+	HIP_TRY(hipDeviceSynchronize());
+	HIP_TRY(hipEventRecord(e0, st));
+	for(int f = 0; f < frames; f++)
+		hipExtLaunchKernelGGL(dev::k_primary<false>, dim3(blocks / SNAIL_BLOCK_WAVES), dim3(64 * SNAIL_BLOCK_WAVES), 0, st, nullptr, nullptr, (unsigned)flags, A);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(e1, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipEventElapsedTime(ms_total, e0, e1));
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st);
 	return 0;
 }
 

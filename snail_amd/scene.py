@@ -202,6 +202,11 @@ class Scene:
         _lib.check(rc, "snail_order_from_cost_dev")
         return order
 
+    @staticmethod
+    def delay(microseconds: float, stream=None):
+        """A stream-ordered pause (snail_delay_dev): de-phases pipelined frame streams that start from idle."""
+        _lib.check(_lib.lib().snail_delay_dev(float(min(max(microseconds, 0.0), 10000.0)), _stream_ptr(stream)), "snail_delay_dev")
+
     def trace_packets(self, cam: Camera, resx: int, resy: int, packet_xy, out=None, stats=None, stream=None, order=None, slot_cost=None):
         """Trace an explicit packet list (int32 device tensor [n,2] of top-left pixels); results are
         packet-major [n,256] in the reference's quad order (t, u, v, tri_id).  `order` / `slot_cost`: optional int32 device tensors

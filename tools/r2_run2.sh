@@ -4,7 +4,8 @@ set -u
 O=gpurun_out/r2b; mkdir -p $O
 export TMPDIR=/tmp
 echo "== gpu tests (product = prefetch loop)"
-timeout -k 10 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; rc=$?; tail -4 $O/pytest_gpu.log; [ $rc -eq 0 ] || exit 1
+timeout -k 10 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; rc=$?; tail -6 $O/pytest_gpu.log
+timeout -k 10 600 python tools/sse_counts.py --write > $O/sse_counts.txt 2>&1; tail -3 $O/sse_counts.txt
 for v in base nopf pfrank; do
   if [ $v = base ]; then unset SNAIL_LIB_PATH; else export SNAIL_LIB_PATH=$PWD/snail_amd/exp/lib_$v.so; fi
   echo "== $v"

@@ -9,8 +9,8 @@ out, bounds = {}, {}
 for name in ("atrium", "stress"):
     r = sse_path_counts(torch, name)
     out[name] = r
-    bounds[name] = {leg: {"hit_miss_flips_max": 0 if leg == "same_rays" else 4 * r[leg]["hit_miss_flips"] + 64, "triId_mismatches_max": 4 * r[leg]["triId_mismatches"] + 64,
-                          "observed": r[leg]} for leg in r}
+    keys = ("hit_miss_flips", "triId_mismatches", "t_outside_tol_same_tri", "uv_outside_tol_same_tri", "mismatches_not_near_tie")
+    bounds[name] = {leg: dict({k + "_max": (0 if leg == "same_rays" and k != "triId_mismatches" else 4 * r[leg][k] + 64) for k in keys}, observed=r[leg]) for leg in r}
     print(name, json.dumps(r))
 bounds["note"] = "observed on an MI355X box (host CPU: %s) by tools/sse_counts.py; bound = 4 x observed + 64 (0 for hit/miss flips on the same-rays leg)" % (
     [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0])

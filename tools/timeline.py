@@ -10,10 +10,11 @@ from snail_amd.scene import Scene
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 warm = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 ns = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+stag = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 tv = scenes.scene_by_name("atrium"); h = HostBVH.build(tv)
 cam = FPSCamera(*scenes.atrium_camera()).camera()
 sc = Scene(h, 0)
-rnd = DistributedRenderer(sc, 1920, 1080, 0, 1, slots=ns)
+rnd = DistributedRenderer(sc, 1920, 1080, 0, 1, slots=ns, stagger=bool(stag))
 for rep in range(3):
     for _ in range(warm): rnd.render(cam)
     rnd.flush(); torch.cuda.synchronize()
