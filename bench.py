@@ -125,7 +125,7 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="frames in flight (HIP streams); 0 = the renderer's default (4); 1 = strictly serial frames")
     ap.add_argument("--event-every", type=int, default=8, help="bracket every n-th traversal launch with HIP events (roofline.kernel_ms)")
     ap.add_argument("--feedback-order", type=int, default=1, help="1 (default) = dispatch packets heaviest first by the node visits of an earlier frame (DistributedRenderer feedback_order)")
-    ap.add_argument("--stagger", type=int, default=1, help="1 (default) = de-phase the frame streams when the pipeline starts from idle (DistributedRenderer stagger)")
+    ap.add_argument("--stagger", type=int, default=0, help="1 = de-phase the frame streams when the pipeline starts from idle (DistributedRenderer stagger; measured: no gain)")
     ap.add_argument("--lone-frames", type=int, default=12, help="N=1: frames traced one at a time after the timed region (lone_frame_ms); 0 = skip")
     args = ap.parse_args()
 
@@ -195,14 +195,18 @@ def main():
     tot = rnd.reduce_stats(st) if world > 1 else st
     total_rays = int(tot.cpu().numpy()[2]) if (rank == 0 and cfg["lights"]) else primary_rays
     node_visits = int(tot.cpu().numpy()[1]) if rank == 0 else 0
+    for _ in range(args.warmup):
+        rnd.render(cam)
+    rnd.flush()
+    barrier()
+
+    # The two diagnostic passes (N = 1) run HERE, directly in front of the timed region, not before the warm-up: they are a few
+    # milliseconds of GPU work, and a 2 ms timed region (the driver's --steps 20) cannot bring an idle GPU to its operating clocks by
+    # itself -- the same 20 steps measure 0.111 ms/step after 5 warm-up frames and 0.102 after 2000 (profiles/README.md, round 2).
     acc = pk = None
     if rank == 0 and world == 1:
         acc = scene.account_primary(cam, resx, resy)                      # single-ray accounting walk, informational
         pk = scene.packet_costs(cam, resx, resy)                          # per-packet {visits, ..., triangle records fetched, ...}
-
-    for _ in range(args.warmup):
-        rnd.render(cam)
-    rnd.flush()
     barrier()
 
     # ---- timed region: EXACTLY K steps (frames are pipelined over the renderer's HIP streams, see DistributedRenderer) ----

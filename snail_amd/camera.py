@@ -25,12 +25,22 @@ class Camera:
     front: np.ndarray
     plane_dist: float = 1.0
 
+    def __setattr__(self, name, value):
+        object.__setattr__(self, name, value)
+        if name != "_a13":
+            object.__setattr__(self, "_a13", None)     # a changed field invalidates the cached flat form
+
     def as_array13(self) -> np.ndarray:
-        """pos, right, up, front, plane_dist -- the flat layout the C-ABI takes."""
-        return np.concatenate([
-            np.asarray(self.pos, dtype=F32), np.asarray(self.right, dtype=F32),
-            np.asarray(self.up, dtype=F32), np.asarray(self.front, dtype=F32),
-            np.asarray([self.plane_dist], dtype=F32)]).astype(F32)
+        """pos, right, up, front, plane_dist -- the flat layout the C-ABI takes (cached: a frame loop asks for it several times per frame;
+        treat the returned array as read-only)."""
+        a = self.__dict__.get("_a13")
+        if a is None:
+            a = np.ascontiguousarray(np.concatenate([
+                np.asarray(self.pos, dtype=F32), np.asarray(self.right, dtype=F32),
+                np.asarray(self.up, dtype=F32), np.asarray(self.front, dtype=F32),
+                np.asarray([self.plane_dist], dtype=F32)]).astype(F32))
+            object.__setattr__(self, "_a13", a)
+        return a
 
 
 def _rotate(axis, radians):

@@ -401,6 +401,9 @@ __device__ __forceinline__ bool leafShared(const uint4 *__restrict__ tris, int c
 
 // ---- leaf, per-ray origins (src/triangle.cpp:30-38; no packet-level triangle cull: src/bvh/traverse.cpp:44): wave-uniform
 // scalar triangle fetch, every lane does the full Collide arithmetic for its 4 rays
+#ifndef SNAIL_PERRAY_CULL
+#define SNAIL_PERRAY_CULL 1 // 0 = without the packet-level early-out below (A/B measurements)
+#endif
 template <bool MASK, int M, bool BARY>
 __device__ __forceinline__ void leafPerRay(const uint4 *__restrict__ tris, int count, int firstTri, int lane, int first, int last, const float (&org)[3][4],
 										   Quad &Q, unsigned mask4, int (&tid)[4], float (&bu)[4], float (&bv)[4], Counters &st) {
@@ -409,22 +412,43 @@ __device__ __forceinline__ void leafPerRay(const uint4 *__restrict__ tris, int c
 	st.leaves++; st.fetched += (unsigned)count;
 	for(int k = 0; k < count; k++) {
 		const Tri t = loadTriScalar(tris, firstTri + k);
+		// The cheap third of Collide first -- det, tv, tmul (src/triangle.cpp:26-33) -- and a packet-level early-out that is EXACT by
+		// construction: a lane can only accept (t < dist && t > 0, :56) if det and tmul are non-zero with equal signs (t = (1/det) * tmul:
+		// the correctly rounded reciprocal keeps det's sign, a product that underflows to zero is not > 0) and if |tmul| does not exceed
+		// dist * |det| by more than roundoff: with |tmul| > (dist |det|) (1 + 1e-5) + 1e-30, (1/det) tmul rounds to more than dist whatever
+		// the two roundings do (each 2^-24 relative; the absolute term covers denormal products).  When no live lane of the packet can
+		// accept, u, v and the inside test -- two thirds of the arithmetic -- cannot change anything and are skipped; `Intersection` is
+		// counted as before (the reference has no packet-level triangle cull for per-ray origins, src/bvh/traverse.cpp:44, its interval
+		// formulas for this case are dead code, src/triangle.cpp:130-160).  Finite inputs only (M_FAST / M_COH packets).
+		float det[4], tmul[4];
+		bool cand = false;
 #pragma unroll
 		for(int l = 0; l < 4; l++) {
-			const float det = Q.d[0][l] * t.n[0] + Q.d[1][l] * t.n[1] + Q.d[2][l] * t.n[2];
-			float tv[3] = {org[0][l] - t.a[0], org[1][l] - t.a[1], org[2][l] - t.a[2]};
+			det[l] = Q.d[0][l] * t.n[0] + Q.d[1][l] * t.n[1] + Q.d[2][l] * t.n[2];
+			const float tv[3] = {org[0][l] - t.a[0], org[1][l] - t.a[1], org[2][l] - t.a[2]};
+			tmul[l] = -(tv[0] * t.n[0] + tv[1] * t.n[1] + tv[2] * t.n[2]);
+			if(M != M_EXACT && SNAIL_PERRAY_CULL) {
+				bool c = inRange & ((__float_as_int(det[l]) ^ __float_as_int(tmul[l])) >= 0) & (det[l] != 0.0f) & (tmul[l] != 0.0f);
+				c = c & (__builtin_fabsf(tmul[l]) <= (Q.dist[l] * __builtin_fabsf(det[l])) * 1.00001f + 1e-30f);
+				if(MASK) c = c & (((mask4 >> l) & 1u) != 0);
+				cand |= c;
+			}
+		}
+		if(M != M_EXACT && SNAIL_PERRAY_CULL && __builtin_amdgcn_ballot_w64(cand) == 0) { st.intersects += width; continue; }
+#pragma unroll
+		for(int l = 0; l < 4; l++) {
+			const float tv[3] = {org[0][l] - t.a[0], org[1][l] - t.a[1], org[2][l] - t.a[2]};   // again: three subtractions against 12 live registers
 			float c0[3] = {t.ba[1] * tv[2] - t.ba[2] * tv[1], t.ba[2] * tv[0] - t.ba[0] * tv[2], t.ba[0] * tv[1] - t.ba[1] * tv[0]};
 			float c1[3] = {tv[1] * t.ca[2] - tv[2] * t.ca[1], tv[2] * t.ca[0] - tv[0] * t.ca[2], tv[0] * t.ca[1] - tv[1] * t.ca[0]};
-			const float tmul = -(tv[0] * t.n[0] + tv[1] * t.n[1] + tv[2] * t.n[2]);
 			const float v = (Q.d[0][l] * c0[0] + Q.d[1][l] * c0[1] + Q.d[2][l] * c0[2]) * t.it0;
 			const float u = (Q.d[0][l] * c1[0] + Q.d[1][l] * c1[1] + Q.d[2][l] * c1[2]) * t.it0;
-			const float duv = det - u - v;
+			const float duv = det[l] - u - v;
 			const float uvmin = Min3<M>(u, v, duv), uvmax = Max3<M>(u, v, duv);
 			bool test = ((uvmax <= 0.0f) | (uvmin >= 0.0f)) & inRange;
 			if(MASK) test = test & (((mask4 >> l) & 1u) != 0);
 			if(test) {
-				const float idet = 1.0f / det;
-				const float dd = idet * tmul;
+				const float idet = 1.0f / det[l];
+				const float dd = idet * tmul[l];
 				if(dd < Q.dist[l] && dd > 0.0f) {
 					Q.dist[l] = dd; tid[l] = firstTri + k;
 					if(BARY) { bu[l] = u * idet; bv[l] = v * idet; }
@@ -1285,6 +1309,7 @@ template <bool DEEP>
 __global__ __launch_bounds__(64) void k_primary_exact(PrimaryArgs A) {
 	__shared__ float lds[LDS_FLOATS_PER_WAVE];
 	const int n = __builtin_amdgcn_readfirstlane(A.defer[0]);
+	if(n == 0) return; // nothing was deferred (the rule): the list is armed as it stands, no fence, no counter
 	for(int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) primaryPacket<DEEP, true>(A, __builtin_amdgcn_readfirstlane(A.defer[2 + i]), lds);
 	__threadfence();
 	if((threadIdx.x & 63) == 0 && atomicAdd(&A.defer[1], 1) == (int)gridDim.x - 1) { A.defer[0] = 0; A.defer[1] = 0; }
@@ -1536,6 +1561,7 @@ template <bool DEEP, int SRC>
 __global__ __launch_bounds__(64) void k_light_exact(ShadeArgs A) {
 	__shared__ float lds[LDS_FLOATS_PER_WAVE];
 	const int cnt = __builtin_amdgcn_readfirstlane(A.defer[0]);
+	if(cnt == 0) return;
 	for(int i = (int)blockIdx.x; i < cnt; i += (int)gridDim.x) {
 		const int e = __builtin_amdgcn_readfirstlane(A.defer[16 + i]);
 		lightPacket<DEEP, SRC, true>(A, e % A.nBlocks, e / A.nBlocks, lds);
@@ -1767,6 +1793,7 @@ template <bool SHARED, bool MASK, bool DEEP, bool BARY>
 __global__ __launch_bounds__(64) void k_rays_exact(RaysArgs A) {
 	__shared__ float lds[LDS_FLOATS_PER_WAVE];
 	const int n = __builtin_amdgcn_readfirstlane(A.defer[0]);
+	if(n == 0) return;
 	for(int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) raysPacket<SHARED, MASK, DEEP, BARY, true>(A, __builtin_amdgcn_readfirstlane(A.defer[16 + i]), lds);
 	__threadfence();
 	if((threadIdx.x & 63) == 0 && atomicAdd(&A.defer[1], 1) == (int)gridDim.x - 1) { A.defer[0] = 0; A.defer[1] = 0; }
@@ -1827,6 +1854,7 @@ template <bool DEEP>
 __global__ __launch_bounds__(64) void k_shadow_exact(RaysArgs A) {
 	__shared__ float lds[LDS_FLOATS_PER_WAVE];
 	const int n = __builtin_amdgcn_readfirstlane(A.defer[0]);
+	if(n == 0) return;
 	for(int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) shadowPacket<DEEP, true>(A, __builtin_amdgcn_readfirstlane(A.defer[16 + i]), lds);
 	__threadfence();
 	if((threadIdx.x & 63) == 0 && atomicAdd(&A.defer[1], 1) == (int)gridDim.x - 1) { A.defer[0] = 0; A.defer[1] = 0; }
@@ -2046,7 +2074,7 @@ struct SnailScene {
 	int fastOK = 0; // every triangle record finite and of sane magnitude (see file header)
 	int lastBlocks = 0, lastThreads = 0;
 	unsigned long long *dStats = nullptr; // 4 x u64 scratch for the host-pointer entry points
-	enum { kDeferSlots = 8 };
+	enum { kDeferSlots = 16 };
 	int *dDefer[kDeferSlots] = {};        // deferred-packet lists, one per launch in flight (round-robin)
 	// a slot's buffers are reused by the 8th launch after it, possibly on another stream and possibly while the host runs far
 	// ahead of the device: each slot carries an event recorded after its last kernel, and the next user's stream waits for it
@@ -2167,7 +2195,8 @@ int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0
 	A.nBlocks = blocks;
 	A.nSlots = dPacketXY ? nPackets : blocks;
 	A.order = dOrder; A.slotCost = dSlotCost;
-	s->lastBlocks = blocks; s->lastThreads = 64;
+	const int gridBlocks = blocks;
+	s->lastBlocks = gridBlocks; s->lastThreads = 64;
 	// deferred-packet list of this launch (re-allocated, synchronously, only when a larger frame than ever before arrives)
 	if(blocks + 2 > s->deferCap) {
 		HIP_TRY(hipDeviceSynchronize());
@@ -2188,7 +2217,7 @@ int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0
 	// a scene with sane records defers (practically) nothing: a handful of blocks suffices; an unsafe scene defers every packet
 	const int exactBlocks = A.fastOK ? (blocks < 8 ? blocks : 8) : (blocks < 2048 ? blocks : 2048);
 	static_assert(128 % SNAIL_BLOCK_WAVES == 0, "the slot count is a multiple of 128");
-	const dim3 grid(blocks / SNAIL_BLOCK_WAVES), block(64 * SNAIL_BLOCK_WAVES);
+	const dim3 grid(gridBlocks / SNAIL_BLOCK_WAVES), block(64 * SNAIL_BLOCK_WAVES);
 	if(dCost) { // diagnostic launch (snail_debug_packet_costs)
 		if(useDeep(s)) hipLaunchKernelGGL(dev::k_primary_diag<true>, dim3(blocks), dim3(64), 0, stream, A);
 		else hipLaunchKernelGGL(dev::k_primary_diag<false>, dim3(blocks), dim3(64), 0, stream, A);

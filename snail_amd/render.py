@@ -165,7 +165,7 @@ class DistributedRenderer:
                  payload: str = "rgb8", slots: int | None = None, stage_cpu: bool = False, force_collective: bool = False, lights7=None,
                  ambient=(0.1, 0.1, 0.1), color=(1.0, 1.0, 1.0), reflections: bool = False, feedback_order: bool = True, order_refresh: int = 16,
                  inline_collective: bool | None = None, rank0_share: float = 1.0, plan_ranks: int | None = None, plan_rank: int | None = None,
-                 stagger: bool = True):
+                 stagger: bool = False):
         import torch
         self.torch = torch
         self.scene = scene
@@ -205,6 +205,7 @@ class DistributedRenderer:
         # (0.43 ms per round of four 1080p frames instead of 0.356 once the phases have drifted apart, tools/timeline.py).  The first
         # launch of stream k after an idle period is therefore preceded by a stream-ordered pause of k x 0.75 x (time per frame), the
         # time per frame being the best one observed over the bursts so far (snail_delay_dev: one sleeping wave).
+        # (measured: no gain -- the streams re-lock within a few frames and the ramp costs more than it saves; kept as an option, default off)
         self.stagger = bool(stagger) and self.nslots > 1
         self.idle, self.burst_t0, self.burst_frames, self.frame_s_est = True, 0.0, 0, None
         # one frame buffer per slot, for both payloads: the scatters of consecutive frames run on different streams and may overlap;

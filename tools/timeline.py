@@ -10,7 +10,7 @@ from snail_amd.scene import Scene
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 warm = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 ns = int(sys.argv[3]) if len(sys.argv) > 3 else 4
-stag = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+stag = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 tv = scenes.scene_by_name("atrium"); h = HostBVH.build(tv)
 cam = FPSCamera(*scenes.atrium_camera()).camera()
 sc = Scene(h, 0)
