@@ -200,9 +200,7 @@ def main():
     rnd.flush()
     barrier()
 
-    # The two diagnostic passes (N = 1) run HERE, directly in front of the timed region, not before the warm-up: they are a few
-    # milliseconds of GPU work, and a 2 ms timed region (the driver's --steps 20) cannot bring an idle GPU to its operating clocks by
-    # itself -- the same 20 steps measure 0.111 ms/step after 5 warm-up frames and 0.102 after 2000 (profiles/README.md, round 2).
+    # the two diagnostic passes (N = 1), outside the timed region
     acc = pk = None
     if rank == 0 and world == 1:
         acc = scene.account_primary(cam, resx, resy)                      # single-ray accounting walk, informational

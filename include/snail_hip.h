@@ -198,6 +198,19 @@ int snail_render_whitted_packets_dev(SnailScene *, const float cam[13], int resx
                                      const float *lights7, int nLights, const float ambient[3], const float color[3], int flags,
                                      uint8_t *d_bgr_packets, uint64_t *d_stats, void *stream);
 
+/* Scene::TraceTransparency (src/scene_trace.cpp:620-634) for primary packets, staged on the device: the rays of the listed packets
+ * continue behind their hits -- origin = dir * (t + 0.001) + origin, direction and reciprocal unchanged -- for the lanes of the
+ * caller's selector (d_sel: 1 byte per quad, low 4 bits = lanes, packet-major; the reference's `transSel`, which its material system
+ * fills: lanes whose hit material has fTransparency and opacity < 1, src/scene_trace.cpp:190,306,349,468-473; a lane without a hit is
+ * dropped), are traced as RayGroup<0,1> and shaded by the nested RayTrace in the simple-shading configuration (samples, lights, shadow
+ * packets; no reflection, no further transparency: with no shading data the nested call's own transSel is empty, :122-126,359-452).
+ * d_t / d_triId = the packets' hit records (packet-major, e.g. from snail_trace_packets_dev); d_color = [nPackets][256][3] floats, the
+ * reference's `transColor`, which the caller blends: diffuse = VLerp(transColor, diffuse, opacity) (:479-482).  d_stats[2] += selected
+ * lanes + their shadow lanes with N.L > 0. */
+int snail_trace_transparency_dev(SnailScene *, const float cam[13], int resx, int resy, const int32_t *d_packet_xy, int nPackets,
+                                 const float *d_t, const int32_t *d_triId, const uint8_t *d_sel, const float *lights7, int nLights,
+                                 const float ambient[3], const float color[3], float *d_color, uint64_t *d_stats, void *stream);
+
 /* ---- the tile API (src/render.h:16-27) with host buffers ------------------------------------------------------------------ */
 /* The two Render(...) shapes of the reference as plain-pointer entry points; include/snail_adapter.hpp wraps them in overloads with
  * the reference's exact signatures.  One call renders the WHOLE tile list / image on the device (same kernels as the *_dev entry

@@ -778,6 +778,36 @@ void renderWhitted(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *ca
 	if(stats) for(auto &s : tstats) { stats[0] += s.intersects; stats[1] += s.iters; stats[2] += s.rays; stats[3] += s.skips; }
 }
 
+// Scene::TraceTransparency (src/scene_trace.cpp:620-634) for one primary packet whose hit distances and transparency selector the
+// caller supplies: origin[q] = rays.Dir(q) * (distance[q] + 0.001) + rays.Origin(q); the packet goes on as RayGroup<0,0> / <0,1> with the
+// SAME dir / idir arrays through RayTrace (:631-633).  Selector lanes without a hit are dropped (only a shaded hit can set transSel,
+// :190,306,349); lanes outside the selector carry zeros (see rayTracePacket: masked lanes cannot influence a result).
+template <int MODE>
+void transparencyPacket(const OrcNode *nodes, const OrcTri *tris, const OrcCamera &cam, const RayGen &g, int px, int py, const float *t /*256*/,
+						const uint8_t *sel /*64*/, const Lighting &L, float (*outColor)[3] /*256*/, Stats &st) {
+	float dir[768], idir[768];
+	genPacket<MODE>(g, px, py, dir, idir);
+	std::vector<float> org(768, 0.0f), d2(768, 0.0f), i2(768, 0.0f);
+	uint8_t m[64];
+	bool all = true;
+	for(int q = 0; q < 64; q++) {
+		m[q] = 0;
+		for(int l = 0; l < 4; l++) {
+			const bool on = ((sel[q] >> l) & 1) != 0 && t[q * 4 + l] < kInf;
+			if(on) m[q] |= (uint8_t)(1 << l);
+			for(int c = 0; c < 3; c++) {
+				const float dv = on ? dir[q * 12 + c * 4 + l] : 0.0f;
+				d2[q * 12 + c * 4 + l] = dv;
+				org[q * 12 + c * 4 + l] = on ? dv * (t[q * 4 + l] + 0.001f) + cam.pos[c] : 0.0f;
+				i2[q * 12 + c * 4 + l] = on ? idir[q * 12 + c * 4 + l] : safeInv<MODE>(0.0f);
+			}
+		}
+		all = all && m[q] == 15;
+	}
+	Rays rr{64, false, org.data(), d2.data(), i2.data(), all ? nullptr : m};
+	rayTracePacket<MODE>(nodes, tris, rr, L, 1, outColor, st);      // depth 1: the nested call of the simple-shading configuration
+}
+
 uint64_t fnv1a(uint64_t h, const void *p, size_t n) {
 	const unsigned char *b = (const unsigned char *)p;
 	for(size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001b3ull; }
@@ -893,6 +923,20 @@ void orc_render_whitted(const OrcNode *nodes, const OrcTri *tris, const OrcCamer
 }
 
 // the `compress` store of RenderTask::Work (src/render.cpp:140-163): planes R, G-R, B-R of a tile, from the interleaved B,G,R frame
+void orc_trace_transparency(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam, int resx, int resy, const int32_t *packet_xy, int nPackets,
+							const float *t, const uint8_t *sel, const float *lights7, int nLights, const float ambient[3], const float color[3],
+							float *out_color, uint64_t *stats, int mode) {
+	const Lighting L{lights7, nLights, ambient, color, false};
+	RayGen g = makeRayGen(*cam, resx, resy);
+	Stats st;
+	for(int p = 0; p < nPackets; p++) {
+		float (*col)[3] = (float (*)[3])(out_color + (size_t)p * 768);
+		if(mode == ORC_MODE_SSE) transparencyPacket<ORC_MODE_SSE>(nodes, tris, *cam, g, packet_xy[p * 2], packet_xy[p * 2 + 1], t + (size_t)p * 256, sel + (size_t)p * 64, L, col, st);
+		else transparencyPacket<ORC_MODE_IEEE>(nodes, tris, *cam, g, packet_xy[p * 2], packet_xy[p * 2 + 1], t + (size_t)p * 256, sel + (size_t)p * 64, L, col, st);
+	}
+	if(stats) { stats[0] += st.intersects; stats[1] += st.iters; stats[2] += st.rays; stats[3] += st.skips; }
+}
+
 void orc_planar_encode_tile(const uint8_t *frame_bgr, int pitch, int x, int y, int w, int h, uint8_t *out) {
 	for(int ty = 0; ty < h; ty++)
 		for(int tx = 0; tx < w; tx++) {

@@ -114,6 +114,15 @@ void orc_render_whitted(const OrcNode *nodes, const OrcTri *tris, const OrcCamer
                         const float *lights7, int nLights, const float ambient[3], const float color[3], int flags,
                         uint8_t *frame_bgr, int pitch, uint64_t *stats, int mode, int threads);
 
+/* Scene::TraceTransparency (src/scene_trace.cpp:620-634) for primary packets: the rays of the listed packets (top-left corners packet_xy,
+ * regenerated from the camera) continue behind their hits -- origin = dir * (t + 0.001) + origin, dir / idir unchanged -- for the lanes
+ * of the caller's selector `sel` (1 byte per quad, the reference's transSel; lanes without a hit are dropped) as RayGroup<0,1>, through
+ * the nested RayTrace of the simple-shading configuration (no reflections, no further transparency).  t = the packets' hit distances
+ * (packet-major, 256 per packet); out_color = 3 floats per ray (`transColor`); stats += the nested call's counters. */
+void orc_trace_transparency(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam, int resx, int resy, const int32_t *packet_xy, int nPackets,
+                            const float *t, const uint8_t *sel, const float *lights7, int nLights, const float ambient[3], const float color[3],
+                            float *out_color, uint64_t *stats, int mode);
+
 /* The render node's tile wire format: the `compress` store of RenderTask::Work (src/render.cpp:140-163) -- planes R, G-R, B-R
  * (mod 256) of tile (x, y, w, h) taken from an interleaved B,G,R frame -- and its inverse, DecompressTask::Work's plane loop
  * (src/compression.cpp:112-141). */

@@ -401,9 +401,9 @@ __device__ __forceinline__ bool leafShared(const uint4 *__restrict__ tris, int c
 
 // ---- leaf, per-ray origins (src/triangle.cpp:30-38; no packet-level triangle cull: src/bvh/traverse.cpp:44): wave-uniform
 // scalar triangle fetch, every lane does the full Collide arithmetic for its 4 rays
-#ifndef SNAIL_PERRAY_CULL
-#define SNAIL_PERRAY_CULL 1 // 0 = without the packet-level early-out below (A/B measurements)
-#endif
+// Measured and not taken (round 2, profiles/README.md): computing det, tv, tmul of all four rays first and skipping u, v and the inside test
+// when no live lane of the packet can accept (det, tmul of equal sign and |tmul| <= dist |det| (1 + 1e-5) + 1e-30: exact by construction)
+// -- mirrored bounce 1.005 vs 0.940 ms per frame: too few leaf triangles are rejected by every ray, and the kernel goes from 79 to 95 VGPRs.
 template <bool MASK, int M, bool BARY>
 __device__ __forceinline__ void leafPerRay(const uint4 *__restrict__ tris, int count, int firstTri, int lane, int first, int last, const float (&org)[3][4],
 										   Quad &Q, unsigned mask4, int (&tid)[4], float (&bu)[4], float (&bv)[4], Counters &st) {
@@ -412,43 +412,22 @@ __device__ __forceinline__ void leafPerRay(const uint4 *__restrict__ tris, int c
 	st.leaves++; st.fetched += (unsigned)count;
 	for(int k = 0; k < count; k++) {
 		const Tri t = loadTriScalar(tris, firstTri + k);
-		// The cheap third of Collide first -- det, tv, tmul (src/triangle.cpp:26-33) -- and a packet-level early-out that is EXACT by
-		// construction: a lane can only accept (t < dist && t > 0, :56) if det and tmul are non-zero with equal signs (t = (1/det) * tmul:
-		// the correctly rounded reciprocal keeps det's sign, a product that underflows to zero is not > 0) and if |tmul| does not exceed
-		// dist * |det| by more than roundoff: with |tmul| > (dist |det|) (1 + 1e-5) + 1e-30, (1/det) tmul rounds to more than dist whatever
-		// the two roundings do (each 2^-24 relative; the absolute term covers denormal products).  When no live lane of the packet can
-		// accept, u, v and the inside test -- two thirds of the arithmetic -- cannot change anything and are skipped; `Intersection` is
-		// counted as before (the reference has no packet-level triangle cull for per-ray origins, src/bvh/traverse.cpp:44, its interval
-		// formulas for this case are dead code, src/triangle.cpp:130-160).  Finite inputs only (M_FAST / M_COH packets).
-		float det[4], tmul[4];
-		bool cand = false;
 #pragma unroll
 		for(int l = 0; l < 4; l++) {
-			det[l] = Q.d[0][l] * t.n[0] + Q.d[1][l] * t.n[1] + Q.d[2][l] * t.n[2];
-			const float tv[3] = {org[0][l] - t.a[0], org[1][l] - t.a[1], org[2][l] - t.a[2]};
-			tmul[l] = -(tv[0] * t.n[0] + tv[1] * t.n[1] + tv[2] * t.n[2]);
-			if(M != M_EXACT && SNAIL_PERRAY_CULL) {
-				bool c = inRange & ((__float_as_int(det[l]) ^ __float_as_int(tmul[l])) >= 0) & (det[l] != 0.0f) & (tmul[l] != 0.0f);
-				c = c & (__builtin_fabsf(tmul[l]) <= (Q.dist[l] * __builtin_fabsf(det[l])) * 1.00001f + 1e-30f);
-				if(MASK) c = c & (((mask4 >> l) & 1u) != 0);
-				cand |= c;
-			}
-		}
-		if(M != M_EXACT && SNAIL_PERRAY_CULL && __builtin_amdgcn_ballot_w64(cand) == 0) { st.intersects += width; continue; }
-#pragma unroll
-		for(int l = 0; l < 4; l++) {
-			const float tv[3] = {org[0][l] - t.a[0], org[1][l] - t.a[1], org[2][l] - t.a[2]};   // again: three subtractions against 12 live registers
+			const float det = Q.d[0][l] * t.n[0] + Q.d[1][l] * t.n[1] + Q.d[2][l] * t.n[2];
+			float tv[3] = {org[0][l] - t.a[0], org[1][l] - t.a[1], org[2][l] - t.a[2]};
 			float c0[3] = {t.ba[1] * tv[2] - t.ba[2] * tv[1], t.ba[2] * tv[0] - t.ba[0] * tv[2], t.ba[0] * tv[1] - t.ba[1] * tv[0]};
 			float c1[3] = {tv[1] * t.ca[2] - tv[2] * t.ca[1], tv[2] * t.ca[0] - tv[0] * t.ca[2], tv[0] * t.ca[1] - tv[1] * t.ca[0]};
+			const float tmul = -(tv[0] * t.n[0] + tv[1] * t.n[1] + tv[2] * t.n[2]);
 			const float v = (Q.d[0][l] * c0[0] + Q.d[1][l] * c0[1] + Q.d[2][l] * c0[2]) * t.it0;
 			const float u = (Q.d[0][l] * c1[0] + Q.d[1][l] * c1[1] + Q.d[2][l] * c1[2]) * t.it0;
-			const float duv = det[l] - u - v;
+			const float duv = det - u - v;
 			const float uvmin = Min3<M>(u, v, duv), uvmax = Max3<M>(u, v, duv);
 			bool test = ((uvmax <= 0.0f) | (uvmin >= 0.0f)) & inRange;
 			if(MASK) test = test & (((mask4 >> l) & 1u) != 0);
 			if(test) {
-				const float idet = 1.0f / det[l];
-				const float dd = idet * tmul[l];
+				const float idet = 1.0f / det;
+				const float dd = idet * tmul;
 				if(dd < Q.dist[l] && dd > 0.0f) {
 					Q.dist[l] = dd; tid[l] = firstTri + k;
 					if(BARY) { bu[l] = u * idet; bv[l] = v * idet; }
@@ -1340,7 +1319,7 @@ __device__ __forceinline__ void loadQuad3(const float *base, size_t quad, float 
 // recomputed (the same operations on the same operands, hence the same bits) wherever they are needed: a few hundred VALU
 // instructions per packet against the thousands of a walk, and no kernel carries state across a walk that the walk does not use.
 enum { SRC_PRIMARY = 0, SRC_MIRROR = 1 };
-enum { DST_FRAME = 0, DST_MIRROR = 1, DST_COLOR = 2 };
+enum { DST_FRAME = 0, DST_MIRROR = 1, DST_COLOR = 2, DST_CONTINUE = 3 };
 struct ShadeArgs {
 	const uint4 *nodes, *tris;
 	GenConst g;
@@ -1362,6 +1341,7 @@ struct ShadeArgs {
 	float *rCol;         // colour of the mirrored rays, [packet][256][3]
 	float *sDist;        // shadow distances after TraverseShadow, [light][packet][256]
 	int blend;           // DST_FRAME: diffuse += (rCol - diffuse) * 0.3 on hit lanes
+	const unsigned char *selIn; // DST_CONTINUE: the caller's transparency selector, 1 byte per quad (low 4 bits = lanes), packet-major
 	int *defer;          // [0] = count, [1] = finished blocks of the M_EXACT pass, [16..] = light * nBlocks + grid index of deferred shadow packets
 	unsigned char *frame;
 	int pitch;
@@ -1582,6 +1562,46 @@ __global__ __launch_bounds__(64) void k_final(ShadeArgs A) {
 	Samples S;
 	loadSamples<SRC>(A, P, lane, d, S);
 
+	if(DST == DST_CONTINUE) {
+		// Scene::TraceTransparency (src/scene_trace.cpp:620-634): the packet's rays continue behind their hits -- origin = dir * (t + 0.001)
+		// + origin, dir and idir (= SafeInv(dir), as the caller's RayGroup carries them) unchanged -- for the lanes of the caller's selector
+		// (transSel: lanes whose material is transparent, src/scene_trace.cpp:190,306,349,472; only lanes with a hit can carry one).
+		// Lanes outside the selector: zeros, distance -inf, exactly as the mirrored packets of DST_MIRROR.
+		float ro[3][4], rd[3][4], ri[3][4], rdist[4];
+		const float4 tv4 = *(const float4 *)(A.hitT + quad * 4);
+		const float tt[4] = {tv4.x, tv4.y, tv4.z, tv4.w};
+		const unsigned selq = A.selIn[quad] & 15u;
+		unsigned sel = 0;
+#pragma unroll
+		for(int l = 0; l < 4; l++) {
+			const bool on = S.hit[l] && ((selq >> l) & 1u) != 0;
+			const float tl = tt[l] + 0.001f;
+#pragma unroll
+			for(int c = 0; c < 3; c++) {
+				rd[c][l] = on ? d[c][l] : 0.0f;
+				ro[c][l] = on ? d[c][l] * tl + A.g.org[c] : 0.0f;
+				ri[c][l] = 1.0f / (rd[c][l] + 0.00000001f);
+			}
+			rdist[l] = on ? inf : -inf;
+			sel |= on ? (1u << l) : 0u;
+		}
+		float4 *po = (float4 *)(A.rOrg + quad * 12), *pd = (float4 *)(A.rDir + quad * 12), *pi = (float4 *)(A.rIDir + quad * 12);
+#pragma unroll
+		for(int c = 0; c < 3; c++) {
+			po[c] = make_float4(ro[c][0], ro[c][1], ro[c][2], ro[c][3]);
+			pd[c] = make_float4(rd[c][0], rd[c][1], rd[c][2], rd[c][3]);
+			pi[c] = make_float4(ri[c][0], ri[c][1], ri[c][2], ri[c][3]);
+		}
+		A.rMask[quad] = (unsigned char)sel;
+		*(float4 *)(A.rDist + quad * 4) = make_float4(rdist[0], rdist[1], rdist[2], rdist[3]);
+		*(int4 *)(A.rObj + quad * 4) = make_int4(0, 0, 0, 0);
+		unsigned cnt = 0;     // stats.TracingRays(CountMaskBits(mask)) of the nested RayTrace (src/scene_trace.cpp:116-117)
+#pragma unroll
+		for(int l = 0; l < 4; l++) cnt += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64((sel >> l) & 1u));
+		const Counters none = {0, 0, 0, 0, 0};
+		flushStats(A.stats, none, cnt, lane);
+		return;
+	}
 	if(DST == DST_MIRROR) {
 		// Scene::TraceReflection (src/scene_trace.cpp:603-618): Reflect (src/rtbase_math.h:54-58), origin = position + 0.001 dir,
 		// SafeInv; selector = hit lanes.  Masked lanes: zeros (see include/snail_hip.h), distance -inf.
@@ -2734,6 +2754,51 @@ int snail_render_whitted_packets_dev(SnailScene *s, const float cam[13], int res
 	if(nPackets <= 0) return 0;
 	return renderWhitted("snail_render_whitted_packets_dev", s, cam, resx, resy, dPacketXY, nPackets, lights7, nLights, ambient, color, flags, nullptr, 0, bgrPackets,
 						 dStats, stream);
+}
+
+int snail_trace_transparency_dev(SnailScene *s, const float cam[13], int resx, int resy, const int32_t *dPacketXY, int nPackets, const float *dT, const int32_t *dTriId,
+								 const uint8_t *dSel, const float *lights7, int nLights, const float ambient[3], const float color[3], float *dColor, uint64_t *dStats,
+								 void *stream) {
+	if(int rc = checkScene(s, "snail_trace_transparency_dev")) return rc;
+	if(nPackets <= 0) return 0;
+	if(!dPacketXY || !dT || !dTriId || !dSel || !dColor || resx <= 0 || resy <= 0 || nLights < 0 || nLights > SNAIL_MAX_LIGHTS || (nLights && !lights7) || !ambient || !color ||
+	   ((unsigned long long)dColor & 3)) {
+		snail_set_error("snail_trace_transparency_dev: bad arguments (null buffer, or more than %d lights)", SNAIL_MAX_LIGHTS);
+		return 1;
+	}
+	DeviceGuard guard(s->device);
+	dev::ShadeArgs A;
+	memset(&A, 0, sizeof(A));
+	A.nodes = s->dNodes; A.tris = s->dTris;
+	A.g = makeGen(cam, resx, resy);
+	A.resx = resx; A.resy = resy; A.pw = (resx + 15) / 16; A.ph = (resy + 15) / 16;
+	A.fastOK = s->fastOK && originSane(cam);
+	A.pack = stackPack(s);
+	A.nLights = nLights;
+	for(int n = 0; n < nLights; n++) for(int k = 0; k < 7; k++) A.lights[n][k] = lights7[n * 7 + k];
+	for(int c = 0; c < 3; c++) { A.ambient[c] = ambient[c]; A.color[c] = color[c]; }
+	A.stats = (dev::u64 *)dStats;
+	A.packetXY = (const int2 *)dPacketXY;
+	const int blocks = ((nPackets + 127) / 128) * 128;
+	A.nPackets = nPackets; A.nBlocks = blocks;
+	SnailScene::ShadeScratch &W = s->shade[s->shadeCount++ % SnailScene::kDeferSlots];
+	if(int rc = shadeScratch(s, W, (size_t)nPackets, (size_t)blocks, true)) return rc;
+	if(!W.done) HIP_TRY(hipEventCreateWithFlags(&W.done, hipEventDisableTiming));
+	if(W.used) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, W.done, 0));
+	A.hitT = dT; A.hitId = dTriId; A.selIn = dSel;   // the caller's hit records (Context::distance / object of the packets)
+	A.rOrg = W.rOrg; A.rDir = W.rDir; A.rIDir = W.rIDir; A.rMask = W.rMask; A.rDist = W.rDist; A.rObj = W.rObj;
+	A.rCol = dColor;                                  // the nested RayTrace's colours go straight to the caller
+	A.sDist = W.sDist; A.defer = W.defer;
+	const hipStream_t st = (hipStream_t)stream;
+	hipLaunchKernelGGL((dev::k_final<dev::SRC_PRIMARY, dev::DST_CONTINUE>), dim3(blocks), dim3(64), 0, st, A);
+	HIP_TRY(hipGetLastError());
+	if(int rc = launchRays(s, false, nPackets, 64, 0, W.rOrg, W.rDir, W.rIDir, W.rMask, W.rDist, W.rObj, nullptr, dStats, st)) return rc;
+	launchLights<dev::SRC_MIRROR>(s, A, st);
+	hipLaunchKernelGGL((dev::k_final<dev::SRC_MIRROR, dev::DST_COLOR>), dim3(blocks), dim3(64), 0, st, A);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(W.done, st));
+	W.used = true;
+	return 0;
 }
 
 int snail_shade_depth_dev(const float *t, int nPackets, uint8_t *bgr, void *stream) {

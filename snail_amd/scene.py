@@ -335,6 +335,24 @@ class Scene:
         _lib.check(rc, "snail_render_whitted_packets_dev")
         return out
 
+    def trace_transparency(self, cam: Camera, resx: int, resy: int, packet_xy, t_packets, tri_id_packets, sel, lights7, ambient=(0.1, 0.1, 0.1),
+                           color=(1.0, 1.0, 1.0), out=None, stats=None, stream=None):
+        """Scene::TraceTransparency (src/scene_trace.cpp:620-634) for the listed primary packets: their rays continued behind the hits for
+        the lanes of `sel` (uint8 [n, 64], the reference's transSel) and shaded by the nested RayTrace; returns the colours
+        [n, 256, 3] float32 (`transColor`).  snail_trace_transparency_dev."""
+        torch = _torch()
+        n = int(packet_xy.shape[0])
+        if out is None:
+            out = torch.zeros((n, 256, 3), dtype=torch.float32, device=self._dev())
+        lights = np.ascontiguousarray(lights7, dtype=np.float32).reshape(-1, 7)
+        cam13 = np.ascontiguousarray(cam.as_array13(), dtype=np.float32)
+        amb = np.ascontiguousarray(ambient, dtype=np.float32); col = np.ascontiguousarray(color, dtype=np.float32)
+        rc = _lib.lib().snail_trace_transparency_dev(self._h, _lib.ptr(cam13), resx, resy, _lib.ptr(packet_xy), n, _lib.ptr(t_packets), _lib.ptr(tri_id_packets),
+                                                     _lib.ptr(sel), _lib.ptr(lights), len(lights), _lib.ptr(amb), _lib.ptr(col), _lib.ptr(out), _lib.ptr(stats),
+                                                     _stream_ptr(stream))
+        _lib.check(rc, "snail_trace_transparency_dev")
+        return out
+
     def trace_primary_host(self, cam: Camera, resx: int, resy: int, rect=None):
         """Host-buffer entry point (what a C++ host would call): numpy planes in, numpy planes out."""
         x0, y0, w, h = rect if rect is not None else (0, 0, resx, resy)

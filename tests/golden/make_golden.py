@@ -180,6 +180,17 @@ def oracle_whitted():
     print("oracle_whitted_refl.json written")
 
 
+def oracle_transparency():
+    name, resx, resy = "atrium:0.05", 320, 192
+    tv, hb, osc = util.scene_pair(name)
+    cam = util.camera_for(name, tv)
+    xy, tp, ip, sel, lights = util.transparency_case(osc, cam, resx, resy, 5)
+    out, st = osc.trace_transparency(cam.as_array13(), resx, resy, xy, tp, sel, lights)
+    json.dump({"scene": name, "res": [resx, resy], "seed": 5, "sha_color": hashlib.sha256(out.tobytes()).hexdigest(), "stats": [int(x) for x in st]},
+              open(os.path.join(HERE, "oracle_transparency.json"), "w"), indent=1)
+    print("oracle_transparency.json", st)
+
+
 if __name__ == "__main__":
     veclib_prims()
     veclib_exprs()
@@ -187,3 +198,4 @@ if __name__ == "__main__":
     oracle_frames()
     oracle_packets()
     oracle_whitted()
+    oracle_transparency()

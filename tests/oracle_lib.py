@@ -50,6 +50,7 @@ def lib():
         L.orc_planar_decode_tile.argtypes = [vp, i32, i32, i32, i32, vp, i32]
         L.orc_render_whitted.argtypes = [vp, vp, vp, i32, i32, vp, i32, vp, vp, i32, vp, i32, u64p, i32, i32]
         L.orc_veclib_exprs.argtypes = [vp, vp, i32]
+        L.orc_trace_transparency.argtypes = [vp, vp, vp, i32, i32, vp, i32, vp, vp, vp, i32, vp, vp, vp, u64p, i32]
         for f in (L.orc_inv, L.orc_rsqrt):
             f.argtypes = [C.c_float, i32]
             f.restype = C.c_float
@@ -118,6 +119,18 @@ class OracleScene:
         lib().orc_render_whitted(_p(self.nodes), _p(self.tris), _p(cam), resx, resy, _p(lights), len(lights), _p(amb), _p(col), 1 if reflections else 0, _p(frame), resx * 3,
                                  _p(stats), mode, threads)
         return frame, stats
+
+    def trace_transparency(self, cam13, resx, resy, packet_xy, t_packets, sel, lights7, ambient=(0.1, 0.1, 0.1), color=(1.0, 1.0, 1.0), mode=MODE_IEEE):
+        cam = np.ascontiguousarray(cam13, dtype=np.float32)
+        xy = np.ascontiguousarray(packet_xy, dtype=np.int32).reshape(-1, 2)
+        lights = np.ascontiguousarray(lights7, dtype=np.float32).reshape(-1, 7)
+        amb = np.asarray(ambient, dtype=np.float32); col = np.asarray(color, dtype=np.float32)
+        t = np.ascontiguousarray(t_packets, dtype=np.float32); s = np.ascontiguousarray(sel, dtype=np.uint8)
+        out = np.zeros((len(xy), 256, 3), dtype=np.float32)
+        stats = np.zeros(4, dtype=np.uint64)
+        lib().orc_trace_transparency(_p(self.nodes), _p(self.tris), _p(cam), resx, resy, _p(xy), len(xy), _p(t), _p(s), _p(lights), len(lights), _p(amb), _p(col),
+                                     _p(out), _p(stats), mode)
+        return out, stats
 
     def trace_rays(self, origin, dir, idir, mask, distance, obj, bary, npackets, size, shared, mode=MODE_IEEE):
         stats = np.zeros(4, dtype=np.uint64)

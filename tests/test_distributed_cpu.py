@@ -20,16 +20,7 @@ def _free_port():
     return p
 
 
-def frame_to_packets(plane, xy):
-    """numpy [resy,resx] -> packet-major [n,256] in the reference's quad order (pixels outside the image = 0)."""
-    resy, resx = plane.shape
-    out = np.zeros((len(xy), 256), dtype=plane.dtype)
-    for i, (x, y) in enumerate(xy.tolist()):
-        blk = np.zeros((16, 16), dtype=plane.dtype)
-        h, w = min(16, resy - y), min(16, resx - x)
-        blk[:h, :w] = plane[y:y + h, x:x + w]
-        out[i] = blk.reshape(-1)          # row ty, then 4 quads of 4 pixels = row-major 16x16
-    return out
+from tests.util import frame_to_packets  # noqa: E402
 
 
 def packets_to_frame(planes, xy, frame):

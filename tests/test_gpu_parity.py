@@ -367,6 +367,32 @@ def test_config3_full_size_frame_byte_exact(torch_mod, refl):
     sc.close()
 
 
+@pytest.mark.parametrize("name,resx,resy,nl", [("atrium:0.05", 320, 192, 1), ("atrium:0.05", 250, 130, 0), ("box", 64, 64, 1), ("stress:0.05", 160, 96, 1)])
+def test_transparency_stage_bit_exact(torch_mod, name, resx, resy, nl):
+    """Scene::TraceTransparency (src/scene_trace.cpp:620-634) staged on the device: continuation rays behind the hits of the caller's
+    selector lanes, RayGroup<0,1> through the nested RayTrace -- colours (float) and TreeStats counters bit-identical to the oracle's
+    restatement, and to the committed digest of the first case."""
+    import hashlib
+    import json
+    tv, sc, osc = gpu_scene(name)
+    cam = util.camera_for(name, tv)
+    xy, tp, ip, sel, lights = util.transparency_case(osc, cam, resx, resy, 5)
+    lights = lights[:nl]
+    want, wst = osc.trace_transparency(cam.as_array13(), resx, resy, xy, tp, sel, lights)
+    dev = lambda a: torch_mod.from_numpy(np.ascontiguousarray(a)).cuda()
+    stats = sc.new_stats()
+    got = sc.trace_transparency(cam, resx, resy, dev(xy), dev(tp), dev(ip), dev(sel), lights, stats=stats)
+    torch_mod.cuda.synchronize()
+    util.assert_bit_equal(got.cpu().numpy(), want, "transColor")
+    assert np.array_equal(stats.cpu().numpy().astype(np.uint64), wst), (stats.cpu().numpy(), wst)
+    on = ((sel[:, :, None] >> np.arange(4)[None, None, :]) & 1).astype(bool).reshape(len(xy), 256) & np.isfinite(tp)
+    assert wst[2] >= on.sum() > 0 and (want[~on] == 0).all()          # unselected lanes: no ray, black
+    if name == "atrium:0.05" and nl == 1:
+        g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_transparency.json")))
+        assert hashlib.sha256(got.cpu().numpy().tobytes()).hexdigest() == g["sha_color"] and [int(x) for x in wst] == g["stats"]
+    sc.close()
+
+
 def test_invalid_arguments_fail_loudly(torch_mod):
     from snail_amd import SnailError
     name = "box"

@@ -114,3 +114,35 @@ def shadow_packets(oscene, n_packets, seed, size=64):
         dist[2 * size:3 * size] = -np.inf      # fully masked packet
     idir = (np.float32(1.0) / (dirs + np.float32(0.00000001))).astype(np.float32)
     return origin, dirs, idir, dist
+
+
+def frame_to_packets(plane, xy):
+    """numpy [resy,resx] -> packet-major [n,256] in the reference's quad order (pixels outside the image = 0)."""
+    resy, resx = plane.shape
+    out = np.zeros((len(xy), 256), dtype=plane.dtype)
+    for i, (x, y) in enumerate(np.asarray(xy).tolist()):
+        blk = np.zeros((16, 16), dtype=plane.dtype)
+        h, w = min(16, resy - y), min(16, resx - x)
+        blk[:h, :w] = plane[y:y + h, x:x + w]
+        out[i] = blk.reshape(-1)          # row ty, then 4 quads of 4 pixels = row-major 16x16
+    return out
+
+
+def transparency_case(osc, cam, resx, resy, seed):
+    """Inputs of a Scene::TraceTransparency call as the reference's RayTrace makes it (src/scene_trace.cpp:468-477): the packets of a frame,
+    their hit distances and triangle ids, a seeded selector (random lane sets, some packets fully selected -- the RayGroup<0,0> branch of
+    :631 --, some not at all) and one light."""
+    t, u, v, tid, _ = osc.render_primary(cam.as_array13(), resx, resy, mode=O.MODE_IEEE)
+    xy = np.array([(x, y) for y in range(0, resy, 16) for x in range(0, resx, 16)], dtype=np.int32)
+    tp, ip = frame_to_packets(t, xy), frame_to_packets(tid, xy)
+    if resx % 16 or resy % 16:      # rays of edge packets outside the image: a miss, as the device hands them back
+        inside = frame_to_packets(np.ones_like(t), xy) > 0
+        tp[~inside] = np.inf
+    rng = np.random.RandomState(seed)
+    sel = rng.randint(0, 16, size=(len(xy), 64)).astype(np.uint8)
+    sel[::3] = 15
+    sel[1::7] = 0
+    bmin, bmax = osc.nodes[0]["bmin"], osc.nodes[0]["bmax"]
+    c, e = (bmin + bmax) * 0.5, (bmax - bmin)
+    lights = np.array([[c[0], c[1] + 0.35 * e[1], c[2], 1.0, 0.9, 0.8, 2.0 * float(e.max())]], dtype=np.float32)
+    return xy, tp, ip, sel, lights
