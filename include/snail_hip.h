@@ -17,7 +17,7 @@
  * scene's device and return after the results are in the host buffers.
  *
  * Concurrency: a SnailScene may be used from several HIP streams at once -- launches keep their per-launch scratch (deferred-packet
- * lists, the staged shading intermediates) in 16 round-robin slots guarded by events, so a slot's next user waits, on the device,
+ * lists, the staged shading intermediates) in 8 round-robin slots guarded by events, so a slot's next user waits, on the device,
  * for its previous one -- but the handle is not thread-safe: make the calls on one scene from one host thread at a time.
  * snail_last_error() is per host thread.
  *

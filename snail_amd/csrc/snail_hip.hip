@@ -758,9 +758,38 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 //   topw = the stack word (node | first << 20 | last << 26) of the top entry, kept in an SGPR: one lane read per pop as before
 #define SNAIL_MOV_REC(D0, D1, D2, D3, S0, S1, S2, S3)                                                                                       \
 	" s_mov_b64 " D0 ", " S0 "\n s_mov_b64 " D1 ", " S1 "\n s_mov_b64 " D2 ", " S2 "\n s_mov_b64 " D3 ", " S3 "\n"
-#define SNAIL_C_FROM_T SNAIL_MOV_REC("s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]", "s[68:69]", "s[70:71]", "s[72:73]", "s[74:75]")
-#define SNAIL_C_FROM_N SNAIL_MOV_REC("s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]", "s[76:77]", "s[78:79]", "s[80:81]", "s[82:83]")
-#define SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, NX, FX, NY, FY, NZ, FZ)                                                   \
+#define SNAIL_A_FROM_T SNAIL_MOV_REC("s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]", "s[68:69]", "s[70:71]", "s[72:73]", "s[74:75]")
+// One visit of the loop with the tested record in register set X (planes NX..FZ, SUB = subNode | leaf bit, AUX) and the near child
+// requested into the OTHER set: a descent is a jump to the other copy of the body, not a copy of eight registers.  Inside the
+// body EXEC = the lanes that survived the node (a lane that fails a box fails every box inside it -- each operation of the slab test
+// rounds monotonically -- so first / last come out as with the whole range); a pop rebuilds EXEC from the popped range.
+#define SNAIL_PF_VISIT(X, Y, OTHERSET, SUB, AUX, PRE, SLAB, TAIL, CNTVISIT, NX, FX, NY, FY, NZ, FZ)                                          \
+				 "L_visit" X "_%=:\n" CNTVISIT                                                                                              \
+				 " s_lshr_b32 %[cur], %[sign16], " AUX "\n s_xor_b32 %[cur], %[cur], " AUX "\n s_bfe_u32 %[cur], %[cur], 0x10010\n"         \
+				 " s_add_u32 %[fl], " SUB ", 1\n s_sub_u32 %[fl], %[fl], %[cur]\n" /* far child */                                          \
+				 " s_add_u32 %[cur], " SUB ", %[cur]\n" /* near child */                                                                    \
+				 " s_cmp_lt_i32 " SUB ", 0\n s_cselect_b32 %[cur], 0, %[cur]\n s_lshl_b32 %[off], %[cur], 5\n"                               \
+				 " s_load_dwordx8 " OTHERSET ", %[base], %[off]\n"                                                                         \
+				 PRE(NX, FX, NY, FY, NZ, FZ)                                                                                               \
+				 SLAB("0", NX, FX, NY, FY, NZ, FZ) TAIL("0", "s0") SLAB("1", NX, FX, NY, FY, NZ, FZ) TAIL("1", "s1")                       \
+				 SLAB("2", NX, FX, NY, FY, NZ, FZ) TAIL("2", "s2") SLAB("3", NX, FX, NY, FY, NZ, FZ) TAIL("3", "s3")                       \
+				 " v_max_f32 %[s2], %[s2], %[s3]\n v_max3_f32 %[s0], %[s0], %[s1], %[s2]\n"                                                \
+				 " v_cmp_le_f32 vcc, 0, %[s0]\n"                                                                                           \
+				 " s_and_b64 %[alive], vcc, exec\n s_cbranch_scc0 L_fail_%=\n"                                                             \
+				 " s_ff1_i32_b64 %[first], %[alive]\n s_flbit_i32_b64 %[last], %[alive]\n s_xor_b32 %[last], %[last], 63\n"                \
+				 " s_mov_b64 exec, %[alive]\n"                                                                                             \
+				 " s_cmp_lt_i32 " SUB ", 0\n s_cbranch_scc1 L_leaf" X "_%=\n"                                                               \
+				 " s_lshl_b32 %[off], %[last], 6\n s_or_b32 %[off], %[off], %[first]\n s_lshl_b32 %[off], %[off], 20\n"                    \
+				 " s_or_b32 %[topw], %[off], %[fl]\n"                                                                                      \
+				 " s_mov_b32 m0, %[sp]\n v_writelane_b32 %[stkN], %[topw], m0\n"                                                           \
+				 " s_add_u32 %[sp], %[sp], 1\n"                                                                                            \
+				 " s_lshl_b32 %[off], %[fl], 5\n"                                                                                          \
+				 " s_waitcnt lgkmcnt(0)\n"                                                                                                 \
+				 " s_load_dwordx8 s[68:75], %[base], %[off]\n" /* the far child is the new top entry */                                    \
+				 " s_branch L_visit" Y "_%=\n"                                                                                              \
+				 "L_leaf" X "_%=:\n s_mov_b32 %[leafSub], " SUB "\n s_mov_b32 %[leafAux], " AUX "\n s_waitcnt lgkmcnt(0)\n s_branch L_end_%=\n"
+// set A = s[84:91] (planes NXA.., sub s90, aux s91), set B = s[76:83] (planes NXB.., sub s82, aux s83)
+#define SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)                 \
 	asm volatile("L_entry_%=:\n"                                                                                                           \
 				 " s_cmp_eq_u32 %[sp], 0\n s_cbranch_scc1 L_done_%=\n"                                                                     \
 				 " s_sub_u32 %[off], %[sp], 1\n"                                                                                           \
@@ -776,40 +805,16 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 " s_sub_u32 %[off], %[sp], 1\n"                                                                                           \
 				 " v_readlane_b32 %[topw], %[stkN], %[off]\n"                                                                              \
 				 " s_and_b32 %[cur], %[topw], 0xfffff\n s_lshl_b32 %[off], %[cur], 5\n"                                                    \
-				 " s_waitcnt lgkmcnt(0)\n" SNAIL_C_FROM_T                                                                                  \
+				 " s_waitcnt lgkmcnt(0)\n" SNAIL_A_FROM_T                                                                                  \
 				 " s_load_dwordx8 s[68:75], %[base], %[off]\n" /* the new top entry's record */                                            \
-				 " s_branch L_visit_%=\n"                                                                                                  \
+				 " s_branch L_visitA_%=\n"                                                                                                 \
 				 "L_last_%=:\n"                                                                                                            \
-				 " s_waitcnt lgkmcnt(0)\n" SNAIL_C_FROM_T                                                                                  \
-				 "L_visit_%=:\n" CNTVISIT                                                                                                  \
-				 " s_lshr_b32 %[cur], %[sign16], s91\n s_xor_b32 %[cur], %[cur], s91\n s_bfe_u32 %[cur], %[cur], 0x10010\n"                \
-				 " s_add_u32 %[fl], s90, 1\n s_sub_u32 %[fl], %[fl], %[cur]\n" /* far child */                                             \
-				 " s_add_u32 %[cur], s90, %[cur]\n" /* near child */                                                                       \
-				 " s_cmp_lt_i32 s90, 0\n s_cselect_b32 %[cur], 0, %[cur]\n s_lshl_b32 %[off], %[cur], 5\n"                                 \
-				 " s_load_dwordx8 s[76:83], %[base], %[off]\n"                                                                             \
-				 PRE(NX, FX, NY, FY, NZ, FZ)                                                                                               \
-				 SLAB("0", NX, FX, NY, FY, NZ, FZ) TAIL("0", "s0") SLAB("1", NX, FX, NY, FY, NZ, FZ) TAIL("1", "s1")                       \
-				 SLAB("2", NX, FX, NY, FY, NZ, FZ) TAIL("2", "s2") SLAB("3", NX, FX, NY, FY, NZ, FZ) TAIL("3", "s3")                       \
-				 " v_max_f32 %[s2], %[s2], %[s3]\n v_max3_f32 %[s0], %[s0], %[s1], %[s2]\n"                                                \
-				 " v_cmp_le_f32 vcc, 0, %[s0]\n"                                                                                           \
-				 " s_and_b64 %[alive], vcc, exec\n s_cbranch_scc0 L_fail_%=\n"                                                             \
-				 " s_ff1_i32_b64 %[first], %[alive]\n s_flbit_i32_b64 %[last], %[alive]\n s_xor_b32 %[last], %[last], 63\n"                \
-				 " s_sub_u32 %[width], %[last], %[first]\n"                                                                                \
-				 " s_bfm_b64 exec, %[width], %[first]\n s_bitset1_b64 exec, %[last]\n"                                                     \
-				 " s_cmp_lt_i32 s90, 0\n s_cbranch_scc1 L_leaf_%=\n"                                                                       \
-				 " s_lshl_b32 %[off], %[last], 6\n s_or_b32 %[off], %[off], %[first]\n s_lshl_b32 %[off], %[off], 20\n"                    \
-				 " s_or_b32 %[topw], %[off], %[fl]\n"                                                                                      \
-				 " s_mov_b32 m0, %[sp]\n v_writelane_b32 %[stkN], %[topw], m0\n"                                                           \
-				 " s_add_u32 %[sp], %[sp], 1\n"                                                                                            \
-				 " s_lshl_b32 %[off], %[fl], 5\n"                                                                                          \
-				 " s_waitcnt lgkmcnt(0)\n" SNAIL_C_FROM_N                                                                                  \
-				 " s_load_dwordx8 s[68:75], %[base], %[off]\n" /* the far child is the new top entry */                                    \
-				 " s_branch L_visit_%=\n"                                                                                                  \
+				 " s_waitcnt lgkmcnt(0)\n" SNAIL_A_FROM_T                                                                                  \
+				 SNAIL_PF_VISIT("A", "B", "s[76:83]", "s90", "s91", PRE, SLAB, TAIL, CNTVISIT, NXA, FXA, NYA, FYA, NZA, FZA)                \
+				 SNAIL_PF_VISIT("B", "A", "s[84:91]", "s82", "s83", PRE, SLAB, TAIL, CNTVISIT, NXB, FXB, NYB, FYB, NZB, FZB)                \
 				 "L_fail_%=:\n"                                                                                                            \
 				 " s_cmp_eq_u32 %[sp], 0\n s_cbranch_scc0 L_pop_%=\n"                                                                      \
-				 " s_branch L_done_%=\n"                                                                                                   \
-				 "L_leaf_%=:\n s_mov_b32 %[leafSub], s90\n s_mov_b32 %[leafAux], s91\n s_waitcnt lgkmcnt(0)\n s_branch L_end_%=\n"        \
-				 "L_done_%=:\n s_mov_b32 %[leafSub], 0\n s_mov_b32 %[leafAux], 0\n s_waitcnt lgkmcnt(0)\n"                                \
+				 "L_done_%=:\n s_mov_b32 %[leafSub], 0\n s_mov_b32 %[leafAux], 0\n s_waitcnt lgkmcnt(0)\n"                                  \
 				 "L_end_%=:\n s_mov_b64 exec, -1\n"                                                                                        \
 				 : [sp] "+s"(sp), [first] "+s"(first), [last] "+s"(last), [cnt] "+s"(cnt), [stkN] "+v"(stkN), [stkF] "+v"(stkF),           \
 				   [leafSub] "=&s"(leafSub), [leafAux] "=&s"(leafAux), [cur] "=&s"(sCur), [fl] "=&s"(sFl), [off] "=&s"(sOff),              \
@@ -826,16 +831,18 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 	asm volatile("" ::"s"(sp), "s"(first), "s"(last), "s"(cnt), "v"(stkN), "v"(stkF), "s"(leafSub), "s"(leafAux), "s"(sCur), "s"(sFl), "s"(sOff),    \
 				 "s"(sWidth), "s"(sTopw), "s"(sAlive), "v"(vt[0]), "v"(vt[1]), "v"(vt[2]), "v"(vt[3]), "v"(vt[4]), "v"(vt[5]), "v"(vt[6]), "v"(vt[7]), \
 				 "v"(vt[8]), "v"(vt[9]), "v"(vt[10]), "v"(vt[11]), "v"(vt[12]), "v"(vt[13]), "v"(vt[14]), "v"(vt[15]), "v"(vt[16]))
+#define SNAIL_DESCEND_PF_PLAIN(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT)                                                                     \
+	SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s85", "s88", "s86", "s89", "s76", "s79", "s77", "s80", "s78", "s81")
 #define SNAIL_DESCEND_PF_OCT(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, OCT)                                                                \
 	switch(OCT) {                                                                                                                          \
-	case 0: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s85", "s88", "s86", "s89"); break;                  \
-	case 1: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s85", "s88", "s86", "s89"); break;                  \
-	case 2: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s88", "s85", "s86", "s89"); break;                  \
-	case 3: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s88", "s85", "s86", "s89"); break;                  \
-	case 4: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s85", "s88", "s89", "s86"); break;                  \
-	case 5: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s85", "s88", "s89", "s86"); break;                  \
-	case 6: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s88", "s85", "s89", "s86"); break;                  \
-	default: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s88", "s85", "s89", "s86"); break;                 \
+	case 0: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s85", "s88", "s86", "s89", "s76", "s79", "s77", "s80", "s78", "s81"); break; \
+	case 1: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s85", "s88", "s86", "s89", "s79", "s76", "s77", "s80", "s78", "s81"); break; \
+	case 2: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s88", "s85", "s86", "s89", "s76", "s79", "s80", "s77", "s78", "s81"); break; \
+	case 3: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s88", "s85", "s86", "s89", "s79", "s76", "s80", "s77", "s78", "s81"); break; \
+	case 4: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s85", "s88", "s89", "s86", "s76", "s79", "s77", "s80", "s81", "s78"); break; \
+	case 5: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s85", "s88", "s89", "s86", "s79", "s76", "s77", "s80", "s81", "s78"); break; \
+	case 6: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s88", "s85", "s89", "s86", "s76", "s79", "s80", "s77", "s81", "s78"); break; \
+	default: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s88", "s85", "s89", "s86", "s79", "s76", "s80", "s77", "s81", "s78"); break; \
 	}
 
 // near/far plane registers by sign octant (bit k set = idir negative on axis k: near plane = bmax[k]); s[84:86] = bmin, s[87:89] = bmax
@@ -921,9 +928,9 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes, c
 				else if(POSDIST) { SNAIL_DESCEND_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_POS, SNAIL_COUNT, "", oct) }
 				else { SNAIL_DESCEND_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_ANY, SNAIL_COUNT, "", oct) }
 			} else {
-				if(SHADOW) { SNAIL_DESCEND_PF(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, "", SNAIL_COUNT, "s84", "s87", "s85", "s88", "s86", "s89"); }
-				else if(POSDIST) { SNAIL_DESCEND_PF(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_POS, SNAIL_COUNT, "", "s84", "s87", "s85", "s88", "s86", "s89"); }
-				else { SNAIL_DESCEND_PF(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, "", "s84", "s87", "s85", "s88", "s86", "s89"); }
+				if(SHADOW) { SNAIL_DESCEND_PF_PLAIN(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, "", SNAIL_COUNT); }
+				else if(POSDIST) { SNAIL_DESCEND_PF_PLAIN(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_POS, SNAIL_COUNT, ""); }
+				else { SNAIL_DESCEND_PF_PLAIN(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, ""); }
 			}
 		} else if(PACK) { SNAIL_SHARED_VARIANTS(SNAIL_POP_1W, SNAIL_PUSH_1W) }
 		else { SNAIL_SHARED_VARIANTS(SNAIL_POP_2W, SNAIL_PUSH_2W) }
@@ -2094,7 +2101,7 @@ struct SnailScene {
 	int fastOK = 0; // every triangle record finite and of sane magnitude (see file header)
 	int lastBlocks = 0, lastThreads = 0;
 	unsigned long long *dStats = nullptr; // 4 x u64 scratch for the host-pointer entry points
-	enum { kDeferSlots = 16 };
+	enum { kDeferSlots = 8 };
 	int *dDefer[kDeferSlots] = {};        // deferred-packet lists, one per launch in flight (round-robin)
 	// a slot's buffers are reused by the 8th launch after it, possibly on another stream and possibly while the host runs far
 	// ahead of the device: each slot carries an event recorded after its last kernel, and the next user's stream waits for it

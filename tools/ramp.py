@@ -1,0 +1,33 @@
+"""How the frame rate develops from an idle GPU: after `idle` seconds without work, 600 pipelined frames with a HIP event after every
+10th; prints ms per frame for each chunk of 10 (on the event's stream: coarse, but the trend is what matters) and the GPU clock that
+rocm-smi reports before / after.  Usage: python tools/ramp.py [idle_seconds]"""
+import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from snail_amd import HostBVH, scenes, FPSCamera
+from snail_amd.render import DistributedRenderer
+from snail_amd.scene import Scene
+idle = float(sys.argv[1]) if len(sys.argv) > 1 else 0.5
+tv = scenes.scene_by_name("atrium"); h = HostBVH.build(tv)
+cam = FPSCamera(*scenes.atrium_camera()).camera()
+sc = Scene(h, 0)
+rnd = DistributedRenderer(sc, 1920, 1080, 0, 1)
+for _ in range(40): rnd.render(cam)
+rnd.flush(); torch.cuda.synchronize()
+for rep in range(2):
+    time.sleep(idle)
+    N, step = 600, 10
+    marks = []
+    t0 = time.perf_counter()
+    e0 = torch.cuda.Event(enable_timing=True); e0.record(rnd.streams[0])
+    for i in range(N):
+        rnd.render(cam)
+        if (i + 1) % step == 0:
+            e = torch.cuda.Event(enable_timing=True); e.record(rnd.streams[i % rnd.nslots]); marks.append(e)
+    rnd.flush(); torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ts = [e0.elapsed_time(e) for e in marks]
+    per = [(ts[k] - (ts[k - 1] if k else 0.0)) / step for k in range(len(ts))]
+    print("rep %d (after %.1f s idle): wall %.3f ms/frame; ms/frame per chunk of %d frames:" % (rep, idle, wall * 1e3 / N, step))
+    print("  " + " ".join("%.3f" % x for x in per))
