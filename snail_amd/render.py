@@ -325,8 +325,26 @@ class DistributedRenderer:
                 if events: events[1].record(st)
             self.frame = out
             return out
+        # the collective runs on the CURRENT stream: make the slot's stream current for the rest of the call.  (torch.cuda.stream(st) as
+        # a context manager costs the host ~16 us per frame -- it looks the device up through is_available() twice -- of the ~45 us a frame
+        # costs it on this route, tools/host_profile.py; at 4-8 ranks the host's issue rate is what bounds the frame rate.)
+        try:
+            prev = torch._C._cuda_getCurrentStream(st.device_index)      # (stream_id, device_index, device_type) of the caller's stream
+            set_raw = torch._C._cuda_setStream
+        except AttributeError:                                           # another torch build: the documented (slower) way
+            with torch.cuda.stream(st):
+                return self._render_multi(cam, stats, events, slot, st)
+        set_raw(stream_id=st.stream_id, device_index=st.device_index, device_type=st.device_type)
+        try:
+            return self._render_multi(cam, stats, events, slot, st)
+        finally:
+            set_raw(stream_id=prev[0], device_index=prev[1], device_type=prev[2])
+
+    def _render_multi(self, cam, stats, events, slot, st):
+        torch = self.torch
         import torch.distributed as dist
-        with torch.cuda.stream(st):
+        sc, p = self.scene, self.plan
+        if True:
             self._finish(slot)                       # the slot's buffers are free again after this
             if events: events[0].record(st)
             if self.payload == "hits":
