@@ -946,19 +946,28 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes, c
 
 // closest hit of a packet with per-ray origins (TraversePrimaryN<0,mask>), node loop in assembly as in walkSharedAsm; any
 // distance on entry (masked lanes -inf), `size` quads
-template <bool MASK, bool COH, bool BARY>
+template <bool MASK, bool COH, bool BARY, bool PACK>
 __device__ __forceinline__ void walkPerRayAsm(const uint4 *__restrict__ nodes, const uint4 *__restrict__ tris, int size, int lane, const float (&org)[3][4],
 											  Quad &Q, unsigned mask4, int (&tid)[4], float (&bu)[4], float (&bv)[4], Counters &st, const int oct) {
 	const int signBits = __builtin_amdgcn_readfirstlane((Q.d[0][0] < 0.0f ? 1 : 0) | (Q.d[1][0] < 0.0f ? 2 : 0) | (Q.d[2][0] < 0.0f ? 4 : 0));
 	const int sign16 = signBits << 16;
 	const u64 nodeBase = (u64)nodes;
-	int stkN = 0, stkF = (size - 1) << 8; // slot 0 = the root with the full quad range
+	int stkN = PACK ? (int)((unsigned)(size - 1) << 26) : 0, stkF = (size - 1) << 8; // slot 0 = the root with the full quad range
 	int sp = 1, first = 0, last = size - 1, cnt = 0;
 	for(;;) {
 		int leafSub, leafAux, sCur, sFl, sOff, sWidth;
 		u64 sRng, sAlive;
 		float vt[17];
-		if(COH) { SNAIL_DESCEND_OCT(SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_COH, SNAIL_TAIL_ANY, SNAIL_COUNT, "", oct) }
+		if(PACK && SNAIL_NODE_PREFETCH && !COH) {
+			// non-coherent packets (the heavy ones among the mirrored packets): one-word stack entries + node records fetched ahead.  The
+			// coherent form would need the prefetching loop once per sign octant, and this compiler cannot place eight (or even two)
+			// copies of it beside the per-ray leaf code ("illegal VGPR to SGPR copy": the scalar-register pressure of the 16-SGPR triangle
+			// record plus three node record sets); coherent packets keep the plain loop.
+			int sTopw;
+			SNAIL_DESCEND_PF_PLAIN(SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, "");
+		} else if(PACK && COH) { SNAIL_DESCEND_OCT_S(SNAIL_POP_1W, SNAIL_PUSH_1W, SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_COH, SNAIL_TAIL_ANY, SNAIL_COUNT, "", oct) }
+		else if(PACK) { SNAIL_DESCEND_ASM_S(SNAIL_POP_1W, SNAIL_PUSH_1W, SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, "", "s84", "s87", "s85", "s88", "s86", "s89"); }
+		else if(COH) { SNAIL_DESCEND_OCT(SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_COH, SNAIL_TAIL_ANY, SNAIL_COUNT, "", oct) }
 		else { SNAIL_DESCEND_ASM(SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, "", "s84", "s87", "s85", "s88", "s86", "s89"); }
 		if(leafSub == 0) break;
 		leafPerRay<MASK, COH ? M_COH : M_FAST, BARY>(tris, leafAux, (int)((unsigned)leafSub & 0x7fffffffu), lane, first, last, org, Q, mask4, tid, bu, bv, st);
@@ -1737,6 +1746,7 @@ __global__ __launch_bounds__(64) void k_final(ShadeArgs A) {
 struct RaysArgs {
 	const uint4 *nodes, *tris;
 	int nPackets, size, fastOK;
+	int pack; // at most 2^20 node slots: one-word stack entries + record prefetch in the per-ray-origin walk
 	const float *origin, *dir, *idir;
 	const unsigned char *mask;
 	float *distance;
@@ -1792,8 +1802,11 @@ __device__ __forceinline__ void raysPacket(const RaysArgs &A, const int p, float
 			return;
 		}
 		if(!SHARED && !DEEP) { // per-ray origins: the hand-written node loop
-			if(mode == M_COH) walkPerRayAsm<MASK, true, BARY>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, st, oct);
-			else walkPerRayAsm<MASK, false, BARY>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, st, 0);
+			if(A.pack) {
+				if(mode == M_COH) walkPerRayAsm<MASK, true, BARY, true>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, st, oct);
+				else walkPerRayAsm<MASK, false, BARY, true>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, st, 0);
+			} else if(mode == M_COH) walkPerRayAsm<MASK, true, BARY, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, st, oct);
+			else walkPerRayAsm<MASK, false, BARY, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, st, 0);
 		} else if(SHARED && !DEEP) { // shared origin, any distances on entry
 			if(mode == M_COH) walkSharedAsm<false, true, false, MASK, BARY, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, lds, st, oct);
 			else walkSharedAsm<false, false, false, MASK, BARY, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, lds, st, 0);
@@ -2314,7 +2327,7 @@ int launchRays(SnailScene *s, bool shadow, int nPackets, int size, int sharedOri
 	dev::RaysArgs A;
 	memset(&A, 0, sizeof(A));
 	A.nodes = s->dNodes; A.tris = s->dTris;
-	A.nPackets = nPackets; A.size = size; A.fastOK = s->fastOK;
+	A.nPackets = nPackets; A.size = size; A.fastOK = s->fastOK; A.pack = stackPack(s);
 	A.origin = origin; A.dir = dir; A.idir = idir; A.mask = mask;
 	A.distance = distance; A.object = object; A.bary = bary;
 	A.stats = (dev::u64 *)dStats;
