@@ -74,21 +74,11 @@ inline void TraceFrame(SnailScene *scene, const CameraT &cam, int resx, int resy
 						 cam.front.x, cam.front.y, cam.front.z, cam.plane_dist};
 	out.resx = resx; out.resy = resy;
 	out.pw = (resx + 15) / 16; out.ph = (resy + 15) / 16;
-	// rays of edge packets that fall outside the image are traced on the device (they are part of their
-	// packet, src/render.cpp:67-68) but never stored by the reference; they are handed back as misses
-	std::vector<float> rt((size_t)resx * resy), ru((size_t)resx * resy), rv((size_t)resx * resy);
-	std::vector<int32_t> ri((size_t)resx * resy);
-	out.stats[0] = out.stats[1] = out.stats[2] = out.stats[3] = 0;
-	SNAIL_CHECK(snail_trace_primary(scene, c, resx, resy, 0, 0, resx, resy, rt.data(), ru.data(), rv.data(), ri.data(), out.stats));
+	// ONE launch, outputs already in the reference's packet-major quad order (src/ray_generator.cpp:29-45): no per-pixel work on the CPU
 	const size_t np = (size_t)out.pw * out.ph;
-	out.t.assign(np * 256, 1.0f / 0.0f); out.u.assign(np * 256, 0.0f); out.v.assign(np * 256, 0.0f); out.triId.assign(np * 256, 0);
-	for(int y = 0; y < resy; y++)
-		for(int x = 0; x < resx; x++) {
-			// quad ty*4+k, lane j  <->  pixel (px + 4k + j, py + ty)   (src/ray_generator.cpp:29-45)
-			const size_t p = out.packetIndex(x, y), q = (size_t)(y & 15) * 4 + (size_t)((x & 15) >> 2), l = (size_t)(x & 3);
-			const size_t d = p * 256 + q * 4 + l, s = (size_t)y * resx + x;
-			out.t[d] = rt[s]; out.u[d] = ru[s]; out.v[d] = rv[s]; out.triId[d] = ri[s];
-		}
+	out.t.resize(np * 256); out.u.resize(np * 256); out.v.resize(np * 256); out.triId.resize(np * 256);
+	out.stats[0] = out.stats[1] = out.stats[2] = out.stats[3] = 0;
+	SNAIL_CHECK(snail_trace_frame_packets(scene, c, resx, resy, out.t.data(), out.u.data(), out.v.data(), out.triId.data(), out.stats));
 }
 
 // A model of the AccStruct concept backed by libsnailhip.  `RefBVH` is the reference's `BVH`

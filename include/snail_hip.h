@@ -86,6 +86,14 @@ int snail_trace_primary(SnailScene *, const float cam[13], int resx, int resy, i
 int snail_trace_primary_dev(SnailScene *, const float cam[13], int resx, int resy, int x0, int y0, int w, int h,
                             float *d_t, float *d_u, float *d_v, int32_t *d_triId, uint64_t *d_stats, void *stream);
 
+/* The whole frame's primary packets with HOST outputs in PACKET-MAJOR order (packet (cx, cy) of the ceil(resx/16) x ceil(resy/16) grid at
+ * index cy * pw + cx; element [p*256 + q*4 + lane] in the reference's quad order): exactly the Context arrays a host's per-packet loop
+ * reads (src/ray_generator.cpp:29-45), so that no per-pixel re-layout is left to the CPU.  Rays of edge packets that fall outside the
+ * image carry what the walk found for them (they are part of their packet, src/render.cpp:67-68).  Buffers: pw * ph * 256 elements each;
+ * any of them may be NULL. */
+int snail_trace_frame_packets(SnailScene *, const float cam[13], int resx, int resy, float *t, float *u, float *v, int32_t *triId,
+                              uint64_t stats[4]);
+
 /* Same, for an explicit list of packets (tile sharding, src/render.cpp:244-267 / src/node.cpp:336-338):
  * d_packet_xy = nPackets x (x,y) top-left pixel.  Outputs are PACKET-MAJOR in the reference's quad
  * order (quad ty*4+k = pixels x+4k..x+4k+3 of row y+ty, src/ray_generator.cpp:29-45): element

@@ -33,6 +33,7 @@ SIGNATURES = {
     "snail_delay_dev": (_I, [C.c_float, _VP]),
     "snail_debug_dispatch_rate": (_I, [_I, _I, _I, _VP]),
     "snail_trace_primary": (_I, [_VP, _F13, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),
+    "snail_trace_frame_packets": (_I, [_VP, _F13, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "snail_trace_primary_dev": (_I, [_VP, _F13, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "snail_trace_packets_dev": (_I, [_VP, _F13, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "snail_trace_packets_shaded_dev": (_I, [_VP, _F13, _I, _I, _VP, _I, _VP, _VP, _VP]),
