@@ -393,6 +393,23 @@ def test_transparency_stage_bit_exact(torch_mod, name, resx, resy, nl):
     sc.close()
 
 
+@pytest.mark.parametrize("env", [{"SNAIL_DEBUG_NO_PACK": "1"}, {"SNAIL_DEBUG_FORCE_DEEP": "1"}, {"SNAIL_DEBUG_NO_PACK": "1", "SNAIL_DEBUG_FORCE_DEEP": "1"}])
+def test_walk_variants_selected_by_scene_size(torch_mod, env):
+    """The walks that the test scenes never select by themselves -- two-word stack entries without record prefetch (scenes of more than 2^20
+    node slots) and the second stack register pair (trees deeper than 62) -- forced through the library's debug switches in a child
+    process (tests/walk_variants_env.py): primary frame, light pipeline with the mirrored bounce, generic and shadow packets, all
+    bit-identical to the oracle."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "walk_variants_env.py")], capture_output=True, text=True, timeout=300, cwd=root,
+                       env=dict(os.environ, **env))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["primary"] and d["whitted_refl"] and d["rays"] and d["shadow"], d
+
+
 def test_invalid_arguments_fail_loudly(torch_mod):
     from snail_amd import SnailError
     name = "box"
