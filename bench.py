@@ -26,8 +26,13 @@ Mrays = rays launched (every lane of every traced packet, hit or miss), as TreeS
 (src/scene_trace.cpp:116-117): frames are padded to whole 16x16 packets (1920x1080 -> 1920x1088); config 3 adds the shadow
 lanes with N.L > 0 (:554-557).
 
-roofline (one denominator everywhere: the step time, i.e. whole-frame throughput with 4 frames in flight -- the per-launch HIP-event
-duration `kernel_ms` is reported too, but with four launches overlapping it is not a stand-alone time):
+Launches: frames are pipelined over 4 HIP streams, and `--frames-per-launch B` frames (default 2 at N = 1, 4 at N > 1, always 1 for config 3)
+share ONE launch -- the heaviest packets of all of them first, one tail and one set of launch overheads (and, at N > 1, one collective)
+for B frames; results are those of B single-frame launches.
+
+roofline (one denominator everywhere: the step time, i.e. whole-frame throughput -- the per-launch HIP-event duration `kernel_ms` is
+reported too, but with four launches overlapping it is not a stand-alone time; counters are per frame: the PMC passes profile one-frame
+launches):
   bound "valu_issue": what the profiles show binds this kernel -- the SIMDs' vector issue (one wave64 VALU instruction per 2 cycles
       per SIMD, 1024 SIMDs, 2.4 GHz = 1228.8 G wave-instructions/s).  achieved = VALU wave-instructions per launch (rocprofv3
       SQ_INSTS_VALU of this workload, profiles/traffic.json) / step time.  frac <= 1 by construction.
@@ -125,6 +130,7 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="frames in flight (HIP streams); 0 = the renderer's default (4); 1 = strictly serial frames")
     ap.add_argument("--event-every", type=int, default=8, help="bracket every n-th traversal launch with HIP events (roofline.kernel_ms)")
     ap.add_argument("--feedback-order", type=int, default=1, help="1 (default) = dispatch packets heaviest first by the node visits of an earlier frame (DistributedRenderer feedback_order)")
+    ap.add_argument("--frames-per-launch", type=int, default=0, help="trace this many frames (1..8) with one launch -- and, at N > 1, move them with one collective (DistributedRenderer frames_per_launch); 0 = 2 at N = 1, 4 at N > 1; config 3 always 1")
     ap.add_argument("--stagger", type=int, default=0, help="1 = de-phase the frame streams when the pipeline starts from idle (DistributedRenderer stagger; measured: no gain)")
     ap.add_argument("--lone-frames", type=int, default=12, help="N=1: frames traced one at a time after the timed region (lone_frame_ms); 0 = skip")
     args = ap.parse_args()
@@ -179,7 +185,8 @@ def main():
         c, e = (bmin + bmax) * 0.5, (bmax - bmin)
         lights7 = np.array([[c[0], c[1] + 0.35 * e[1], c[2], 1.0, 0.9, 0.8, 2.0 * float(e.max())]], dtype=np.float32)   # one point light above the nave
     rnd = DistributedRenderer(scene, resx, resy, rank, world, slots=args.streams if args.streams > 0 else None, stage_cpu=rehearsal,
-                              feedback_order=bool(args.feedback_order), lights7=lights7, rank0_share=args.rank0_share, stagger=bool(args.stagger))
+                              feedback_order=bool(args.feedback_order), lights7=lights7, rank0_share=args.rank0_share, stagger=bool(args.stagger),
+                              frames_per_launch=args.frames_per_launch if args.frames_per_launch > 0 else (2 if world == 1 else 4))
     primary_rays = rnd.rays_per_frame() if world > 1 else resx * ((resy + 15) // 16 * 16)
 
     def barrier():
@@ -248,17 +255,19 @@ def main():
         traffic = tr.get("bytes_per_launch") if tr else None
         roof = {"bound": "valu_issue", "achieved": round(valu / step_s / 1e9, 1) if valu else None, "peak": round(VALU_PEAK_GINST, 1), "unit": "Gwaveinst/s",
                 "frac": round(valu / step_s / 1e9 / VALU_PEAK_GINST, 4) if valu else None,
-                "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE)",
+                "traffic": traffic * rnd.batch if traffic else None,
+                "traffic_unit": "HBM bytes per launch of %d frame(s) (rocprofv3 PMC of a one-frame launch: 2 x FETCH_SIZE + WRITE_SIZE, x frames per launch)" % rnd.batch,
+                "frames_per_launch": rnd.batch, "traffic_bytes_per_frame": traffic,
                 "hbm_peak_GBs": HBM_PEAK_GBS, "hbm_frac_traffic": round(traffic / step_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-                "valu_insts_per_launch": valu, "counters_source": tr.get("source") if tr else "no PMC pass committed for workload key %s" % key,
-                "kernel": "dev::k_primary", "kernel_ms": round(kern_ms, 5), "kernel_ms_note": "HIP events around the launch on its own stream while %d frames are in flight: overlapped, not a stand-alone duration; every fraction here uses ms_per_step" % rnd.nslots,
+                "valu_insts_per_launch": valu * rnd.batch if valu else None, "valu_insts_per_frame": valu, "counters_source": tr.get("source") if tr else "no PMC pass committed for workload key %s" % key,
+                "kernel": "dev::k_primary", "kernel_ms": round(kern_ms, 5), "kernel_ms_note": "HIP events around one launch (%d frame(s)) on its own stream while %d launches are in flight: overlapped, not a stand-alone duration; every fraction here uses ms_per_step (per frame) and per-frame counters" % (rnd.batch, rnd.nslots),
                 "denominator_ms": round(ms_per_step, 5), "lone_frame_ms": round(lone_ms, 5) if lone_ms is not None else None}
         if pk is not None:
             visits, fetched = int(pk[:, 0].sum()), int(pk[:, 4].sum())
             pbytes = 32 * visits + 64 * fetched + 16 * 256 * len(pk)
-            roof.update({"packet_alg_bytes_per_launch": pbytes, "packet_node_visits": visits, "packet_tri_records_fetched": fetched,
+            roof.update({"packet_alg_bytes_per_launch": pbytes * rnd.batch, "packet_alg_bytes_per_frame": pbytes, "packet_node_visits": visits, "packet_tri_records_fetched": fetched,
                          "hbm_frac_packet_alg": round(pbytes / step_s / 1e9 / HBM_PEAK_GBS, 4),
-                         "compulsory_bytes_per_launch": 32 * hbvh.n_nodes + 64 * hbvh.n_tris + 16 * primary_rays})
+                         "compulsory_bytes_per_frame": 32 * hbvh.n_nodes + 64 * hbvh.n_tris + 16 * primary_rays})
         if acc is not None:
             b_alg = (32.0 * float(acc[1]) + 64.0 * float(acc[2])) / float(acc[0]) + 16.0
             roof.update({"alg_single_ray_bytes_per_ray": round(b_alg, 1),
@@ -282,7 +291,7 @@ def main():
                                                                                      ", sponza.obj stand-in" if scene_name.startswith("atrium") else "", resx, resy, cfg["what"]),
                        "baseline_config": args.config, "rays_per_step": total_rays, "primary_rays_per_step": primary_rays, "node_visits_per_step": node_visits,
                        "packets": "16x16 px = 1 wavefront", "bvh_nodes": hbvh.n_nodes, "bvh_depth": hbvh.depth,
-                       "bvh_build_s": round(build_s, 3), "hit_fraction": round(hit_frac, 5), "frames_in_flight": rnd.nslots,
+                       "bvh_build_s": round(build_s, 3), "hit_fraction": round(hit_frac, 5), "frames_in_flight": rnd.nslots * rnd.batch, "frames_per_launch": rnd.batch, "launches_in_flight": rnd.nslots,
                        "packet_order": "heaviest first (node visits of an earlier frame)" if rnd.feedback else "built-in region interleave",
                        "traversal_stack": "VGPR pair per wave (lane i = slot i), at most bvh_depth = %d slots; LDS 0 B/wave in the main kernel (3328 B/wave only in the deferred M_EXACT pass)" % hbvh.depth,
                        "packets_per_rank": [len(p) for p in rnd.plan.packets] if world > 1 else None,

@@ -122,6 +122,18 @@ int snail_trace_packets_ordered_dev(SnailScene *, const float cam[13], int resx,
                                     float *d_t, float *d_u, float *d_v, int32_t *d_triId, uint64_t *d_stats,
                                     const int32_t *d_order, int32_t *d_slot_cost, void *stream);
 int snail_order_from_cost_dev(const int32_t *d_slot_cost, int nSlots, int32_t *d_order, void *stream);
+/* Multi-frame launches: ONE launch traces nFrames (1..SNAIL_MAX_BATCH) frames of the same rect / packet list, each with its own camera
+ * (cams13: HOST array nFrames x 13) and its own output planes (HOST arrays of nFrames DEVICE pointers; a NULL array = that plane is not
+ * wanted).  The heaviest packets of all the frames are dispatched first; a frame's tail -- ~0.2 ms whatever the launch holds -- and the
+ * launch overheads are paid once per nFrames frames.  What it costs is latency (a frame is complete when its launch is): the choice of
+ * a host that renders a camera path for throughput, or whose launches are small (one rank's share of a frame).  Hit records, shaded
+ * bytes and counters are those of nFrames single-frame launches; d_slot_cost receives the first frame's costs. */
+#define SNAIL_MAX_BATCH 8
+int snail_trace_primary_batch_dev(SnailScene *, int nFrames, const float *cams13, int resx, int resy, float *const *d_t, float *const *d_u,
+                                  float *const *d_v, int32_t *const *d_triId, uint64_t *d_stats, const int32_t *d_order,
+                                  int32_t *d_slot_cost, void *stream);
+int snail_trace_packets_shaded_batch_dev(SnailScene *, int nFrames, const float *cams13, int resx, int resy, const int32_t *d_packet_xy,
+                                         int nPackets, uint8_t *const *d_bgr, uint64_t *d_stats, void *stream);
 /* Scatter packet-major planes into row-major resx*resy frame planes (clipped to the image). */
 int snail_packets_to_frame_dev(const int32_t *d_packet_xy, int nPackets, int resx, int resy,
                                const float *d_pt, const float *d_pu, const float *d_pv, const int32_t *d_pid,
@@ -158,6 +170,11 @@ int snail_shade_depth_dev(const float *d_t, int nPackets, uint8_t *d_bgr, void *
 /* Scatter packet-major BGR bytes into an interleaved rgb8 frame (pitch bytes per row), clipped to the image. */
 int snail_packets_bgr_to_frame_dev(const int32_t *d_packet_xy, int nPackets, int resx, int resy, const uint8_t *d_bgr,
                                    uint8_t *d_frame, int pitch, void *stream);
+
+/* The same scatter from a source cut into chunks: packet p of the list = entry p % nPerChunk of the chunk that starts (p / nPerChunk) *
+ * chunkStrideBytes into d_bgr -- rank r's shard of a gathered buffer that holds several frames per rank (multi-frame launches). */
+int snail_packets_bgr_to_frame_chunked_dev(const int32_t *d_packet_xy, int nPackets, int nPerChunk, int64_t chunkStrideBytes, int resx, int resy,
+                                           const uint8_t *d_bgr, uint8_t *d_frame, int pitch, void *stream);
 
 /* The render node's wire format for a tile and its inverse.  Encode = the `compress` store of RenderTask::Work
  * (src/render.cpp:140-163): tile (x, y, w, h) -> three w*h byte planes R, G-R, B-R (mod 256) at d_out + d_out_offsets[tile]

@@ -37,6 +37,8 @@ SIGNATURES = {
     "snail_trace_primary_dev": (_I, [_VP, _F13, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "snail_trace_packets_dev": (_I, [_VP, _F13, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "snail_trace_packets_shaded_dev": (_I, [_VP, _F13, _I, _I, _VP, _I, _VP, _VP, _VP]),
+    "snail_trace_primary_batch_dev": (_I, [_VP, _I, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "snail_trace_packets_shaded_batch_dev": (_I, [_VP, _I, _VP, _I, _I, _VP, _I, _VP, _VP, _VP]),
     "snail_primary_slots": (_I, [_I, _I]),
     "snail_trace_primary_ordered_dev": (_I, [_VP, _F13, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "snail_trace_packets_ordered_dev": (_I, [_VP, _F13, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
@@ -48,6 +50,7 @@ SIGNATURES = {
     "snail_trace_shadow_dev": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "snail_shade_depth_dev": (_I, [_VP, _I, _VP, _VP]),
     "snail_packets_bgr_to_frame_dev": (_I, [_VP, _I, _I, _I, _VP, _VP, _I, _VP]),
+    "snail_packets_bgr_to_frame_chunked_dev": (_I, [_VP, _I, _I, C.c_int64, _I, _I, _VP, _VP, _I, _VP]),
     "snail_packets_bgr_to_planar_dev": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP]),
     "snail_planar_to_frame_dev": (_I, [_VP, _VP, _I, _VP, _VP, _I, _I, _I, _VP]),
     "snail_render_whitted_dev": (_I, [_VP, _F13, _I, _I, _VP, _I, _VP, _VP, _I, _VP, _I, _VP, _VP]),

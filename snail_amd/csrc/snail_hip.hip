@@ -1053,9 +1053,20 @@ struct GenConst {
 	float tright[3], tup[3], txyz[3][4], org[3];
 };
 
+// Multi-frame launches: ONE launch may trace up to SNAIL_MAX_BATCH frames of the same packet set (each with its own camera and output
+// planes): block b takes frame b % nFrames at dispatch rank b / nFrames, so that the heaviest packets of ALL its frames start first.  A
+// frame's tail -- its heaviest packets, ~0.2 ms whatever the launch holds -- and the launch overheads are then paid once per nFrames
+// frames; what it costs is latency: a frame is complete when its launch is.
+struct FrameOut {
+	float *t, *u, *v;
+	int *id;
+	unsigned char *bgr; // packet-major B,G,R of the gVals[1] depth shading (src/scene_trace.cpp:128-137), 3 B/ray, or null
+};
 struct PrimaryArgs {
 	const uint4 *nodes, *tris;
-	GenConst g;
+	int nFrames;
+	GenConst g[SNAIL_MAX_BATCH];
+	FrameOut out[SNAIL_MAX_BATCH];
 	int resx, resy, x0, y0, w, h; // rect (frame layout) ...
 	const int2 *packetXY;		  // ... or explicit packet list (packet-major layout)
 	int nPackets, pw, ph;		  // packet grid of the rect
@@ -1063,15 +1074,12 @@ struct PrimaryArgs {
 	int pack;                     // at most 2^20 node slots: one-word stack entries in the hand-written walks
 	int packetMajor;              // rect mode: store packet-major ([cy*pw+cx][256], the reference's quad order) instead of frame layout
 	int fastOK;
-	float *t, *u, *v;
-	int *id;
-	unsigned char *bgr; // packet-major B,G,R of the gVals[1] depth shading (src/scene_trace.cpp:128-137), 3 B/ray, or null
 	u64 *stats;
 	unsigned *cost; // diagnostic (k_primary_diag only): per packet 8 words {iters, intersects, shader cycles, start time >> 6, triangle records fetched, leaf bodies, 0, 0}
 	const int *order; // dispatch order (block -> slot index, a permutation of [0, nSlots)) or null = the built-in interleave
 	int *slotCost;	  // out, per slot: node visits of its packet (0 for a slot without a packet) or null
 	int nSlots;		  // rect mode: nBlocks; list mode: nPackets
-	int *defer;		// [0] = count, [1] = finished blocks of the M_EXACT pass, [2..] = logical indices of deferred packets
+	int *defer;		// [0] = count, [1] = finished blocks of the M_EXACT pass, [2..] = frame * nSlots + logical index of deferred packets
 };
 
 #define LDS_FLOATS_PER_WAVE (64 * 12 + 64)
@@ -1092,8 +1100,10 @@ __device__ __forceinline__ int interleave16(int b) { // -> logical index; 16 con
 // left to the second, tiny kernel (EXACTPASS=true).  Keeping the select-based M_EXACT walk out of the main kernel
 // takes its register allocation from 128 to 84-96 VGPRs, i.e. from 4 to 5 waves per SIMD.
 template <bool DEEP, bool EXACTPASS, bool DIAG = false>
-__device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li, float *lds) {
+__device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li, const int fi, float *lds) {
 	const int lane = threadIdx.x & 63;
+	const GenConst &G = A.g[fi];
+	const FrameOut &F = A.out[fi];
 
 	int px, py, pidx;
 	if(A.packetXY) {
@@ -1108,7 +1118,7 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 		const int rx = region % nrx, ry = region / nrx;
 		const int cx = rx * 4 + (k & 3), cy = ry * 4 + (k >> 2);
 		if(cx >= A.pw || cy >= A.ph) {
-			if(A.slotCost && lane == 0 && (unsigned)li < (unsigned)A.nSlots) A.slotCost[li] = 0;
+			if(A.slotCost && fi == 0 && lane == 0 && (unsigned)li < (unsigned)A.nSlots) A.slotCost[li] = 0;
 			return;
 		}
 		px = A.x0 + cx * 16;
@@ -1126,9 +1136,9 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 		const float yoff = (float)(py - (l >= 2 ? 1 : 0));
 		const float tposx = (float)(4 * k4) + xoff;
 		const float tposy = (float)ty + yoff;
-		const float p0 = A.g.tright[0] * tposx + (A.g.tup[0] * tposy + A.g.txyz[0][l]);
-		const float p1 = A.g.tright[1] * tposx + (A.g.tup[1] * tposy + A.g.txyz[1][l]);
-		const float p2 = A.g.tright[2] * tposx + (A.g.tup[2] * tposy + A.g.txyz[2][l]);
+		const float p0 = G.tright[0] * tposx + (G.tup[0] * tposy + G.txyz[0][l]);
+		const float p1 = G.tright[1] * tposx + (G.tup[1] * tposy + G.txyz[1][l]);
+		const float p2 = G.tright[2] * tposx + (G.tup[2] * tposy + G.txyz[2][l]);
 		const float rs = 1.0f / __builtin_sqrtf(p0 * p0 + p1 * p1 + p2 * p2);
 		Q.d[0][l] = p0 * rs; Q.d[1][l] = p1 * rs; Q.d[2][l] = p2 * rs;
 #pragma unroll
@@ -1141,14 +1151,14 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 #pragma unroll
 	for(int c = 0; c < 3; c++)
 #pragma unroll
-		for(int l = 0; l < 4; l++) org[c][l] = A.g.org[c];
+		for(int l = 0; l < 4; l++) org[c][l] = G.org[c];
 
 	Counters st = {0, 0, 0, 0, 0};
 	int oct;
 	const int mode = classify(A.fastOK != 0, finite4(Q.id) && finite4(Q.d), true, Q.id, Q.dist, oct);
 	if(EXACTPASS) walk<true, false, false, M_EXACT, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st);
 	else if(mode == M_EXACT) {
-		if(lane == 0) A.defer[2 + atomicAdd(&A.defer[0], 1)] = li;
+		if(lane == 0) A.defer[2 + atomicAdd(&A.defer[0], 1)] = fi * A.nSlots + li;
 		return;
 	} else if(DEEP) { // depth > 62: the C++ walk with its second stack register pair
 		if(mode == M_COH) walk<true, false, false, M_COH, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, oct);
@@ -1158,10 +1168,10 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 		else walkSharedAsm<false, false, true, false, false, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, 0);
 	} else if(mode == M_COH) walkSharedAsm<false, true, false, false, false, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, oct);
 	else walkSharedAsm<false, false, false, false, false, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, 0);
-	if(A.u || A.v) finalBarycentrics(A.tris, org, Q, tid, bu, bv); // (the staged shading pipeline asks for t and triId only)
+	if(F.u || F.v) finalBarycentrics(A.tris, org, Q, tid, bu, bv); // (the staged shading pipeline asks for t and triId only)
 
 	flushStats(A.stats, st, 256u, lane);
-	if(A.slotCost && lane == 0) A.slotCost[li] = (int)st.iters;
+	if(A.slotCost && fi == 0 && lane == 0) A.slotCost[li] = (int)st.iters;
 	if(DIAG && A.cost && lane == 0) {
 		const u64 tEnd = __builtin_amdgcn_s_memtime();
 		unsigned *c = A.cost + (size_t)pidx * 8;
@@ -1169,41 +1179,41 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 		c[4] = st.fetched; c[5] = st.leaves; c[6] = 0; c[7] = 0;
 	}
 
-	if(A.bgr) { // fused gVals[1] depth shading + ConvColor: c = Inv(t) * (20, 250, 2), bytes B,G,R (same operations as k_shade_depth)
+	if(F.bgr) { // fused gVals[1] depth shading + ConvColor: c = Inv(t) * (20, 250, 2), bytes B,G,R (same operations as k_shade_depth)
 		unsigned bytes[12];
 #pragma unroll
 		for(int l = 0; l < 4; l++) {
 			const float dist = 1.0f / Q.dist[l];
 			bytes[l * 3 + 0] = (unsigned)convChannelW(dist * 2.0f); bytes[l * 3 + 1] = (unsigned)convChannelW(dist * 250.0f); bytes[l * 3 + 2] = (unsigned)convChannelW(dist * 20.0f);
 		}
-		unsigned *o = (unsigned *)(A.bgr + ((size_t)pidx * 256 + (size_t)lane * 4) * 3);
+		unsigned *o = (unsigned *)(F.bgr + ((size_t)pidx * 256 + (size_t)lane * 4) * 3);
 #pragma unroll
 		for(int k = 0; k < 3; k++) o[k] = bytes[4 * k] | (bytes[4 * k + 1] << 8) | (bytes[4 * k + 2] << 16) | (bytes[4 * k + 3] << 24);
 	}
 	if(A.packetXY || A.packetMajor) { // packet-major (Context layout)
 		const size_t o = (size_t)pidx * 256 + (size_t)lane * 4;
-		if(A.t) *(float4 *)(A.t + o) = make_float4(Q.dist[0], Q.dist[1], Q.dist[2], Q.dist[3]);
-		if(A.u) *(float4 *)(A.u + o) = make_float4(bu[0], bu[1], bu[2], bu[3]);
-		if(A.v) *(float4 *)(A.v + o) = make_float4(bv[0], bv[1], bv[2], bv[3]);
-		if(A.id) *(int4 *)(A.id + o) = make_int4(tid[0], tid[1], tid[2], tid[3]);
+		if(F.t) *(float4 *)(F.t + o) = make_float4(Q.dist[0], Q.dist[1], Q.dist[2], Q.dist[3]);
+		if(F.u) *(float4 *)(F.u + o) = make_float4(bu[0], bu[1], bu[2], bu[3]);
+		if(F.v) *(float4 *)(F.v + o) = make_float4(bv[0], bv[1], bv[2], bv[3]);
+		if(F.id) *(int4 *)(F.id + o) = make_int4(tid[0], tid[1], tid[2], tid[3]);
 	} else {
 		const int yy = py + ty, xx = px + k4 * 4;
 		const int xlim = min(A.resx, A.x0 + A.w), ylim = min(A.resy, A.y0 + A.h);
 		if(yy < ylim) {
 			const size_t o = (size_t)yy * A.resx + xx;
 			if(xx + 3 < xlim && (A.resx & 3) == 0) {
-				if(A.t) *(float4 *)(A.t + o) = make_float4(Q.dist[0], Q.dist[1], Q.dist[2], Q.dist[3]);
-				if(A.u) *(float4 *)(A.u + o) = make_float4(bu[0], bu[1], bu[2], bu[3]);
-				if(A.v) *(float4 *)(A.v + o) = make_float4(bv[0], bv[1], bv[2], bv[3]);
-				if(A.id) *(int4 *)(A.id + o) = make_int4(tid[0], tid[1], tid[2], tid[3]);
+				if(F.t) *(float4 *)(F.t + o) = make_float4(Q.dist[0], Q.dist[1], Q.dist[2], Q.dist[3]);
+				if(F.u) *(float4 *)(F.u + o) = make_float4(bu[0], bu[1], bu[2], bu[3]);
+				if(F.v) *(float4 *)(F.v + o) = make_float4(bv[0], bv[1], bv[2], bv[3]);
+				if(F.id) *(int4 *)(F.id + o) = make_int4(tid[0], tid[1], tid[2], tid[3]);
 			} else {
 #pragma unroll
 				for(int l = 0; l < 4; l++)
 					if(xx + l < xlim) {
-						if(A.t) A.t[o + l] = Q.dist[l];
-						if(A.u) A.u[o + l] = bu[l];
-						if(A.v) A.v[o + l] = bv[l];
-						if(A.id) A.id[o + l] = tid[l];
+						if(F.t) F.t[o + l] = Q.dist[l];
+						if(F.u) F.u[o + l] = bu[l];
+						if(F.v) F.v[o + l] = bv[l];
+						if(F.id) F.id[o + l] = tid[l];
 					}
 			}
 		}
@@ -1225,10 +1235,12 @@ template <bool DEEP>
 __global__ __launch_bounds__(64 * SNAIL_BLOCK_WAVES) __attribute__((amdgpu_waves_per_eu(SNAIL_PRIMARY_WAVES))) void k_primary(PrimaryArgs A) {
 	__shared__ float lds[LDS_FLOATS_PER_WAVE];
 	const int wv = SNAIL_BLOCK_WAVES > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
-	const int b = (int)blockIdx.x * SNAIL_BLOCK_WAVES + wv; // dispatch index of this wave's packet
+	int b = (int)blockIdx.x * SNAIL_BLOCK_WAVES + wv; // dispatch index of this wave's packet
+	int fi = 0;
+	if(A.nFrames > 1) { fi = b % A.nFrames; b = b / A.nFrames; } // several frames in one launch: frame fi at dispatch rank b
 	int li;
 	if(SNAIL_BLOCK_WAVES > 1) {
-		const int xcd = (int)blockIdx.x & 7, j = ((int)blockIdx.x >> 3) * SNAIL_BLOCK_WAVES + wv;
+		const int xcd = (int)blockIdx.x & 7, j = ((int)blockIdx.x >> 3) * SNAIL_BLOCK_WAVES + wv;   // (single-frame launches only)
 		li = (((j >> 4) << 3) + xcd) * 16 + (j & 15);
 	} else li = interleave16(b);
 	if(A.order) { // fed-back dispatch order (snail_order_from_cost_dev): heaviest packets of the previous frame first
@@ -1245,13 +1257,13 @@ __global__ __launch_bounds__(64 * SNAIL_BLOCK_WAVES) __attribute__((amdgpu_waves
 		else if(b < 4 * SNAIL_PRIO_RANK) __builtin_amdgcn_s_setprio(1);
 #endif
 	}
-	primaryPacket<DEEP, false>(A, li, lds);
+	primaryPacket<DEEP, false>(A, li, fi, lds);
 }
 // the diagnostic build of the same packet code (snail_debug_packet_costs): per-packet cost records; never on a product path
 template <bool DEEP>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SNAIL_PRIMARY_WAVES))) void k_primary_diag(PrimaryArgs A) {
 	__shared__ float lds[LDS_FLOATS_PER_WAVE];
-	primaryPacket<DEEP, false, true>(A, interleave16((int)blockIdx.x), lds);
+	primaryPacket<DEEP, false, true>(A, interleave16((int)blockIdx.x), 0, lds);
 }
 
 // Dispatch order from per-slot costs: slots in (approximately) descending cost -- a counting sort over 4096 cost classes, one
@@ -1305,7 +1317,10 @@ __global__ __launch_bounds__(64) void k_primary_exact(PrimaryArgs A) {
 	__shared__ float lds[LDS_FLOATS_PER_WAVE];
 	const int n = __builtin_amdgcn_readfirstlane(A.defer[0]);
 	if(n == 0) return; // nothing was deferred (the rule): the list is armed as it stands, no fence, no counter
-	for(int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) primaryPacket<DEEP, true>(A, __builtin_amdgcn_readfirstlane(A.defer[2 + i]), lds);
+	for(int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
+		const int e = __builtin_amdgcn_readfirstlane(A.defer[2 + i]);
+		primaryPacket<DEEP, true>(A, e % A.nSlots, e / A.nSlots, lds);
+	}
 	__threadfence();
 	if((threadIdx.x & 63) == 0 && atomicAdd(&A.defer[1], 1) == (int)gridDim.x - 1) { A.defer[0] = 0; A.defer[1] = 0; }
 }
@@ -1954,15 +1969,18 @@ __global__ __launch_bounds__(256) void k_shade_depth(const float *t, int nRays, 
 		for(int k = 0; k < 12; k++) bgr[(size_t)i * 3 + k] = (unsigned char)bytes[k];
 	}
 }
+// nPerChunk > 0: the source is cut into chunks of nPerChunk packets that lie chunkStride bytes apart (rank r's shard of a gathered buffer that
+// holds several frames per rank: packet p = entry p % nPerChunk of chunk p / nPerChunk); 0 = one contiguous array
 __global__ __launch_bounds__(256) void k_bgr_to_frame(const int2 *packetXY, int nPackets, int resx, int resy, const unsigned char *src,
-														unsigned char *frame, int pitch) {
+														unsigned char *frame, int pitch, int nPerChunk, long long chunkStride) {
 	const int lane = threadIdx.x & 63;
 	const int p = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
 	if(p >= nPackets) return;
 	const int2 xy = packetXY[p];
 	const int yy = xy.y + (lane >> 2), xx = xy.x + (lane & 3) * 4;
 	if(yy >= resy) return;
-	const unsigned char *s = src + ((size_t)p * 256 + (size_t)lane * 4) * 3;
+	const unsigned char *s = nPerChunk > 0 ? src + (size_t)(p / nPerChunk) * (size_t)chunkStride + ((size_t)(p % nPerChunk) * 256 + (size_t)lane * 4) * 3
+										   : src + ((size_t)p * 256 + (size_t)lane * 4) * 3;
 	unsigned char *d = frame + (size_t)yy * pitch + (size_t)xx * 3;
 	if(xx + 3 < resx && (pitch & 3) == 0 && (((unsigned long long)frame | (unsigned long long)src) & 3) == 0) { // 4 pixels = three aligned dwords
 		const unsigned *sw = (const unsigned *)s;
@@ -2199,21 +2217,31 @@ int checkScene(const SnailScene *s, const char *fn) {
 	return 0;
 }
 
-int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0, int y0, int w, int h, const int32_t *dPacketXY,
-				  int nPackets, float *t, float *u, float *v, int32_t *id, uint64_t *dStats, hipStream_t stream, unsigned *dCost = nullptr,
-				  bool packetMajor = false, uint8_t *dBgr = nullptr, const int32_t *dOrder = nullptr, int32_t *dSlotCost = nullptr) {
+// the frames of one launch: cameras (13 floats each) and output planes per frame (any plane may be null)
+struct FrameSet {
+	int n = 0;
+	const float *cam[SNAIL_MAX_BATCH] = {};
+	dev::FrameOut out[SNAIL_MAX_BATCH] = {};
+};
+
+int launchPrimaryFrames(SnailScene *s, const FrameSet &FS, int resx, int resy, int x0, int y0, int w, int h, const int32_t *dPacketXY, int nPackets, uint64_t *dStats,
+						hipStream_t stream, unsigned *dCost = nullptr, bool packetMajor = false, const int32_t *dOrder = nullptr, int32_t *dSlotCost = nullptr) {
 	if(resx <= 0 || resy <= 0) { snail_set_error("snail_trace_primary: bad resolution %dx%d", resx, resy); return 1; }
+	if(FS.n < 1 || FS.n > SNAIL_MAX_BATCH || (SNAIL_BLOCK_WAVES > 1 && FS.n > 1)) { snail_set_error("snail_trace_primary: 1..%d frames per launch (got %d)", SNAIL_MAX_BATCH, FS.n); return 1; }
 	dev::PrimaryArgs A;
 	memset(&A, 0, sizeof(A));
 	A.nodes = s->dNodes; A.tris = s->dTris;
-	A.g = makeGen(cam, resx, resy);
+	A.nFrames = FS.n;
+	A.fastOK = s->fastOK;
+	for(int k = 0; k < FS.n; k++) {
+		A.g[k] = makeGen(FS.cam[k], resx, resy);
+		A.out[k] = FS.out[k];
+		A.fastOK = A.fastOK && originSane(FS.cam[k]);
+	}
 	A.resx = resx; A.resy = resy;
-	A.fastOK = s->fastOK && originSane(cam);
-	A.t = t; A.u = u; A.v = v; A.id = id;
 	A.stats = (dev::u64 *)dStats;
 	A.cost = dCost;
 	A.packetMajor = packetMajor ? 1 : 0;
-	A.bgr = dBgr;
 	A.pack = stackPack(s);
 	int blocks;
 	if(dPacketXY) {
@@ -2235,18 +2263,18 @@ int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0
 	A.nBlocks = blocks;
 	A.nSlots = dPacketXY ? nPackets : blocks;
 	A.order = dOrder; A.slotCost = dSlotCost;
-	const int gridBlocks = blocks;
+	const int gridBlocks = blocks * FS.n;
 	s->lastBlocks = gridBlocks; s->lastThreads = 64;
-	// deferred-packet list of this launch (re-allocated, synchronously, only when a larger frame than ever before arrives)
-	if(blocks + 2 > s->deferCap) {
+	// deferred-packet list of this launch (re-allocated, synchronously, only when a larger launch than ever before arrives)
+	if(gridBlocks + 2 > s->deferCap) {
 		HIP_TRY(hipDeviceSynchronize());
 		for(int k = 0; k < SnailScene::kDeferSlots; k++) {
 			if(s->dDefer[k]) (void)hipFree(s->dDefer[k]);
 			s->dDefer[k] = nullptr;
-			HIP_TRY(hipMalloc((void **)&s->dDefer[k], (size_t)(blocks + 2) * sizeof(int)));
+			HIP_TRY(hipMalloc((void **)&s->dDefer[k], (size_t)(gridBlocks + 2) * sizeof(int)));
 			HIP_TRY(hipMemset(s->dDefer[k], 0, 2 * sizeof(int)));
 		}
-		s->deferCap = blocks + 2;
+		s->deferCap = gridBlocks + 2;
 	}
 	const int slot = (int)(s->launchCount++ % SnailScene::kDeferSlots);
 	A.defer = s->dDefer[slot];
@@ -2269,6 +2297,16 @@ int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0
 	HIP_TRY(hipEventRecord(s->deferDone[slot], stream));
 	s->deferUsed[slot] = true;
 	return 0;
+}
+
+// one frame per launch (every entry point but the *_batch_dev ones)
+int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0, int y0, int w, int h, const int32_t *dPacketXY,
+				  int nPackets, float *t, float *u, float *v, int32_t *id, uint64_t *dStats, hipStream_t stream, unsigned *dCost = nullptr,
+				  bool packetMajor = false, uint8_t *dBgr = nullptr, const int32_t *dOrder = nullptr, int32_t *dSlotCost = nullptr) {
+	FrameSet FS;
+	FS.n = 1; FS.cam[0] = cam;
+	FS.out[0].t = t; FS.out[0].u = u; FS.out[0].v = v; FS.out[0].id = (int *)id; FS.out[0].bgr = dBgr;
+	return launchPrimaryFrames(s, FS, resx, resy, x0, y0, w, h, dPacketXY, nPackets, dStats, stream, dCost, packetMajor, dOrder, dSlotCost);
 }
 
 // scratch of one staged frame: ONE allocation, carved (hitT is its base); grown synchronously when a larger frame or the first
@@ -2567,6 +2605,40 @@ int snail_trace_packets_dev(SnailScene *s, const float cam[13], int resx, int re
 	return launchPrimary(s, cam, resx, resy, 0, 0, 0, 0, dPacketXY, nPackets, t, u, v, id, dStats, (hipStream_t)stream);
 }
 
+static int frameSetFrom(const char *fn, FrameSet &FS, int nFrames, const float *cams13) {
+	if(nFrames < 1 || nFrames > SNAIL_MAX_BATCH || !cams13) { snail_set_error("%s: 1..%d frames per launch and their cameras are required (got %d)", fn, SNAIL_MAX_BATCH, nFrames); return 1; }
+	FS.n = nFrames;
+	for(int k = 0; k < nFrames; k++) FS.cam[k] = cams13 + (size_t)k * 13;
+	return 0;
+}
+
+int snail_trace_primary_batch_dev(SnailScene *s, int nFrames, const float *cams13, int resx, int resy, float *const *t, float *const *u, float *const *v,
+								  int32_t *const *id, uint64_t *dStats, const int32_t *dOrder, int32_t *dSlotCost, void *stream) {
+	if(int rc = checkScene(s, "snail_trace_primary_batch_dev")) return rc;
+	FrameSet FS;
+	if(int rc = frameSetFrom("snail_trace_primary_batch_dev", FS, nFrames, cams13)) return rc;
+	for(int k = 0; k < nFrames; k++) {
+		FS.out[k].t = t ? t[k] : nullptr; FS.out[k].u = u ? u[k] : nullptr; FS.out[k].v = v ? v[k] : nullptr; FS.out[k].id = id ? (int *)id[k] : nullptr;
+	}
+	DeviceGuard guard(s->device);
+	return launchPrimaryFrames(s, FS, resx, resy, 0, 0, resx, resy, nullptr, 0, dStats, (hipStream_t)stream, nullptr, false, dOrder, dSlotCost);
+}
+
+int snail_trace_packets_shaded_batch_dev(SnailScene *s, int nFrames, const float *cams13, int resx, int resy, const int32_t *dPacketXY, int nPackets,
+										 uint8_t *const *bgr, uint64_t *dStats, void *stream) {
+	if(int rc = checkScene(s, "snail_trace_packets_shaded_batch_dev")) return rc;
+	if((!dPacketXY || !bgr) && nPackets > 0) { snail_set_error("snail_trace_packets_shaded_batch_dev: null buffer"); return 1; }
+	if(nPackets <= 0) return 0;
+	FrameSet FS;
+	if(int rc = frameSetFrom("snail_trace_packets_shaded_batch_dev", FS, nFrames, cams13)) return rc;
+	for(int k = 0; k < nFrames; k++) {
+		if(!bgr[k] || ((unsigned long long)bgr[k] & 3)) { snail_set_error("snail_trace_packets_shaded_batch_dev: d_bgr[%d] must be a 4-byte aligned device pointer", k); return 1; }
+		FS.out[k].bgr = bgr[k];
+	}
+	DeviceGuard guard(s->device);
+	return launchPrimaryFrames(s, FS, resx, resy, 0, 0, 0, 0, dPacketXY, nPackets, dStats, (hipStream_t)stream);
+}
+
 int snail_trace_packets_shaded_dev(SnailScene *s, const float cam[13], int resx, int resy, const int32_t *dPacketXY, int nPackets, uint8_t *bgr,
 								   uint64_t *dStats, void *stream) {
 	if(int rc = checkScene(s, "snail_trace_packets_shaded_dev")) return rc;
@@ -2835,7 +2907,20 @@ int snail_packets_bgr_to_frame_dev(const int32_t *dPacketXY, int nPackets, int r
 	if(nPackets <= 0) return 0;
 	if(!dPacketXY || !bgr || !frame || pitch < resx * 3) { snail_set_error("snail_packets_bgr_to_frame_dev: bad arguments"); return 1; }
 	hipLaunchKernelGGL(dev::k_bgr_to_frame, dim3((nPackets + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const int2 *)dPacketXY, nPackets, resx,
-					   resy, bgr, frame, pitch);
+					   resy, bgr, frame, pitch, 0, 0ll);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+int snail_packets_bgr_to_frame_chunked_dev(const int32_t *dPacketXY, int nPackets, int nPerChunk, int64_t chunkStrideBytes, int resx, int resy, const uint8_t *bgr,
+										   uint8_t *frame, int pitch, void *stream) {
+	if(nPackets <= 0) return 0;
+	if(!dPacketXY || !bgr || !frame || pitch < resx * 3 || nPerChunk <= 0 || chunkStrideBytes < (int64_t)nPerChunk * 768 || (chunkStrideBytes & 3)) {
+		snail_set_error("snail_packets_bgr_to_frame_chunked_dev: bad arguments");
+		return 1;
+	}
+	hipLaunchKernelGGL(dev::k_bgr_to_frame, dim3((nPackets + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const int2 *)dPacketXY, nPackets, resx,
+					   resy, bgr, frame, pitch, nPerChunk, (long long)chunkStrideBytes);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
@@ -2898,7 +2983,8 @@ int snail_debug_anyorder(SnailScene *s, const float cam[13], int resx, int resy,
 	dev::PrimaryArgs A;
 	memset(&A, 0, sizeof(A));
 	A.nodes = s->dNodes; A.tris = s->dTris;
-	A.g = makeGen(cam, resx, resy);
+	A.nFrames = 1;
+	A.g[0] = makeGen(cam, resx, resy);
 	A.resx = resx; A.resy = resy; A.w = resx; A.h = resy;
 	A.fastOK = s->fastOK && originSane(cam);
 	A.pack = stackPack(s);

@@ -165,7 +165,7 @@ class DistributedRenderer:
                  payload: str = "rgb8", slots: int | None = None, stage_cpu: bool = False, force_collective: bool = False, lights7=None,
                  ambient=(0.1, 0.1, 0.1), color=(1.0, 1.0, 1.0), reflections: bool = False, feedback_order: bool = True, order_refresh: int = 16,
                  inline_collective: bool | None = None, rank0_share: float = 1.0, plan_ranks: int | None = None, plan_rank: int | None = None,
-                 stagger: bool = False):
+                 stagger: bool = False, frames_per_launch: int = 1):
         import torch
         self.torch = torch
         self.scene = scene
@@ -200,6 +200,17 @@ class DistributedRenderer:
         self.nslots = max(1, slots) if slots is not None else (3 if self.multi and not self.inline else 4)
         self.streams = _stream_pool(torch, dev, self.nslots)
         self.step = 0
+        # frames_per_launch = B > 1 (single-GPU hit-record route): render() collects B cameras and traces them with ONE launch
+        # (Scene.trace_primary_batch): the heaviest packets of all B frames start first, and a frame's tail -- its heaviest packets, ~0.2 ms
+        # whatever the launch holds -- is paid once per B frames.  It buys throughput where the pipeline cannot reach its steady state (a short
+        # burst of frames from idle) at the price of latency: a frame is complete when its launch is.  flush() launches what is pending.
+        # On the tile-sharded route (rgb8 payload, depth shading, gather on the slot's stream) the B frames also travel in ONE collective and
+        # rank 0 scatters each of them with one launch (Scene.packets_bgr_to_frame_chunked): at N ranks a rank's launch holds only 8160 / N
+        # packets, so launches, collectives and the ~0.2 ms latency of a frame's heaviest packets are what bound the rate there.
+        multi_now = world_size > 1 or force_collective
+        batch_ok = lights7 is None and (not multi_now or (payload == "rgb8" and (self.inline or stage_cpu)))
+        self.batch = max(1, min(8, int(frames_per_launch))) if batch_ok else 1
+        self.pending_cams, self.pending_events, self.pending_stats = [], None, None
         # stagger: streams that all start from idle at the same moment stay in phase for many frames -- their grids are dispatched one
         # after the other, so the later frames' heaviest packets start late and every round of `slots` frames ends in a common tail
         # (0.43 ms per round of four 1080p frames instead of 0.356 once the phases have drifted apart, tools/timeline.py).  The first
@@ -215,6 +226,8 @@ class DistributedRenderer:
         want_hits = rank == 0 and ((not self.multi and not self.whitted_single) or (self.multi and payload == "hits"))
         self.frames = [scene.alloc_frame(resx, resy) for _ in range(self.nslots)] if want_hits else []
         self.frame = self.frames[0] if self.frames else None
+        # multi-frame launches: B frame buffers per slot (slot k's buffer 0 is self.frames[k])
+        self.batch_frames = [[self.frames[k]] + [scene.alloc_frame(resx, resy) for _ in range(self.batch - 1)] for k in range(self.nslots)] if (want_hits and self.batch > 1) else []
         self.frames_rgb8 = ([torch.zeros((resy, resx, 3), dtype=torch.uint8, device=dev) for _ in range(self.nslots)]
                             if (rank == 0 and ((self.multi and payload == "rgb8") or self.whitted_single)) else [])
         self.frame_rgb8 = self.frames_rgb8[0] if self.frames_rgb8 else None
@@ -249,6 +262,9 @@ class DistributedRenderer:
                 self.planes = [(b[0][:n_real], b[1][:n_real], b[2][:n_real], b[3][:n_real].view(torch.int32)) for b in self.local]
             self.bgr = [torch.zeros((n, 256, 3), dtype=torch.uint8, device=dev) for _ in range(self.nslots)]
             self.bgr_real = [b[:n_real] for b in self.bgr]
+            if self.batch > 1:   # multi-frame launches: B frames per slot, one payload buffer [B, n, 256, 3] = one collective
+                self.bgrB = [torch.zeros((self.batch, n, 256, 3), dtype=torch.uint8, device=dev) for _ in range(self.nslots)]
+                self.bgrB_real = [[b[k][:n_real] for k in range(self.batch)] for b in self.bgrB]
             if rank == 0:
                 nw = world_size
                 # rank r's shard of the receive buffer is scattered with ITS padded list; pad entries (y = PAD_Y) are skipped
@@ -262,6 +278,10 @@ class DistributedRenderer:
                     self.gathered_all = [torch.empty((nw, n, 256, 3), dtype=torch.uint8, device=dev) for _ in range(self.nslots)]
                     self.gathered = [[g[r] for r in range(nw)] for g in self.gathered_all]
                     self.all_xy_cat = torch.cat(self.all_xy, dim=0).contiguous()
+                    if self.batch > 1:
+                        self.gatheredB_all = [torch.empty((nw, self.batch, n, 256, 3), dtype=torch.uint8, device=dev) for _ in range(self.nslots)]
+                        self.gatheredB = [[g[r] for r in range(nw)] for g in self.gatheredB_all]
+                        self.framesB_rgb8 = [[torch.zeros((resy, resx, 3), dtype=torch.uint8, device=dev) for _ in range(self.batch)] for _ in range(self.nslots)]
             else:
                 self.gathered = [None] * self.nslots
 
@@ -300,6 +320,12 @@ class DistributedRenderer:
         traversal launch on the stream it is launched on (bench.py)."""
         torch = self.torch
         sc, p = self.scene, self.plan
+        if self.batch > 1:       # multi-frame launches: collect, launch when the batch is full (or at flush())
+            self.pending_cams.append(cam)
+            if events and self.pending_events is None: self.pending_events = events
+            if stats is not None: self.pending_stats = stats
+            if len(self.pending_cams) == self.batch: self._launch_batch()
+            return self.frame_rgb8 if self.multi else self.frame
         slot = self.step % self.nslots
         self.step += 1
         st = self.streams[slot]
@@ -328,15 +354,20 @@ class DistributedRenderer:
         # the collective runs on the CURRENT stream: make the slot's stream current for the rest of the call.  (torch.cuda.stream(st) as
         # a context manager costs the host ~16 us per frame -- it looks the device up through is_available() twice -- of the ~45 us a frame
         # costs it on this route, tools/host_profile.py; at 4-8 ranks the host's issue rate is what bounds the frame rate.)
+        return self._on_stream(st, self._render_multi, cam, stats, events, slot, st)
+
+    def _on_stream(self, st, fn, *args):
+        """fn(*args) with `st` as the current stream (what torch.distributed launches its collectives on), the caller's stream restored after"""
+        torch = self.torch
         try:
             prev = torch._C._cuda_getCurrentStream(st.device_index)      # (stream_id, device_index, device_type) of the caller's stream
             set_raw = torch._C._cuda_setStream
         except AttributeError:                                           # another torch build: the documented (slower) way
             with torch.cuda.stream(st):
-                return self._render_multi(cam, stats, events, slot, st)
+                return fn(*args)
         set_raw(stream_id=st.stream_id, device_index=st.device_index, device_type=st.device_type)
         try:
-            return self._render_multi(cam, stats, events, slot, st)
+            return fn(*args)
         finally:
             set_raw(stream_id=prev[0], device_index=prev[1], device_type=prev[2])
 
@@ -391,6 +422,57 @@ class DistributedRenderer:
             self.pending[slot] = dist.gather(self.bgr[slot], self.gathered[slot] if self.rank == 0 else None, dst=0, group=self.group, async_op=True)
         return self.frame_rgb8
 
+    def _launch_batch(self):
+        """trace the pending cameras with ONE launch on the next slot's stream"""
+        cams, events, stats = self.pending_cams, self.pending_events, self.pending_stats
+        self.pending_cams, self.pending_events, self.pending_stats = [], None, None
+        if not cams:
+            return
+        sc, p = self.scene, self.plan
+        slot = self.step % self.nslots
+        self.step += 1
+        st = self.streams[slot]
+        if self.idle:
+            self.idle, self.burst_t0, self.burst_frames = False, time.perf_counter(), 0
+        self.burst_frames += len(cams)
+        if self.multi:
+            return self._on_stream(st, self._launch_batch_multi, cams, events, stats, slot, st)
+        outs = self.batch_frames[slot][:len(cams)]
+        if events: events[0].record(st)
+        if self.feedback:
+            order, key = self._order_for(slot, cams[0])
+            sc.trace_primary_batch(cams, p.resx, p.resy, outs, stats=stats, stream=st, order=order, slot_cost=self.slot_cost[slot])
+            if events: events[1].record(st)
+            if key is not None: self._refresh_order(slot, st, key)
+        else:
+            sc.trace_primary_batch(cams, p.resx, p.resy, outs, stats=stats, stream=st)
+            if events: events[1].record(st)
+        self.frame = outs[-1]
+
+    def _launch_batch_multi(self, cams, events, stats, slot, st):
+        """the tile-sharded route for a batch: one launch (this rank's packets x the batch's cameras), one collective, one scatter per frame"""
+        import torch.distributed as dist
+        torch = self.torch
+        sc, p = self.scene, self.plan
+        if events: events[0].record(st)
+        sc.trace_packets_shaded_batch(cams, p.resx, p.resy, self.packet_xy, self.bgrB_real[slot][:len(cams)], stats=stats, stream=st)
+        if events: events[1].record(st)
+        if self.stage_cpu:    # rehearsal transport (gloo): the payload moves through the host
+            host = self.bgrB[slot].cpu()
+            glist = [torch.empty_like(host) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(host, glist, dst=0, group=self.group)
+            if self.rank == 0:
+                for r in range(self.world):
+                    self.gatheredB[slot][r].copy_(glist[r], non_blocking=False)
+        else:
+            dist.gather(self.bgrB[slot], self.gatheredB[slot] if self.rank == 0 else None, dst=0, group=self.group, async_op=False)
+        if self.rank == 0:
+            n = self.plan.padded
+            for k in range(len(cams)):
+                self.frame_rgb8 = self.framesB_rgb8[slot][k]
+                sc.packets_bgr_to_frame_chunked(self.all_xy_cat, n, self.batch * n * 768, self.gatheredB_all[slot][0, k], self.frame_rgb8, stream=st)
+        return self.frame_rgb8
+
     def reduce_stats(self, stats):
         """Sum the ranks' TreeStats accumulators (device int64[4], Scene.new_stats()) onto rank 0; call after flush()."""
         if self.stage_cpu and self.world > 1:
@@ -404,6 +486,8 @@ class DistributedRenderer:
     def flush(self):
         """Complete every frame still in flight (call after the last render() of a sequence)."""
         torch = self.torch
+        if self.batch > 1:
+            self._launch_batch()
         for k in range(self.nslots):     # oldest frame first, so that frame_rgb8 ends up naming the newest
             slot = (self.step + k) % self.nslots
             with torch.cuda.stream(self.streams[slot]):

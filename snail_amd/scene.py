@@ -187,6 +187,29 @@ class Scene:
         _lib.check(rc, "snail_trace_primary_dev")
         return out
 
+    def trace_primary_batch(self, cams, resx: int, resy: int, outs, stats=None, stream=None, order=None, slot_cost=None):
+        """ONE launch for len(cams) frames (<= 8) of the whole image, each with its own camera and HitFrame (snail_trace_primary_batch_dev):
+        the heaviest packets of all the frames first, one tail and one set of launch overheads for all of them."""
+        n = len(cams)
+        cam13 = np.ascontiguousarray(np.stack([c.as_array13() for c in cams]), dtype=np.float32)
+        arr = lambda xs: (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+        rc = _lib.lib().snail_trace_primary_batch_dev(self._h, n, _lib.ptr(cam13), resx, resy, arr([o.t for o in outs]), arr([o.u for o in outs]),
+                                                      arr([o.v for o in outs]), arr([o.tri_id for o in outs]), _lib.ptr(stats), _lib.ptr(order),
+                                                      _lib.ptr(slot_cost), _stream_ptr(stream))
+        _lib.check(rc, "snail_trace_primary_batch_dev")
+        return outs
+
+    def trace_packets_shaded_batch(self, cams, resx: int, resy: int, packet_xy, outs, stats=None, stream=None):
+        """ONE launch for len(cams) frames of a packet list with the depth shading fused in; outs = one [n,256,3] uint8 tensor per frame
+        (snail_trace_packets_shaded_batch_dev)."""
+        n = len(cams)
+        cam13 = np.ascontiguousarray(np.stack([c.as_array13() for c in cams]), dtype=np.float32)
+        ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in outs])
+        rc = _lib.lib().snail_trace_packets_shaded_batch_dev(self._h, n, _lib.ptr(cam13), resx, resy, _lib.ptr(packet_xy), int(packet_xy.shape[0]), ptrs,
+                                                             _lib.ptr(stats), _stream_ptr(stream))
+        _lib.check(rc, "snail_trace_packets_shaded_batch_dev")
+        return outs
+
     @staticmethod
     def primary_slots(w: int, h: int) -> int:
         """Dispatch slots of a w x h rect (>= its packets): the length of the order / slot_cost arrays of trace_primary."""
@@ -272,6 +295,16 @@ class Scene:
         rc = _lib.lib().snail_packets_bgr_to_frame_dev(_lib.ptr(packet_xy), int(packet_xy.shape[0]), resx, resy, _lib.ptr(bgr_packets),
                                                        _lib.ptr(frame_rgb8), resx * 3, _stream_ptr(stream))
         _lib.check(rc, "snail_packets_bgr_to_frame_dev")
+        return frame_rgb8
+
+    @staticmethod
+    def packets_bgr_to_frame_chunked(packet_xy, n_per_chunk: int, chunk_stride_bytes: int, bgr_base, frame_rgb8, stream=None):
+        """packets_bgr_to_frame from a source cut into chunks of n_per_chunk packets, chunk_stride_bytes apart (bgr_base = a tensor whose
+        data pointer is the first chunk's first packet): one launch scatters one frame's tiles of all ranks out of a multi-frame gather."""
+        resy, resx = int(frame_rgb8.shape[0]), int(frame_rgb8.shape[1])
+        rc = _lib.lib().snail_packets_bgr_to_frame_chunked_dev(_lib.ptr(packet_xy), int(packet_xy.shape[0]), int(n_per_chunk), int(chunk_stride_bytes), resx, resy,
+                                                               _lib.ptr(bgr_base), _lib.ptr(frame_rgb8), resx * 3, _stream_ptr(stream))
+        _lib.check(rc, "snail_packets_bgr_to_frame_chunked_dev")
         return frame_rgb8
 
     @staticmethod

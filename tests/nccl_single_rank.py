@@ -64,6 +64,27 @@ def main():
         rnd.flush()
         torch.cuda.synchronize()
         out[payload + ("_inline" if inline else "") + "_ms_per_frame"] = round((time.perf_counter() - t0) / 30 * 1e3, 4)
+    # multi-frame launches on the route: 7 frames of a moving camera, 3 per launch (one collective and one chunked scatter per frame), the
+    # last batch partial -- after flush() the renderer's frame is the LAST camera's
+    rnd = DistributedRenderer(sc, resx, resy, 0, 1, force_collective=True, frames_per_launch=3)
+    assert rnd.batch == 3
+    rng = np.random.default_rng(12)
+    bmin, bmax = h.bbox()
+    ctr, ext = (bmin + bmax) * 0.5, (bmax - bmin)
+    cams = [FPSCamera((ctr + (rng.random(3) - 0.5) * ext * 0.6).astype(np.float32), rng.random() * 6.28, (rng.random() - 0.5)).camera() for _ in range(7)]
+    stb = sc.new_stats()
+    for cm in cams:
+        rnd.render(cm, stats=stb)
+    fr = rnd.flush()
+    torch.cuda.synchronize()
+    refs = [osc.render_primary(cm.as_array13(), resx, resy, mode=O.MODE_IEEE) for cm in cams]
+    out["batched_equal"] = bool(np.array_equal(fr.cpu().numpy(), O.shade_depth(refs[-1][0]).reshape(resy, resx, 3)))
+    out["batched_stats_equal"] = bool(np.array_equal(stb.cpu().numpy().astype(np.uint64), sum(r[4] for r in refs)))
+    # every frame of a full batch, not just the last one
+    rnd.render(cams[0]); rnd.render(cams[1]); rnd.render(cams[2])
+    rnd.flush(); torch.cuda.synchronize()
+    slot = (rnd.step - 1) % rnd.nslots
+    out["batched_all_frames_equal"] = bool(all(np.array_equal(rnd.framesB_rgb8[slot][k].cpu().numpy(), O.shade_depth(refs[k][0]).reshape(resy, resx, 3)) for k in range(3)))
     # an UNEVEN 3-rank plan rendered share by share through the product route (real packets traced once each, pad entries skipped by
     # the scatter): the shares' frames add up to the oracle's frame, and their TreeStats -- reduce_stats() over this one-rank group
     # is the identity -- add up to the oracle's counters (src/node.cpp:358-359)

@@ -620,7 +620,8 @@ def test_depth_shading_and_tile_pipeline(torch_mod):
 
 
 @pytest.mark.parametrize("extra,scaling,res", [([], "strong", (1920, 1080)), (["--rank0-share", "0.25"], "strong", (1920, 1080)),
-                                               (["--scaling", "weak"], "weak", (2720, 1528)), (["--config", "3"], "strong", (1920, 1080))])
+                                               (["--scaling", "weak"], "weak", (2720, 1528)), (["--config", "3"], "strong", (1920, 1080)),
+                                               (["--frames-per-launch", "1"], "strong", (1920, 1080))])
 def test_two_rank_bench_rehearsal(torch_mod, extra, scaling, res):
     """The N>1 flow of bench.py end to end with two ranks sharing this GPU (gloo, payload staged through the host --
     NCCL refuses two ranks on one device): plan, packet-list launches, shading, per-frame gather, rank-0 scatter,
@@ -665,6 +666,7 @@ def test_rccl_code_path_single_rank(torch_mod):
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["rgb8_equal"] and d["hits_equal"] and d["moving_equal"] and d["moving_hits_equal"], d
     assert d["uneven_frame_equal"] and d["uneven_stats_equal"], d
+    assert d["batched_equal"] and d["batched_stats_equal"] and d["batched_all_frames_equal"], d
 
 
 @pytest.mark.parametrize("name,resx,resy,nl,refl", [("atrium:0.05", 640, 368, 2, False), ("atrium:0.05", 250, 130, 1, False), ("box", 256, 256, 1, False),
@@ -777,6 +779,69 @@ def test_exact_mode_primary_frame_with_degenerate_triangles(torch_mod):
     torch_mod.cuda.synchronize()
     compare_frames(frame2, ref, "second launch")
     sc.close()
+
+
+@pytest.mark.parametrize("name,resx,resy,nf", [("atrium:0.05", 328, 200, 3), ("stress:0.05", 250, 130, 8), ("box", 256, 256, 2)])
+def test_multi_frame_launch_equals_single_frame_launches(torch_mod, name, resx, resy, nf):
+    """snail_trace_primary_batch_dev / snail_trace_packets_shaded_batch_dev: ONE launch for several frames, each with its own camera and output
+    planes -- hit records, shaded bytes and the summed TreeStats are those of the oracle frame by frame; with a fed-back dispatch order and
+    through DistributedRenderer(frames_per_launch=...) (a partial last batch at flush()); and with every packet deferred to the M_EXACT pass
+    (the deferred list carries the frame index)."""
+    from snail_amd import FPSCamera, HostBVH, scenes, survey_camera
+    from snail_amd import render as R
+    from snail_amd.scene import Scene
+    tv, sc, osc = gpu_scene(name)
+    base = util.camera_for(name, tv)
+    rng = np.random.RandomState(17)
+    bmin, bmax = osc.nodes[0]["bmin"], osc.nodes[0]["bmax"]
+    ext = (bmax - bmin)
+    cams = [base] + [FPSCamera((base.pos + (rng.rand(3) - 0.5) * 0.05 * ext).astype(np.float32), float(rng.rand() * 6.28), float(rng.rand() - 0.5) * 0.4).camera() for _ in range(nf - 1)]
+    refs = [osc.render_primary(c.as_array13(), resx, resy, mode=O.MODE_IEEE) for c in cams]
+    outs = [sc.alloc_frame(resx, resy) for _ in range(nf)]
+    stats = sc.new_stats()
+    n = sc.primary_slots(resx, resy)
+    cost = torch_mod.zeros(n, dtype=torch_mod.int32, device="cuda")
+    sc.trace_primary_batch(cams, resx, resy, outs, stats=stats, slot_cost=cost)
+    torch_mod.cuda.synchronize()
+    for k in range(nf):
+        compare_frames(outs[k], refs[k], "batched frame %d" % k)
+    assert np.array_equal(stats.cpu().numpy().astype(np.uint64), sum(r[4] for r in refs))
+    assert int(cost.sum().item()) == int(refs[0][4][1])              # the first frame's node visits
+    order = sc.order_from_cost(cost)
+    outs2 = [sc.alloc_frame(resx, resy) for _ in range(nf)]
+    sc.trace_primary_batch(cams, resx, resy, outs2, order=order)
+    torch_mod.cuda.synchronize()
+    for k in range(nf):
+        compare_frames(outs2[k], refs[k], "batched + ordered frame %d" % k)
+    # the packet-list form with the fused depth shading (a rank's share of the frames)
+    plan = R.ShardPlan.make(resx, resy, 2)
+    xy = torch_mod.from_numpy(plan.packets[1]).cuda()
+    bg = [torch_mod.zeros((len(plan.packets[1]), 256, 3), dtype=torch_mod.uint8, device="cuda") for _ in range(nf)]
+    sc.trace_packets_shaded_batch(cams, resx, resy, xy, bg)
+    for k in range(nf):
+        assert torch_mod.equal(bg[k], sc.trace_packets_shaded(cams[k], resx, resy, xy)), k
+    # through the renderer: nf + 1 frames with batches of min(nf, 3): full batches and a partial one at flush()
+    rnd = R.DistributedRenderer(sc, resx, resy, frames_per_launch=min(nf, 3))
+    for c in cams + [cams[0]]:
+        rnd.render(c)
+    fr = rnd.flush()
+    torch_mod.cuda.synchronize()
+    compare_frames(fr, refs[0], "renderer, last frame of a partial batch")
+    sc.close()
+    if name == "box":   # every packet deferred (a scene with non-finite records): the M_EXACT pass decodes frame and packet
+        p = np.array([[0.2, 0.3, -0.5]] * 3, dtype=np.float32)
+        tv2 = np.concatenate([scenes.box_scene(), p[None]], axis=0)
+        hb, osc2 = HostBVH.build(tv2), O.OracleScene(tv2)
+        sc2 = Scene(hb, 0)
+        refs2 = [osc2.render_primary(c.as_array13(), resx, resy, mode=O.MODE_IEEE) for c in cams]
+        outs3 = [sc2.alloc_frame(resx, resy) for _ in range(nf)]
+        st2 = sc2.new_stats()
+        sc2.trace_primary_batch(cams, resx, resy, outs3, stats=st2)
+        torch_mod.cuda.synchronize()
+        for k in range(nf):
+            compare_frames(outs3[k], refs2[k], "deferred batched frame %d" % k)
+        assert np.array_equal(st2.cpu().numpy().astype(np.uint64), sum(r[4] for r in refs2))
+        sc2.close()
 
 
 def test_every_sign_octant_and_walk_variant(torch_mod):
