@@ -26,7 +26,8 @@ Mrays = rays launched (every lane of every traced packet, hit or miss), as TreeS
 (src/scene_trace.cpp:116-117): frames are padded to whole 16x16 packets (1920x1080 -> 1920x1088); config 3 adds the shadow
 lanes with N.L > 0 (:554-557).
 
-Launches: frames are pipelined over 4 HIP streams, and `--frames-per-launch B` frames (default 2 at N = 1, 4 at N > 1, always 1 for config 3)
+Launches: frames are pipelined over 4 HIP streams, and `--frames-per-launch B` frames (default: enough for a launch to hold a 1080p frame's worth of packets, i.e. 2 / 2 / 4 / 8 at N = 1 / 2 / 4 / 8;
+always 1 for config 3)
 share ONE launch -- the heaviest packets of all of them first, one tail and one set of launch overheads (and, at N > 1, one collective)
 for B frames; results are those of B single-frame launches.
 
@@ -130,7 +131,7 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="frames in flight (HIP streams); 0 = the renderer's default (4); 1 = strictly serial frames")
     ap.add_argument("--event-every", type=int, default=8, help="bracket every n-th traversal launch with HIP events (roofline.kernel_ms)")
     ap.add_argument("--feedback-order", type=int, default=1, help="1 (default) = dispatch packets heaviest first by the node visits of an earlier frame (DistributedRenderer feedback_order)")
-    ap.add_argument("--frames-per-launch", type=int, default=0, help="trace this many frames (1..8) with one launch -- and, at N > 1, move them with one collective (DistributedRenderer frames_per_launch); 0 = 2 at N = 1, 4 at N > 1; config 3 always 1")
+    ap.add_argument("--frames-per-launch", type=int, default=0, help="trace this many frames (1..8) with one launch -- and, at N > 1, move them with one collective (DistributedRenderer frames_per_launch); 0 = enough for a launch to hold 8160 packets (one 1080p frame), at least 2, at most 8: 2 / 2 / 4 / 8 at N = 1 / 2 / 4 / 8; config 3 always 1")
     ap.add_argument("--stagger", type=int, default=0, help="1 = de-phase the frame streams when the pipeline starts from idle (DistributedRenderer stagger; measured: no gain)")
     ap.add_argument("--lone-frames", type=int, default=12, help="N=1: frames traced one at a time after the timed region (lone_frame_ms); 0 = skip")
     args = ap.parse_args()
@@ -184,9 +185,12 @@ def main():
         bmin, bmax = hbvh.bbox()
         c, e = (bmin + bmax) * 0.5, (bmax - bmin)
         lights7 = np.array([[c[0], c[1] + 0.35 * e[1], c[2], 1.0, 0.9, 0.8, 2.0 * float(e.max())]], dtype=np.float32)   # one point light above the nave
+    # frames per launch, unless given: enough for a launch to hold at least one 1080p frame's worth of packets (8160), at least 2, at most 8
+    per_rank = ((resx + 15) // 16) * ((resy + 15) // 16) / float(world)
+    auto_fpl = int(min(8, max(2, math.ceil(8160.0 / max(1.0, per_rank)))))
     rnd = DistributedRenderer(scene, resx, resy, rank, world, slots=args.streams if args.streams > 0 else None, stage_cpu=rehearsal,
                               feedback_order=bool(args.feedback_order), lights7=lights7, rank0_share=args.rank0_share, stagger=bool(args.stagger),
-                              frames_per_launch=args.frames_per_launch if args.frames_per_launch > 0 else (2 if world == 1 else 4))
+                              frames_per_launch=args.frames_per_launch if args.frames_per_launch > 0 else auto_fpl)
     primary_rays = rnd.rays_per_frame() if world > 1 else resx * ((resy + 15) // 16 * 16)
 
     def barrier():
