@@ -274,6 +274,10 @@ int snail_delay_dev(float microseconds, void *stream);
  * B_alg(ray) = 32*V_n + 64*V_t + 16. */
 int snail_account_primary(SnailScene *, const float cam[13], int resx, int resy, int x0, int y0, int w, int h, uint64_t out[4]);
 
+/* Diagnostic: one sleeping wave that reads the shader-cycle counter and the 100 MHz constant clock `microseconds` apart: d_out2[0] = shader
+ * cycles, d_out2[1] = constant-clock ticks; clock = d_out2[0] / d_out2[1] x 100 MHz.  tools/ramp.py samples it beside the frames. */
+int snail_debug_clock_dev(float microseconds, uint64_t *d_out2, void *stream);
+
 /* Diagnostic: time per launch of an EMPTY kernel of `blocks` x `threads` (what the workgroup dispatcher alone sustains), averaged
  * over `reps` back-to-back launches on the default stream of the current device.  tools/dispatch_rate.py. */
 int snail_debug_dispatch_rate(int blocks, int threads, int reps, float *ms_per_launch);

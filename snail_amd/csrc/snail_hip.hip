@@ -2037,6 +2037,15 @@ __global__ __launch_bounds__(64) void k_delay(unsigned ticks) {
 	while((unsigned)(__builtin_amdgcn_s_memrealtime() - t0) < ticks) __builtin_amdgcn_s_sleep(1);
 }
 
+// diagnostic: the shader clock as the guide's DVFS check reads it (MI355X_MICROARCH.md, "DVFS give-back" item 6): delta s_memtime (shader
+// cycles) over delta s_memrealtime (100 MHz) across `ticks` periods of the constant clock, one sleeping wave; out[0] = cycles, out[1] = ticks
+__global__ __launch_bounds__(64) void k_clock(unsigned ticks, unsigned long long *out) {
+	const u64 r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+	while((unsigned)(__builtin_amdgcn_s_memrealtime() - r0) < ticks) __builtin_amdgcn_s_sleep(1);
+	const u64 c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+	if(threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+}
+
 // diagnostic: what the workgroup dispatcher alone sustains (tools/dispatch_rate.py)
 __global__ void k_nop(int *sink) { if(sink && threadIdx.x == 0 && blockIdx.x == 0x7fffffff) *sink = 1; }
 
@@ -2952,6 +2961,13 @@ int snail_delay_dev(float microseconds, void *stream) {
 	const unsigned ticks = (unsigned)(microseconds * 100.0f);
 	if(ticks == 0) return 0;
 	hipLaunchKernelGGL(dev::k_delay, dim3(1), dim3(64), 0, (hipStream_t)stream, ticks);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+int snail_debug_clock_dev(float microseconds, uint64_t *dOut2, void *stream) {
+	if(!(microseconds > 0.0f) || microseconds > 10000.0f || !dOut2) { snail_set_error("snail_debug_clock_dev: bad arguments"); return 1; }
+	hipLaunchKernelGGL(dev::k_clock, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned)(microseconds * 100.0f), (unsigned long long *)dOut2);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
