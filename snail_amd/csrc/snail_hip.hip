@@ -328,6 +328,9 @@ __device__ __forceinline__ TriTerms triTerms(const Tri &t, float ox, float oy, f
 // ---- leaf, shared origin (src/bvh/traverse.cpp:34-56 / :98-124): lanes 0..chunk-1 each take one triangle (packet-level
 // cull + shared-origin terms in parallel), survivors are broadcast one by one to the whole packet.  Returns true when a
 // shadow packet is fully occluded (the walk ends, src/bvh/traverse.cpp:117-121).
+#ifndef SNAIL_LEAF_MASK
+#define SNAIL_LEAF_MASK 1 // 0 = every lane computes everything in the leaf (A/B measurements)
+#endif
 template <bool MASK, bool SHADOW, int M, bool BARY>
 __device__ __forceinline__ bool leafShared(const uint4 *__restrict__ tris, int count, int firstTri, int size, int lane, int first, int last,
 										   const float (&org)[3][4], Quad &Q, unsigned mask4, int (&tid)[4], float (&bu)[4], float (&bv)[4],
@@ -341,9 +344,26 @@ __device__ __forceinline__ bool leafShared(const uint4 *__restrict__ tris, int c
 		const int chunk = count - base < 64 ? count - base : 64;
 		st.fetched += (unsigned)chunk;
 		const bool mine = lane < chunk;
-		const Tri t = loadTriVector(tris, firstTri + base + (mine ? lane : 0));
-		const TriTerms tt = triTerms(t, org[0][0], org[1][0], org[2][0]);
-		u64 keep = __builtin_amdgcn_ballot_w64(mine & triTestInterval<M>(t, iv));
+		// Closest-hit packets: only the lanes that own a triangle (typically <= 4 of 64) fetch it and evaluate the cull and the shared-origin
+		// terms, and only the quads of the range [first, last] intersect a survivor: the other lanes' results were never read, now they are
+		// not computed either (EXEC off: the instruction count is the same, the switched lanes are not -- this part is power-limited,
+		// profiles/README.md).  Any-hit packets keep every lane on: their test is three compares shorter and the masks cost more than they save.
+		constexpr bool LANE_MASK = SNAIL_LEAF_MASK && !SHADOW;
+		Tri t = {};
+		TriTerms tt = {};
+		bool pass = false;
+		if(LANE_MASK) {
+			if(mine) {
+				t = loadTriVector(tris, firstTri + base + lane);
+				tt = triTerms(t, org[0][0], org[1][0], org[2][0]);
+				pass = triTestInterval<M>(t, iv);
+			}
+		} else {
+			t = loadTriVector(tris, firstTri + base + (mine ? lane : 0));
+			tt = triTerms(t, org[0][0], org[1][0], org[2][0]);
+			pass = mine & triTestInterval<M>(t, iv);
+		}
+		u64 keep = __builtin_amdgcn_ballot_w64(pass);
 
 		while(keep) {
 			const int k = __builtin_ctzll(keep);
@@ -364,6 +384,7 @@ __device__ __forceinline__ bool leafShared(const uint4 *__restrict__ tris, int c
 #undef BCAST
 			const int idx = firstTri + base + k;
 			bool all4 = true;
+			if(!LANE_MASK || inRange)
 #pragma unroll
 			for(int l = 0; l < 4; l++) {
 				const float det = Q.d[0][l] * nx + Q.d[1][l] * ny + Q.d[2][l] * nz;
