@@ -277,6 +277,10 @@ int snail_account_primary(SnailScene *, const float cam[13], int resx, int resy,
 /* Diagnostic: one sleeping wave that reads the shader-cycle counter and the 100 MHz constant clock `microseconds` apart: d_out2[0] = shader
  * cycles, d_out2[1] = constant-clock ticks; clock = d_out2[0] / d_out2[1] x 100 MHz.  tools/ramp.py samples it beside the frames. */
 int snail_debug_clock_dev(float microseconds, uint64_t *d_out2, void *stream);
+/* Runs the kernels' reciprocal (v_rcp_f32 + one Newton step inside 2^-126 <= |x| < 2^126, the full division outside) on all 2^32 float bit
+ * patterns against the correctly rounded 1.0f / x: out2[0] = results that differ (must be 0), out2[1] = inputs inside that range
+ * (2 * 252 * 2^23).  Blocks the device for a few tens of milliseconds. */
+int snail_debug_recip_check(uint64_t out2[2]);
 
 /* Diagnostic: time per launch of an EMPTY kernel of `blocks` x `threads` (what the workgroup dispatcher alone sustains), averaged
  * over `reps` back-to-back launches on the default stream of the current device.  tools/dispatch_rate.py. */

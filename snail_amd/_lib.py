@@ -32,6 +32,7 @@ SIGNATURES = {
     "snail_scene_download": (_I, [_VP, _VP, _VP]),
     "snail_delay_dev": (_I, [C.c_float, _VP]),
     "snail_debug_clock_dev": (_I, [C.c_float, _VP, _VP]),
+    "snail_debug_recip_check": (_I, [_VP]),
     "snail_debug_dispatch_rate": (_I, [_I, _I, _I, _VP]),
     "snail_trace_primary": (_I, [_VP, _F13, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "snail_trace_frame_packets": (_I, [_VP, _F13, _I, _I, _VP, _VP, _VP, _VP, _VP]),

@@ -131,6 +131,25 @@ __device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f3
 __device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
+// Inv(det) of the hit test (src/triangle.cpp:55; exact IEEE division here and in the oracle).  For every x with biased exponent 1..252
+// (2^-126 <= |x| < 2^126) v_rcp_f32 followed by ONE Newton step in two FMAs is bit-identical to the 11-instruction correctly rounded
+// division sequence -- checked over all 2^32 inputs on the device (tools/micro/recip_check.hip, snail_debug_recip_check): 0 differences
+// inside that range; outside it (denormal or 0 inputs, denormal results, +-inf) the wave takes the full division.
+#ifndef SNAIL_FAST_RECIP
+#define SNAIL_FAST_RECIP 1
+#endif
+__device__ __forceinline__ float recipExact(float x) {
+#if SNAIL_FAST_RECIP
+	const unsigned e = (__float_as_uint(x) & 0x7f800000u) - 0x00800000u;
+	if(__builtin_expect(__builtin_amdgcn_ballot_w64(e >= 0x7e000000u) == 0, 1)) {
+		float r = __builtin_amdgcn_rcpf(x);
+		const float err = __builtin_fmaf(-x, r, 1.0f);
+		return __builtin_fmaf(err, r, r);
+	}
+#endif
+	return 1.0f / x;
+}
+
 template <int M> __device__ __forceinline__ float Min(float a, float b) {
 	if(M == M_EXACT) return a < b ? a : b;
 	return vmin(a, b);
@@ -401,7 +420,7 @@ __device__ __forceinline__ bool leafShared(const uint4 *__restrict__ tris, int c
 					bool test = ((uvmax <= 0.0f) | (uvmin >= 0.0f)) & inRange;
 					if(MASK) test = test & (((mask4 >> l) & 1u) != 0);
 					if(test) {
-						const float idet = 1.0f / det;
+						const float idet = recipExact(det);
 						const float dd = idet * tmul;
 						if(dd < Q.dist[l] && dd > 0.0f) {
 							Q.dist[l] = dd; tid[l] = idx;
@@ -447,7 +466,7 @@ __device__ __forceinline__ void leafPerRay(const uint4 *__restrict__ tris, int c
 			bool test = ((uvmax <= 0.0f) | (uvmin >= 0.0f)) & inRange;
 			if(MASK) test = test & (((mask4 >> l) & 1u) != 0);
 			if(test) {
-				const float idet = 1.0f / det;
+				const float idet = recipExact(det);
 				const float dd = idet * tmul;
 				if(dd < Q.dist[l] && dd > 0.0f) {
 					Q.dist[l] = dd; tid[l] = firstTri + k;
@@ -2067,6 +2086,22 @@ __global__ __launch_bounds__(64) void k_clock(unsigned ticks, unsigned long long
 	if(threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
 }
 
+// exhaustive check of recipExact() against the correctly rounded division: thread = one float bit pattern (a wave holds 64 consecutive
+// patterns, i.e. one exponent, so every in-range input goes through the short sequence); out[0] = results that differ bitwise (NaN = one
+// class), out[1] = inputs inside the short sequence's range
+__global__ __launch_bounds__(256) void k_recip_check(unsigned base, unsigned long long *out) {
+	const unsigned bits = base + blockIdx.x * 256u + threadIdx.x;
+	const float x = __uint_as_float(bits);
+	const float ref = 1.0f / x, got = recipExact(x);
+	const bool same = (ref != ref) ? (got != got) : __float_as_uint(ref) == __float_as_uint(got);
+	const bool inside = ((bits & 0x7f800000u) - 0x00800000u) < 0x7e000000u;
+	const u64 bad = __builtin_amdgcn_ballot_w64(!same), in = __builtin_amdgcn_ballot_w64(inside);
+	if((threadIdx.x & 63) == 0) {
+		if(bad) atomicAdd(&out[0], (unsigned long long)__builtin_popcountll(bad));
+		if(in) atomicAdd(&out[1], (unsigned long long)__builtin_popcountll(in));
+	}
+}
+
 // diagnostic: what the workgroup dispatcher alone sustains (tools/dispatch_rate.py)
 __global__ void k_nop(int *sink) { if(sink && threadIdx.x == 0 && blockIdx.x == 0x7fffffff) *sink = 1; }
 
@@ -2990,6 +3025,19 @@ int snail_debug_clock_dev(float microseconds, uint64_t *dOut2, void *stream) {
 	if(!(microseconds > 0.0f) || microseconds > 10000.0f || !dOut2) { snail_set_error("snail_debug_clock_dev: bad arguments"); return 1; }
 	hipLaunchKernelGGL(dev::k_clock, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned)(microseconds * 100.0f), (unsigned long long *)dOut2);
 	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+int snail_debug_recip_check(uint64_t out2[2]) {
+	if(!out2) { snail_set_error("snail_debug_recip_check: bad arguments"); return 1; }
+	unsigned long long *d = nullptr;
+	HIP_TRY(hipMalloc(&d, 16));
+	HIP_TRY(hipMemset(d, 0, 16));
+	for(unsigned part = 0; part < 256; part++) hipLaunchKernelGGL(dev::k_recip_check, dim3(1u << 16), dim3(256), 0, 0, part << 24, d);
+	hipError_t e = hipDeviceSynchronize();
+	if(e == hipSuccess) e = hipMemcpy(out2, d, 16, hipMemcpyDeviceToHost);
+	(void)hipFree(d);
+	HIP_TRY(e);
 	return 0;
 }
 
