@@ -1179,10 +1179,10 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 		const float p0 = G.tright[0] * tposx + (G.tup[0] * tposy + G.txyz[0][l]);
 		const float p1 = G.tright[1] * tposx + (G.tup[1] * tposy + G.txyz[1][l]);
 		const float p2 = G.tright[2] * tposx + (G.tup[2] * tposy + G.txyz[2][l]);
-		const float rs = 1.0f / __builtin_sqrtf(p0 * p0 + p1 * p1 + p2 * p2);
+		const float rs = recipExact(__builtin_sqrtf(p0 * p0 + p1 * p1 + p2 * p2));
 		Q.d[0][l] = p0 * rs; Q.d[1][l] = p1 * rs; Q.d[2][l] = p2 * rs;
 #pragma unroll
-		for(int c = 0; c < 3; c++) Q.id[c][l] = 1.0f / (Q.d[c][l] + 0.00000001f); // SafeInv (src/rtbase.h:117-120)
+		for(int c = 0; c < 3; c++) Q.id[c][l] = recipExact(Q.d[c][l] + 0.00000001f); // SafeInv (src/rtbase.h:117-120)
 		Q.dist[l] = __builtin_inff();											   // src/scene_trace.cpp:112-115
 	}
 	int tid[4] = {0, 0, 0, 0};
@@ -1473,7 +1473,7 @@ __device__ __forceinline__ void loadSamples(const ShadeArgs &A, const PacketPos 
 			const float p0 = A.g.tright[0] * tposx + (A.g.tup[0] * tposy + A.g.txyz[0][l]);
 			const float p1 = A.g.tright[1] * tposx + (A.g.tup[1] * tposy + A.g.txyz[1][l]);
 			const float p2 = A.g.tright[2] * tposx + (A.g.tup[2] * tposy + A.g.txyz[2][l]);
-			const float rs = 1.0f / __builtin_sqrtf(p0 * p0 + p1 * p1 + p2 * p2);
+			const float rs = recipExact(__builtin_sqrtf(p0 * p0 + p1 * p1 + p2 * p2));
 			d[0][l] = p0 * rs; d[1][l] = p1 * rs; d[2][l] = p2 * rs;
 #pragma unroll
 			for(int c = 0; c < 3; c++) org[c][l] = A.g.org[c];
@@ -1651,7 +1651,7 @@ __global__ __launch_bounds__(64) void k_final(ShadeArgs A) {
 			for(int c = 0; c < 3; c++) {
 				rd[c][l] = on ? d[c][l] : 0.0f;
 				ro[c][l] = on ? d[c][l] * tl + A.g.org[c] : 0.0f;
-				ri[c][l] = 1.0f / (rd[c][l] + 0.00000001f);
+				ri[c][l] = recipExact(rd[c][l] + 0.00000001f);
 			}
 			rdist[l] = on ? inf : -inf;
 			sel |= on ? (1u << l) : 0u;
@@ -1687,7 +1687,7 @@ __global__ __launch_bounds__(64) void k_final(ShadeArgs A) {
 				const float r = d[c][l] - S.nrm[c][l] * dt2;
 				rd[c][l] = S.hit[l] ? r : 0.0f;
 				ro[c][l] = S.hit[l] ? S.pos[c][l] + r * 0.001f : 0.0f;
-				ri[c][l] = 1.0f / (rd[c][l] + 0.00000001f);
+				ri[c][l] = recipExact(rd[c][l] + 0.00000001f);
 			}
 			rdist[l] = S.hit[l] ? inf : -inf; // src/scene_trace.cpp:112-115
 			sel |= S.hit[l] ? (1u << l) : 0u;
