@@ -344,6 +344,96 @@ __device__ __forceinline__ TriTerms triTerms(const Tri &t, float ox, float oy, f
 	return r;
 }
 
+// ---- leaf of a NARROW closest-hit packet range --------------------------------------------------------------------------------
+// A lane holds one SSE quad = 4 rays, so intersecting a triangle costs 4 x 23 VALU instructions whatever the width of [first, last] --
+// and at the leaves that range is narrow (atrium frame: 43 % of the leaf bodies see <= 16 quads, 70 % <= 32; stress-1M: 77 % / 94 %;
+// tests/range_hist.py).  For width <= 64 / (4 / R) the rays of the range are spread over the wave, R rays per lane (R = 1: lane j <- quad
+// first + j / 4, ray j % 4;  R = 2: lane j <- quad first + j / 2, rays 2 (j % 2), 2 (j % 2) + 1), through the LDS crossbar (ds_bpermute_b32: no
+// VALU issue, no LDS memory): 16 crossbar reads + 12 (8) selects in, 8 reads + 8 selects out.  Every ray sees exactly the operations of
+// the wide form in the same order; the triangles are taken in the same order; lanes past the range's last ray never accept; a leaf
+// whose triangles all fail the packet-level cull returns before anything moves.  Not for masked / any-hit / barycentric-tracking
+// packets and not for leaves of more than 64 triangles (they keep the wide form).
+// (Control flow: the early return and the unconditional write-back are what this compiler can place beside the hand-written node
+// loop; a flag-guarded gather or a "nothing was hit" early-out end in "illegal VGPR to SGPR copy" on the loop's operands.)
+#ifndef SNAIL_LEAF_COMPACT
+#define SNAIL_LEAF_COMPACT 1 // 0 = every leaf in the wide form (A/B measurements)
+#endif
+__device__ __forceinline__ float selLanes(float a, float b, u64 lanesOfB) {
+	float r;
+	asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(lanesOfB));
+	return r;
+}
+__device__ __forceinline__ float xbar(int byteAddr, float x) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byteAddr, __float_as_int(x))); }
+template <int R> struct NarrowRays {
+	float d[3][R], dist[R];
+	int tid[R];
+};
+// lane j's R rays out of the quad lanes (all lanes active)
+template <int R> __device__ __forceinline__ void narrowGather(const float (&q)[4], int srcAddr, float (&out)[R]) {
+	const float a0 = xbar(srcAddr, q[0]), a1 = xbar(srcAddr, q[1]), a2 = xbar(srcAddr, q[2]), a3 = xbar(srcAddr, q[3]);
+	if(R == 1) out[0] = selLanes(selLanes(a0, a1, 0xaaaaaaaaaaaaaaaaull), selLanes(a2, a3, 0xaaaaaaaaaaaaaaaaull), 0xccccccccccccccccull);
+	else { out[0] = selLanes(a0, a2, 0xaaaaaaaaaaaaaaaaull); out[R - 1] = selLanes(a1, a3, 0xaaaaaaaaaaaaaaaaull); }
+}
+template <int R, int M>
+__device__ __forceinline__ void leafSharedNarrow(const uint4 *__restrict__ tris, int count, int firstTri, int lane, int first, int last,
+												 const float (&org)[3][4], Quad &Q, int (&tid)[4], const Interval &iv, Counters &st) {
+	constexpr int LPQ = 4 / R;                      // lanes per quad
+	const int width = last - first + 1;             // count <= 64: one chunk
+	const bool inRange = lane >= first && lane <= last;
+	const bool live = lane < width * LPQ;           // this lane holds rays of the range
+	st.leaves++;
+	st.fetched += (unsigned)count;
+	Tri t = {};
+	TriTerms tt = {};
+	bool pass = false;
+	if(lane < count) {
+		t = loadTriVector(tris, firstTri + lane);
+		tt = triTerms(t, org[0][0], org[1][0], org[2][0]);
+		pass = triTestInterval<M>(t, iv);
+	}
+	u64 keep = __builtin_amdgcn_ballot_w64(pass);
+	if(keep == 0) return;
+	NarrowRays<R> N;
+	const int srcAddr = (first + lane / LPQ) * 4;   // lanes past the range read some quad's rays and never accept
+#pragma unroll
+	for(int c = 0; c < 3; c++) narrowGather<R>(Q.d[c], srcAddr, N.d[c]);
+	narrowGather<R>(Q.dist, srcAddr, N.dist);
+#pragma unroll
+	for(int i = 0; i < R; i++) N.tid[i] = -1;
+	do {
+		const int k = __builtin_ctzll(keep);
+		keep &= keep - 1;
+		const float nx = xbar(k * 4, t.n[0]), ny = xbar(k * 4, t.n[1]), nz = xbar(k * 4, t.n[2]);
+		const float ax = xbar(k * 4, tt.t0v[0]), ay = xbar(k * 4, tt.t0v[1]), az = xbar(k * 4, tt.t0v[2]);
+		const float bx = xbar(k * 4, tt.t1v[0]), by = xbar(k * 4, tt.t1v[1]), bz = xbar(k * 4, tt.t1v[2]);
+		const float tmul = xbar(k * 4, tt.tmul);
+		const int idx = firstTri + k;
+		if(live)
+#pragma unroll
+			for(int i = 0; i < R; i++) { // src/triangle.cpp:44-60
+				const float det = N.d[0][i] * nx + N.d[1][i] * ny + N.d[2][i] * nz;
+				const float v = N.d[0][i] * ax + N.d[1][i] * ay + N.d[2][i] * az;
+				const float u = N.d[0][i] * bx + N.d[1][i] * by + N.d[2][i] * bz;
+				const float duv = det - u - v;
+				const float uvmin = Min3<M>(u, v, duv), uvmax = Max3<M>(u, v, duv);
+				if((uvmax <= 0.0f) | (uvmin >= 0.0f)) {
+					const float dd = recipExact(det) * tmul;
+					if(dd < N.dist[i] && dd > 0.0f) { N.dist[i] = dd; N.tid[i] = idx; }
+				}
+			}
+		st.intersects += width;
+	} while(keep);
+	// back to the quad lanes (lanes outside the range read garbage and keep their own values)
+	const int q = lane - first;
+#pragma unroll
+	for(int l = 0; l < 4; l++) {
+		const int src = (q * LPQ + l / R) * 4;
+		const float nd = xbar(src, N.dist[l % R]);
+		const int nt = __builtin_amdgcn_ds_bpermute(src, N.tid[l % R]);
+		if(inRange && nt >= 0) { Q.dist[l] = nd; tid[l] = nt; }
+	}
+}
+
 // ---- leaf, shared origin (src/bvh/traverse.cpp:34-56 / :98-124): lanes 0..chunk-1 each take one triangle (packet-level
 // cull + shared-origin terms in parallel), survivors are broadcast one by one to the whole packet.  Returns true when a
 // shadow packet is fully occluded (the walk ends, src/bvh/traverse.cpp:117-121).
@@ -357,6 +447,18 @@ __device__ __forceinline__ bool leafShared(const uint4 *__restrict__ tris, int c
 	const float inf = __builtin_inff();
 	const bool inRange = lane >= first && lane <= last;
 	const int width = last - first + 1;
+	if(SNAIL_LEAF_COMPACT && !SHADOW && !MASK && !BARY) {
+		// (first / last come out of an asm statement with vector outputs too, which makes them divergent in the compiler's eyes: a branch
+		// on them would drag every counter into VGPRs)
+		const int widthU = __builtin_amdgcn_readfirstlane(width);
+		const int countU = __builtin_amdgcn_readfirstlane(count);
+		if(widthU <= 32 && countU <= 64) {
+			const int firstU = __builtin_amdgcn_readfirstlane(first);
+			if(widthU <= 16) leafSharedNarrow<1, M>(tris, countU, firstTri, lane, firstU, firstU + widthU - 1, org, Q, tid, iv, st);
+			else leafSharedNarrow<2, M>(tris, countU, firstTri, lane, firstU, firstU + widthU - 1, org, Q, tid, iv, st);
+			return false;
+		}
+	}
 	const u64 curRange = rangeMask(first, last);
 	st.leaves++;
 	for(int base = 0; base < count; base += 64) {
@@ -1122,6 +1224,15 @@ struct PrimaryArgs {
 	int *defer;		// [0] = count, [1] = finished blocks of the M_EXACT pass, [2..] = frame * nSlots + logical index of deferred packets
 };
 
+typedef const PrimaryArgs __attribute__((address_space(4))) *PrimaryArgsK;
+typedef const FrameOut __attribute__((address_space(4))) *FrameOutK;
+// the kernels that run primaryPacket take ONE argument, the PrimaryArgs by value: it sits at offset 0 of the kernel-argument segment
+__device__ __forceinline__ PrimaryArgsK lateArgs() {
+	PrimaryArgsK p = (PrimaryArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+	asm volatile("" : "+s"(p));
+	return p;
+}
+
 #define LDS_FLOATS_PER_WAVE (64 * 12 + 64)
 
 // Block -> packet mapping of the primary kernel.  ONE WAVE PER BLOCK: packet costs vary ~10x (p5 66 K .. max
@@ -1143,7 +1254,6 @@ template <bool DEEP, bool EXACTPASS, bool DIAG = false>
 __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li, const int fi, float *lds) {
 	const int lane = threadIdx.x & 63;
 	const GenConst &G = A.g[fi];
-	const FrameOut &F = A.out[fi];
 
 	int px, py, pidx;
 	if(A.packetXY) {
@@ -1208,52 +1318,56 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 		else walkSharedAsm<false, false, true, false, false, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, 0);
 	} else if(mode == M_COH) walkSharedAsm<false, true, false, false, false, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, oct);
 	else walkSharedAsm<false, false, false, false, false, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, 0);
-	if(F.u || F.v) finalBarycentrics(A.tris, org, Q, tid, bu, bv); // (the staged shading pipeline asks for t and triId only)
+	// The epilogue reads its arguments (output planes, layout) through an opaque copy of the kernel-argument pointer: otherwise their loads
+	// are hoisted to the top of the kernel and ~20 SGPRs stay live across the walk, whose hand-written loop already pins 24.
+	const PrimaryArgsK E = lateArgs();
+	const FrameOutK F = &E->out[fi];
+	if(F->u || F->v) finalBarycentrics(E->tris, org, Q, tid, bu, bv); // (the staged shading pipeline asks for t and triId only)
 
-	flushStats(A.stats, st, 256u, lane);
-	if(A.slotCost && fi == 0 && lane == 0) A.slotCost[li] = (int)st.iters;
-	if(DIAG && A.cost && lane == 0) {
+	flushStats(E->stats, st, 256u, lane);
+	if(E->slotCost && fi == 0 && lane == 0) E->slotCost[li] = (int)st.iters;
+	if(DIAG && E->cost && lane == 0) {
 		const u64 tEnd = __builtin_amdgcn_s_memtime();
-		unsigned *c = A.cost + (size_t)pidx * 8;
+		unsigned *c = E->cost + (size_t)pidx * 8;
 		c[0] = st.iters; c[1] = st.intersects; c[2] = (unsigned)(tEnd - tStart); c[3] = (unsigned)(tStart >> 6);
 		c[4] = st.fetched; c[5] = st.leaves; c[6] = 0; c[7] = 0;
 	}
 
-	if(F.bgr) { // fused gVals[1] depth shading + ConvColor: c = Inv(t) * (20, 250, 2), bytes B,G,R (same operations as k_shade_depth)
+	if(F->bgr) { // fused gVals[1] depth shading + ConvColor: c = Inv(t) * (20, 250, 2), bytes B,G,R (same operations as k_shade_depth)
 		unsigned bytes[12];
 #pragma unroll
 		for(int l = 0; l < 4; l++) {
 			const float dist = 1.0f / Q.dist[l];
 			bytes[l * 3 + 0] = (unsigned)convChannelW(dist * 2.0f); bytes[l * 3 + 1] = (unsigned)convChannelW(dist * 250.0f); bytes[l * 3 + 2] = (unsigned)convChannelW(dist * 20.0f);
 		}
-		unsigned *o = (unsigned *)(F.bgr + ((size_t)pidx * 256 + (size_t)lane * 4) * 3);
+		unsigned *o = (unsigned *)(F->bgr + ((size_t)pidx * 256 + (size_t)lane * 4) * 3);
 #pragma unroll
 		for(int k = 0; k < 3; k++) o[k] = bytes[4 * k] | (bytes[4 * k + 1] << 8) | (bytes[4 * k + 2] << 16) | (bytes[4 * k + 3] << 24);
 	}
-	if(A.packetXY || A.packetMajor) { // packet-major (Context layout)
+	if(E->packetXY || E->packetMajor) { // packet-major (Context layout)
 		const size_t o = (size_t)pidx * 256 + (size_t)lane * 4;
-		if(F.t) *(float4 *)(F.t + o) = make_float4(Q.dist[0], Q.dist[1], Q.dist[2], Q.dist[3]);
-		if(F.u) *(float4 *)(F.u + o) = make_float4(bu[0], bu[1], bu[2], bu[3]);
-		if(F.v) *(float4 *)(F.v + o) = make_float4(bv[0], bv[1], bv[2], bv[3]);
-		if(F.id) *(int4 *)(F.id + o) = make_int4(tid[0], tid[1], tid[2], tid[3]);
+		if(F->t) *(float4 *)(F->t + o) = make_float4(Q.dist[0], Q.dist[1], Q.dist[2], Q.dist[3]);
+		if(F->u) *(float4 *)(F->u + o) = make_float4(bu[0], bu[1], bu[2], bu[3]);
+		if(F->v) *(float4 *)(F->v + o) = make_float4(bv[0], bv[1], bv[2], bv[3]);
+		if(F->id) *(int4 *)(F->id + o) = make_int4(tid[0], tid[1], tid[2], tid[3]);
 	} else {
 		const int yy = py + ty, xx = px + k4 * 4;
-		const int xlim = min(A.resx, A.x0 + A.w), ylim = min(A.resy, A.y0 + A.h);
+		const int xlim = min(E->resx, E->x0 + E->w), ylim = min(E->resy, E->y0 + E->h);
 		if(yy < ylim) {
-			const size_t o = (size_t)yy * A.resx + xx;
-			if(xx + 3 < xlim && (A.resx & 3) == 0) {
-				if(F.t) *(float4 *)(F.t + o) = make_float4(Q.dist[0], Q.dist[1], Q.dist[2], Q.dist[3]);
-				if(F.u) *(float4 *)(F.u + o) = make_float4(bu[0], bu[1], bu[2], bu[3]);
-				if(F.v) *(float4 *)(F.v + o) = make_float4(bv[0], bv[1], bv[2], bv[3]);
-				if(F.id) *(int4 *)(F.id + o) = make_int4(tid[0], tid[1], tid[2], tid[3]);
+			const size_t o = (size_t)yy * E->resx + xx;
+			if(xx + 3 < xlim && (E->resx & 3) == 0) {
+				if(F->t) *(float4 *)(F->t + o) = make_float4(Q.dist[0], Q.dist[1], Q.dist[2], Q.dist[3]);
+				if(F->u) *(float4 *)(F->u + o) = make_float4(bu[0], bu[1], bu[2], bu[3]);
+				if(F->v) *(float4 *)(F->v + o) = make_float4(bv[0], bv[1], bv[2], bv[3]);
+				if(F->id) *(int4 *)(F->id + o) = make_int4(tid[0], tid[1], tid[2], tid[3]);
 			} else {
 #pragma unroll
 				for(int l = 0; l < 4; l++)
 					if(xx + l < xlim) {
-						if(F.t) F.t[o + l] = Q.dist[l];
-						if(F.u) F.u[o + l] = bu[l];
-						if(F.v) F.v[o + l] = bv[l];
-						if(F.id) F.id[o + l] = tid[l];
+						if(F->t) F->t[o + l] = Q.dist[l];
+						if(F->u) F->u[o + l] = bu[l];
+						if(F->v) F->v[o + l] = bv[l];
+						if(F->id) F->id[o + l] = tid[l];
 					}
 			}
 		}
