@@ -302,6 +302,28 @@ def chain(n: int = 400, ratio: float = 1.2) -> np.ndarray:
     return np.asarray(tris, dtype=F32)
 
 
+def patches(n: int = 6) -> np.ndarray:
+    """Test scene for the narrow-range leaf forms: an n x n board of axis-aligned squares in the plane z = 0 whose sides grow from a few
+    percent of a cell to a whole cell, each tessellated into 2 x 2 x 2 triangles, plus a clump of 100 coincident triangles in front of one cell
+    (tests collapse its subtree into ONE leaf of more than 64 triangles that a narrow range reaches).  Seen head-on at 16 pixels per cell the
+    squares cover 1 .. 64 quads of a packet."""
+    tris = []
+    for j in range(n):
+        for i in range(n):
+            k = j * n + i
+            side = 0.04 + 0.96 * k / (n * n - 1)
+            x0, y0 = i + 0.5 - side / 2, j + 0.5 - side / 2
+            h = side / 2
+            for b in range(2):
+                for a in range(2):
+                    xa, ya = x0 + a * h, y0 + b * h
+                    tris.append([[xa, ya, 0.0], [xa + h, ya, 0.0], [xa + h, ya + h, 0.0]])
+                    tris.append([[xa + h, ya + h, 0.0], [xa, ya + h, 0.0], [xa, ya, 0.0]])
+    for _ in range(100):
+        tris.append([[0.30, 0.30, -0.25], [0.55, 0.32, -0.25], [0.40, 0.52, -0.25]])
+    return np.asarray(tris, dtype=F32)
+
+
 def drop_degenerate(tri_verts: np.ndarray) -> np.ndarray:
     """Apply Object::Repair to an explicit triangle soup (generators can emit zero-area faces)."""
     tv = np.asarray(tri_verts, dtype=F32)
@@ -324,6 +346,8 @@ def scene_by_name(name: str, scenes_dir: str | None = None) -> np.ndarray:
         return drop_degenerate(stress(detail=d))
     if name.startswith("chain"):
         return chain()
+    if name.startswith("patches"):
+        return patches()
     path = name
     if not os.path.exists(path) and scenes_dir:
         path = os.path.join(scenes_dir, name)

@@ -49,6 +49,8 @@ def compare_frames(frame, oracle_out, what):
     ("atrium:0.05", 328, 200),
     ("chain", 256, 144),          # depth-63 tree (second stack register pair) and a > 64-triangle leaf (chunked leaf loop)
     ("stress:0.05", 320, 192),
+    ("patches", 96, 96),          # squares covering 1 .. 64 quads of a packet: the narrow-range leaf forms at every width
+    ("patches", 200, 120),
 ])
 def test_primary_frame_bit_exact(torch_mod, name, resx, resy):
     tv, sc, osc = gpu_scene(name)
@@ -1177,3 +1179,73 @@ def test_hit_reciprocal_equals_ieee_division_for_every_float(torch_mod):
     assert _lib.lib().snail_debug_recip_check(out) == 0
     assert out[0] == 0, "%d of 2^32 reciprocals differ from 1.0f / x" % out[0]
     assert out[1] == 2 * 252 * (1 << 23)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("resx,resy", [(96, 96), (200, 120)])
+def test_big_leaf_under_a_narrow_range(torch_mod, resx, resy):
+    """A hand-made tree, walked by the kernels and by the oracle alike: the SAH tree of the `patches` scene with the subtree of its 100
+    coincident triangles collapsed into ONE leaf (the reference's trees reach such leaves only at BVH::maxDepth, i.e. on the deep-tree
+    walk).  A shallow tree keeps the packet on the hand-written walk, whose narrow-range leaf forms must hand a leaf of more than 64
+    triangles to the chunked wide form."""
+    from snail_amd.bvh import HostBVH
+    from snail_amd.scene import Scene
+    tv, hb, osc = util.scene_pair("patches")
+    nodes = hb.nodes.copy()
+    sub = nodes["sub"].astype(np.int64)
+    is_leaf = (sub & 0x80000000) != 0
+
+    def tris_below(i):
+        if is_leaf[i]:
+            f = int(sub[i] & 0x7fffffff); return list(range(f, f + int(nodes["aux"][i])))
+        c = int(sub[i]); return tris_below(c) + tris_below(c + 1)
+
+    clump = set(np.nonzero((hb.tris["a"][:, 2] == np.float32(-0.25)))[0].tolist())
+    assert len(clump) == 100
+    # the highest node whose triangles are all clump triangles and contiguous: becomes the leaf
+    best = None
+    for i in range(len(nodes)):
+        t = tris_below(i)
+        if set(t) <= clump and len(t) > 64 and sorted(t) == list(range(min(t), min(t) + len(t))):
+            if best is None or len(t) > best[1]: best = (i, len(t), min(t))
+    assert best is not None, "no contiguous clump subtree of more than 64 triangles"
+    i, n, first = best
+    nodes["sub"][i] = np.uint32(0x80000000 | first); nodes["aux"][i] = n        # (the now unreachable nodes stay in the array)
+    # unreachable nodes are rejected by snail_scene_create? -> compact the array instead
+    keep = []
+    def reach(k):
+        keep.append(k)
+        if (int(nodes["sub"][k]) & 0x80000000) == 0:
+            c = int(nodes["sub"][k]); reach(c); reach(c + 1)
+    reach(0)
+    order = sorted(keep)
+    # children must stay adjacent: BFS re-layout
+    new_nodes = np.zeros(len(order), dtype=nodes.dtype); slot = {0: 0}; nxt = 1; queue = [0]
+    while queue:
+        k = queue.pop(0)
+        new_nodes[slot[k]] = nodes[k]
+        if (int(nodes[k]["sub"]) & 0x80000000) == 0:
+            c = int(nodes[k]["sub"]); slot[c] = nxt; slot[c + 1] = nxt + 1
+            new_nodes[slot[k]]["sub"] = nxt; nxt += 2; queue += [c, c + 1]
+    depth = 0
+    def dep(k, d):
+        nonlocal depth; depth = max(depth, d)
+        if (int(new_nodes[k]["sub"]) & 0x80000000) == 0:
+            c = int(new_nodes[k]["sub"]); dep(c, d + 1); dep(c + 1, d + 1)
+    dep(0, 1)
+    assert depth <= 62 and int(new_nodes["aux"][(new_nodes["sub"] & 0x80000000) != 0].max()) == n
+    hb2 = HostBVH(hb.tris, new_nodes, depth, hb.perm)
+    osc2 = O.OracleScene.__new__(O.OracleScene)
+    osc2.tris = np.ascontiguousarray(hb.tris.view(O.TRI_DTYPE)); osc2.nodes = np.ascontiguousarray(new_nodes.view(O.NODE_DTYPE)); osc2.depth = depth; osc2.perm = hb.perm
+    sc = Scene(hb2, 0)
+    cam = util.camera_for("patches", tv)
+    stats = sc.new_stats()
+    frame = sc.trace_primary(cam, resx, resy, stats=stats)
+    torch_mod.cuda.synchronize()
+    ref = osc2.render_primary(cam.as_array13(), resx, resy, mode=O.MODE_IEEE)
+    compare_frames(frame, ref, "patches, collapsed clump %dx%d" % (resx, resy))
+    assert np.array_equal(stats.cpu().numpy().astype(np.uint64), ref[4]), (stats.cpu().numpy(), ref[4])
+    hit_clump = np.isin(ref[3][np.isfinite(ref[0])], np.arange(first, first + n)).sum()
+    assert hit_clump > 0
+    sc.close()
+
