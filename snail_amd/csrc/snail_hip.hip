@@ -355,6 +355,9 @@ __device__ __forceinline__ TriTerms triTerms(const Tri &t, float ox, float oy, f
 // packets and not for leaves of more than 64 triangles (they keep the wide form).
 // (Control flow: the early return and the unconditional write-back are what this compiler can place beside the hand-written node
 // loop; a flag-guarded gather or a "nothing was hit" early-out end in "illegal VGPR to SGPR copy" on the loop's operands.)
+#ifndef SNAIL_LEAF_COMPACT_SHADOW
+#define SNAIL_LEAF_COMPACT_SHADOW 1 // the narrow-range form for any-hit packets too
+#endif
 #ifndef SNAIL_LEAF_COMPACT
 #define SNAIL_LEAF_COMPACT 1 // 0 = every leaf in the wide form (A/B measurements)
 #endif
@@ -434,6 +437,54 @@ __device__ __forceinline__ void leafSharedNarrow(const uint4 *__restrict__ tris,
 	}
 }
 
+// the same for an any-hit (shadow) packet: a lane's rays carry their distance only (negative = masked, -inf once occluded); never taken when
+// the range is the whole packet (the "every quad occluded" early-out of src/bvh/traverse.cpp:117-121 needs the wide form's bookkeeping)
+template <int R, int M>
+__device__ __forceinline__ void leafSharedNarrowShadow(const uint4 *__restrict__ tris, int count, int firstTri, int lane, int first, int last,
+													   const float (&org)[3][4], Quad &Q, const Interval &iv, Counters &st) {
+	constexpr int LPQ = 4 / R;
+	const float inf = __builtin_inff();
+	const int width = last - first + 1;             // count <= 64: one chunk
+	const bool inRange = lane >= first && lane <= last;
+	const bool live = lane < width * LPQ;
+	st.leaves++;
+	st.fetched += (unsigned)count;
+	const bool mine = lane < count;
+	const Tri t = loadTriVector(tris, firstTri + (mine ? lane : 0));
+	const TriTerms tt = triTerms(t, org[0][0], org[1][0], org[2][0]);
+	u64 keep = __builtin_amdgcn_ballot_w64(mine & triTestInterval<M>(t, iv));
+	if(keep == 0) return;
+	float nd[3][R], ndist[R];
+	const int srcAddr = (first + lane / LPQ) * 4;
+#pragma unroll
+	for(int c = 0; c < 3; c++) narrowGather<R>(Q.d[c], srcAddr, nd[c]);
+	narrowGather<R>(Q.dist, srcAddr, ndist);
+	do {
+		const int k = __builtin_ctzll(keep);
+		keep &= keep - 1;
+		const float nx = xbar(k * 4, t.n[0]), ny = xbar(k * 4, t.n[1]), nz = xbar(k * 4, t.n[2]);
+		const float ax = xbar(k * 4, tt.t0v[0]), ay = xbar(k * 4, tt.t0v[1]), az = xbar(k * 4, tt.t0v[2]);
+		const float bx = xbar(k * 4, tt.t1v[0]), by = xbar(k * 4, tt.t1v[1]), bz = xbar(k * 4, tt.t1v[2]);
+		const float tmul = xbar(k * 4, tt.tmul);
+#pragma unroll
+		for(int i = 0; i < R; i++) { // src/triangle.cpp:91-98
+			const float det = nd[0][i] * nx + nd[1][i] * ny + nd[2][i] * nz;
+			const float v = nd[0][i] * ax + nd[1][i] * ay + nd[2][i] * az;
+			const float u = nd[0][i] * bx + nd[1][i] * by + nd[2][i] * bz;
+			bool test = (Min<M>(u, v) >= 0.0f) & (u + v <= det);
+			test = test & (tmul > 0.0f) & (tmul < ndist[i] * det);
+			if(live && test) ndist[i] = -inf;
+		}
+		st.intersects += width;
+	} while(keep);
+	const int q = lane - first;
+#pragma unroll
+	for(int l = 0; l < 4; l++) {
+		const float d = xbar((q * LPQ + l / R) * 4, ndist[l % R]);
+		if(inRange) Q.dist[l] = d;
+	}
+}
+
 // ---- leaf, shared origin (src/bvh/traverse.cpp:34-56 / :98-124): lanes 0..chunk-1 each take one triangle (packet-level
 // cull + shared-origin terms in parallel), survivors are broadcast one by one to the whole packet.  Returns true when a
 // shadow packet is fully occluded (the walk ends, src/bvh/traverse.cpp:117-121).
@@ -456,6 +507,15 @@ __device__ __forceinline__ bool leafShared(const uint4 *__restrict__ tris, int c
 			const int firstU = __builtin_amdgcn_readfirstlane(first);
 			if(widthU <= 16) leafSharedNarrow<1, M>(tris, countU, firstTri, lane, firstU, firstU + widthU - 1, org, Q, tid, iv, st);
 			else leafSharedNarrow<2, M>(tris, countU, firstTri, lane, firstU, firstU + widthU - 1, org, Q, tid, iv, st);
+			return false;
+		}
+	}
+	if(SNAIL_LEAF_COMPACT_SHADOW && SHADOW && !MASK && !BARY) {
+		const int widthU = __builtin_amdgcn_readfirstlane(width);
+		const int countU = __builtin_amdgcn_readfirstlane(count);
+		if(widthU <= 16 && widthU < size && countU <= 64) {   // (one ray per lane only: the two-ray form takes these kernels past 80 VGPRs)
+			const int firstU = __builtin_amdgcn_readfirstlane(first);
+			leafSharedNarrowShadow<1, M>(tris, countU, firstTri, lane, firstU, firstU + widthU - 1, org, Q, iv, st);
 			return false;
 		}
 	}
@@ -1718,7 +1778,7 @@ __device__ __forceinline__ void lightPacket(const ShadeArgs &A, const int li, co
 }
 
 template <bool DEEP, int SRC>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_light(ShadeArgs A) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_light(ShadeArgs A) {
 	__shared__ float lds[LDS_FLOATS_PER_WAVE];
 	lightPacket<DEEP, SRC, false>(A, interleave16((int)blockIdx.x), (int)blockIdx.y, lds);
 }
@@ -2055,7 +2115,7 @@ __device__ __forceinline__ void shadowPacket(const RaysArgs &A, const int p, flo
 	if(live) *(float4 *)(A.distance + q * 4) = make_float4(Q.dist[0], Q.dist[1], Q.dist[2], Q.dist[3]);
 }
 template <bool DEEP>
-__global__ __launch_bounds__(64) void k_shadow(RaysArgs A) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_shadow(RaysArgs A) {
 	__shared__ float lds[LDS_FLOATS_PER_WAVE];
 	shadowPacket<DEEP, false>(A, interleave16((int)blockIdx.x), lds);
 }
