@@ -1031,10 +1031,11 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 SLAB("0", NX, FX, NY, FY, NZ, FZ) TAIL("0", "s0") SLAB("1", NX, FX, NY, FY, NZ, FZ) TAIL("1", "s1")                       \
 				 SLAB("2", NX, FX, NY, FY, NZ, FZ) TAIL("2", "s2") SLAB("3", NX, FX, NY, FY, NZ, FZ) TAIL("3", "s3")                       \
 				 " v_max_f32 %[s2], %[s2], %[s3]\n v_max3_f32 %[s0], %[s0], %[s1], %[s2]\n"                                                \
-				 " v_cmp_le_f32 vcc, 0, %[s0]\n"                                                                                           \
-				 " s_and_b64 %[alive], vcc, exec\n s_cbranch_scc0 L_fail_%=\n"                                                             \
-				 " s_ff1_i32_b64 %[first], %[alive]\n s_flbit_i32_b64 %[last], %[alive]\n s_xor_b32 %[last], %[last], 63\n"                \
-				 " s_mov_b64 exec, %[alive]\n"                                                                                             \
+				 SNAIL_EXP_PAD                                                                                                             \
+				 " v_cmp_le_f32 vcc, 0, %[s0]\n" /* EXEC = the parent's survivors: VCC has no bit outside them, VCC IS the new survivor set */ \
+				 " s_cbranch_vccz L_fail_%=\n"                                                                                             \
+				 " s_ff1_i32_b64 %[first], vcc\n s_flbit_i32_b64 %[last], vcc\n s_xor_b32 %[last], %[last], 63\n"                          \
+				 " s_mov_b64 exec, vcc\n"                                                                                                  \
 				 " s_cmp_lt_i32 " SUB ", 0\n s_cbranch_scc1 L_leaf" X "_%=\n"                                                               \
 				 " s_lshl_b32 %[off], %[last], 6\n s_or_b32 %[off], %[off], %[first]\n s_lshl_b32 %[off], %[off], 20\n"                    \
 				 " s_or_b32 %[topw], %[off], %[fl]\n"                                                                                      \
