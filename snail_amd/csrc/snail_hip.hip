@@ -1025,7 +1025,7 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 " s_lshr_b32 %[cur], %[sign16], " AUX "\n s_xor_b32 %[cur], %[cur], " AUX "\n s_bfe_u32 %[cur], %[cur], 0x10010\n"         \
 				 " s_add_u32 %[fl], " SUB ", 1\n s_sub_u32 %[fl], %[fl], %[cur]\n" /* far child */                                          \
 				 " s_add_u32 %[cur], " SUB ", %[cur]\n" /* near child */                                                                    \
-				 " s_cmp_lt_i32 " SUB ", 0\n s_cselect_b32 %[cur], 0, %[cur]\n s_lshl_b32 %[off], %[cur], 5\n"                               \
+				 " s_lshl_b32 %[off], %[cur], 5\n" /* a leaf: firstTri (+1) << 5, inside the padded node buffer (nodeBufferRecords) */       \
 				 " s_load_dwordx8 " OTHERSET ", %[base], %[off]\n"                                                                         \
 				 PRE(NX, FX, NY, FY, NZ, FZ)                                                                                               \
 				 SLAB("0", NX, FX, NY, FY, NZ, FZ) TAIL("0", "s0") SLAB("1", NX, FX, NY, FY, NZ, FZ) TAIL("1", "s1")                       \
@@ -1039,8 +1039,8 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 " s_cmp_lt_i32 " SUB ", 0\n s_cbranch_scc1 L_leaf" X "_%=\n"                                                               \
 				 " s_lshl_b32 %[off], %[last], 6\n s_or_b32 %[off], %[off], %[first]\n s_lshl_b32 %[off], %[off], 20\n"                    \
 				 " s_or_b32 %[topw], %[off], %[fl]\n"                                                                                      \
-				 " s_mov_b32 m0, %[sp]\n v_writelane_b32 %[stkN], %[topw], m0\n"                                                           \
-				 " s_add_u32 %[sp], %[sp], 1\n"                                                                                            \
+				 " v_writelane_b32 %[stkN], %[topw], m0\n" /* m0 = sp throughout this statement */                                                           \
+				 " s_add_u32 m0, m0, 1\n"                                                                                            \
 				 " s_lshl_b32 %[off], %[fl], 5\n"                                                                                          \
 				 " s_waitcnt lgkmcnt(0)\n"                                                                                                 \
 				 " s_load_dwordx8 s[68:75], %[base], %[off]\n" /* the far child is the new top entry */                                    \
@@ -1048,19 +1048,20 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 "L_leaf" X "_%=:\n s_mov_b32 %[leafSub], " SUB "\n s_mov_b32 %[leafAux], " AUX "\n s_waitcnt lgkmcnt(0)\n s_branch L_end_%=\n"
 // set A = s[84:91] (planes NXA.., sub s90, aux s91), set B = s[76:83] (planes NXB.., sub s82, aux s83)
 #define SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)                 \
-	asm volatile("L_entry_%=:\n"                                                                                                           \
-				 " s_cmp_eq_u32 %[sp], 0\n s_cbranch_scc1 L_done_%=\n"                                                                     \
-				 " s_sub_u32 %[off], %[sp], 1\n"                                                                                           \
+	asm volatile(" s_mov_b32 m0, %[sp]\n"                                                                                                 \
+				 "L_entry_%=:\n"                                                                                                           \
+				 " s_cmp_eq_u32 m0, 0\n s_cbranch_scc1 L_done_%=\n"                                                                     \
+				 " s_sub_u32 %[off], m0, 1\n"                                                                                           \
 				 " v_readlane_b32 %[topw], %[stkN], %[off]\n"                                                                              \
 				 " s_and_b32 %[cur], %[topw], 0xfffff\n s_lshl_b32 %[off], %[cur], 5\n"                                                    \
 				 " s_load_dwordx8 s[68:75], %[base], %[off]\n"                                                                             \
 				 "L_pop_%=:\n" /* sp > 0, topw = the top entry, T = its record (requested) */                                              \
-				 " s_sub_u32 %[sp], %[sp], 1\n" CNTPOP                                                                                     \
+				 " s_sub_u32 m0, m0, 1\n" CNTPOP                                                                                     \
 				 " s_bfe_u32 %[first], %[topw], 0x60014\n s_lshr_b32 %[last], %[topw], 26\n"                                               \
 				 " s_sub_u32 %[width], %[last], %[first]\n"                                                                                \
 				 " s_bfm_b64 exec, %[width], %[first]\n s_bitset1_b64 exec, %[last]\n"                                                     \
-				 " s_cmp_eq_u32 %[sp], 0\n s_cbranch_scc1 L_last_%=\n"                                                                     \
-				 " s_sub_u32 %[off], %[sp], 1\n"                                                                                           \
+				 " s_cmp_eq_u32 m0, 0\n s_cbranch_scc1 L_last_%=\n"                                                                     \
+				 " s_sub_u32 %[off], m0, 1\n"                                                                                           \
 				 " v_readlane_b32 %[topw], %[stkN], %[off]\n"                                                                              \
 				 " s_and_b32 %[cur], %[topw], 0xfffff\n s_lshl_b32 %[off], %[cur], 5\n"                                                    \
 				 " s_waitcnt lgkmcnt(0)\n" SNAIL_A_FROM_T                                                                                  \
@@ -1071,9 +1072,9 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 SNAIL_PF_VISIT("A", "B", "s[76:83]", "s90", "s91", PRE, SLAB, TAIL, CNTVISIT, NXA, FXA, NYA, FYA, NZA, FZA)                \
 				 SNAIL_PF_VISIT("B", "A", "s[84:91]", "s82", "s83", PRE, SLAB, TAIL, CNTVISIT, NXB, FXB, NYB, FYB, NZB, FZB)                \
 				 "L_fail_%=:\n"                                                                                                            \
-				 " s_cmp_eq_u32 %[sp], 0\n s_cbranch_scc0 L_pop_%=\n"                                                                      \
+				 " s_cmp_eq_u32 m0, 0\n s_cbranch_scc0 L_pop_%=\n"                                                                      \
 				 "L_done_%=:\n s_mov_b32 %[leafSub], 0\n s_mov_b32 %[leafAux], 0\n s_waitcnt lgkmcnt(0)\n"                                  \
-				 "L_end_%=:\n s_mov_b64 exec, -1\n"                                                                                        \
+				 "L_end_%=:\n s_mov_b64 exec, -1\n s_mov_b32 %[sp], m0\n"                                                                                        \
 				 : [sp] "+s"(sp), [first] "+s"(first), [last] "+s"(last), [cnt] "+s"(cnt), [stkN] "+v"(stkN), [stkF] "+v"(stkF),           \
 				   [leafSub] "=&s"(leafSub), [leafAux] "=&s"(leafAux), [cur] "=&s"(sCur), [fl] "=&s"(sFl), [off] "=&s"(sOff),              \
 				   [width] "=&s"(sWidth), [topw] "=&s"(sTopw), [alive] "=&s"(sAlive), [pnx] "=&v"(vt[0]), [pny] "=&v"(vt[1]),              \
@@ -2713,6 +2714,10 @@ void launchLights(const SnailScene *s, const dev::ShadeArgs &A, hipStream_t stre
 
 } // namespace
 
+// The node buffer is at least nTris + 2 records long: the prefetching loop requests "the near child" of EVERY record as soon as it has arrived,
+// and for a leaf (sub = 0x80000000 | firstTri) that is the 32 bytes at record firstTri or firstTri + 1 -- never used, but it has to be readable
+// (a compare + select that redirected it to the root cost two scalar instructions per visit, and a scalar instruction costs what a vector one does).
+static size_t nodeBufferRecords(size_t nNodes, size_t nTris) { return nNodes > nTris + 2 ? nNodes : nTris + 2; }
 #include "lbvh.inc"
 
 extern "C" {
@@ -2778,7 +2783,7 @@ SnailScene *snail_scene_create(const void *nodes32, int nNodes, const void *tris
 	SnailScene *s = new SnailScene();
 	s->device = device; s->nNodes = nNodes; s->nTris = nTris; s->depth = realDepth; s->fastOK = fastOK; // the measured depth (<= declared) picks the stack form
 	hipError_t e;
-	if((e = hipMalloc((void **)&s->dNodes, (size_t)nNodes * 32)) != hipSuccess || (e = hipMalloc((void **)&s->dTris, (size_t)nTris * 64)) != hipSuccess ||
+	if((e = hipMalloc((void **)&s->dNodes, nodeBufferRecords((size_t)nNodes, (size_t)nTris) * 32)) != hipSuccess || (e = hipMalloc((void **)&s->dTris, (size_t)nTris * 64)) != hipSuccess ||
 	   (e = hipMalloc((void **)&s->dStats, 4 * sizeof(unsigned long long))) != hipSuccess ||
 	   (e = hipMemcpy(s->dNodes, nodes32, (size_t)nNodes * 32, hipMemcpyHostToDevice)) != hipSuccess ||
 	   (e = hipMemcpy(s->dTris, tris64, (size_t)nTris * 64, hipMemcpyHostToDevice)) != hipSuccess) {
