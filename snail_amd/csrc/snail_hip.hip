@@ -1025,7 +1025,7 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 " s_lshr_b32 %[cur], %[sign16], " AUX "\n s_xor_b32 %[cur], %[cur], " AUX "\n s_bfe_u32 %[cur], %[cur], 0x10010\n"         \
 				 " s_add_u32 %[fl], " SUB ", 1\n s_sub_u32 %[fl], %[fl], %[cur]\n" /* far child */                                          \
 				 " s_add_u32 %[cur], " SUB ", %[cur]\n" /* near child */                                                                    \
-				 " s_lshl_b32 %[off], %[cur], 5\n" /* a leaf: firstTri (+1) << 5, inside the padded node buffer (nodeBufferRecords) */       \
+				 " s_max_i32 %[cur], %[cur], 0\n s_lshl_b32 %[off], %[cur], 5\n" /* a leaf's sub is negative: its "near child" is the root */ \
 				 " s_load_dwordx8 " OTHERSET ", %[base], %[off]\n"                                                                         \
 				 PRE(NX, FX, NY, FY, NZ, FZ)                                                                                               \
 				 SLAB("0", NX, FX, NY, FY, NZ, FZ) TAIL("0", "s0") SLAB("1", NX, FX, NY, FY, NZ, FZ) TAIL("1", "s1")                       \
@@ -2714,10 +2714,6 @@ void launchLights(const SnailScene *s, const dev::ShadeArgs &A, hipStream_t stre
 
 } // namespace
 
-// The node buffer is at least nTris + 2 records long: the prefetching loop requests "the near child" of EVERY record as soon as it has arrived,
-// and for a leaf (sub = 0x80000000 | firstTri) that is the 32 bytes at record firstTri or firstTri + 1 -- never used, but it has to be readable
-// (a compare + select that redirected it to the root cost two scalar instructions per visit, and a scalar instruction costs what a vector one does).
-static size_t nodeBufferRecords(size_t nNodes, size_t nTris) { return nNodes > nTris + 2 ? nNodes : nTris + 2; }
 #include "lbvh.inc"
 
 extern "C" {
@@ -2783,7 +2779,7 @@ SnailScene *snail_scene_create(const void *nodes32, int nNodes, const void *tris
 	SnailScene *s = new SnailScene();
 	s->device = device; s->nNodes = nNodes; s->nTris = nTris; s->depth = realDepth; s->fastOK = fastOK; // the measured depth (<= declared) picks the stack form
 	hipError_t e;
-	if((e = hipMalloc((void **)&s->dNodes, nodeBufferRecords((size_t)nNodes, (size_t)nTris) * 32)) != hipSuccess || (e = hipMalloc((void **)&s->dTris, (size_t)nTris * 64)) != hipSuccess ||
+	if((e = hipMalloc((void **)&s->dNodes, (size_t)nNodes * 32)) != hipSuccess || (e = hipMalloc((void **)&s->dTris, (size_t)nTris * 64)) != hipSuccess ||
 	   (e = hipMalloc((void **)&s->dStats, 4 * sizeof(unsigned long long))) != hipSuccess ||
 	   (e = hipMemcpy(s->dNodes, nodes32, (size_t)nNodes * 32, hipMemcpyHostToDevice)) != hipSuccess ||
 	   (e = hipMemcpy(s->dTris, tris64, (size_t)nTris * 64, hipMemcpyHostToDevice)) != hipSuccess) {
