@@ -144,7 +144,8 @@ int snail_packets_to_frame_dev(const int32_t *d_packet_xy, int nPackets, int res
  * :631-633 (transparency).  nPackets packets of `size` quads (1..64).  origin: one quad per packet if
  * sharedOrigin else `size` quads per packet.  mask: NULL (hasMask=0) or 1 byte per quad.
  * distance/object/bary are IN/OUT and must be initialised by the caller as Scene::RayTrace does
- * (+inf / -inf for masked lanes, 0).  `element` of Context is not written by BVH and is not passed. */
+ * (+inf / -inf for masked lanes, 0).  `element` of Context is not written by BVH and is not passed.
+ * bary may be NULL (both forms): barycentrics are then not tracked, which is the cheaper walk (what the staged shading pipeline uses). */
 int snail_trace_rays(SnailScene *, int nPackets, int size, int sharedOrigin, const float *origin, const float *dir,
                      const float *idir, const uint8_t *mask, float *distance, int32_t *object, float *bary, uint64_t stats[4]);
 int snail_trace_rays_dev(SnailScene *, int nPackets, int size, int sharedOrigin, const float *d_origin, const float *d_dir,

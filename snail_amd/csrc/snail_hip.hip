@@ -3022,16 +3022,16 @@ int snail_trace_rays(SnailScene *s, int nPackets, int size, int sharedOrigin, co
 	const size_t nq = (size_t)nPackets * size;
 	DevBuf o, d, i, m, ds, ob, ba;
 	if(o.upload(origin, (sharedOrigin ? (size_t)nPackets : nq) * 48) || d.upload(dir, nq * 48) || i.upload(idir, nq * 48) ||
-	   (mask && m.upload(mask, nq)) || ds.upload(distance, nq * 16) || ob.upload(object, nq * 16) || ba.upload(bary, nq * 32)) {
+	   (mask && m.upload(mask, nq)) || ds.upload(distance, nq * 16) || ob.upload(object, nq * 16) || (bary && ba.upload(bary, nq * 32))) {
 		snail_set_error("snail_trace_rays: device staging failed");
 		return 2;
 	}
 	if(stats) HIP_TRY(hipMemset(s->dStats, 0, 32));
 	int rc = launchRays(s, false, nPackets, size, sharedOrigin, (float *)o.p, (float *)d.p, (float *)i.p, mask ? (uint8_t *)m.p : nullptr, (float *)ds.p,
-						(int32_t *)ob.p, (float *)ba.p, stats ? (uint64_t *)s->dStats : nullptr, 0);
+						(int32_t *)ob.p, bary ? (float *)ba.p : nullptr, stats ? (uint64_t *)s->dStats : nullptr, 0);
 	if(rc) return rc;
 	HIP_TRY(hipDeviceSynchronize());
-	if(ds.download(distance, nq * 16) || ob.download(object, nq * 16) || ba.download(bary, nq * 32)) { snail_set_error("snail_trace_rays: download failed"); return 2; }
+	if(ds.download(distance, nq * 16) || ob.download(object, nq * 16) || (bary && ba.download(bary, nq * 32))) { snail_set_error("snail_trace_rays: download failed"); return 2; }
 	if(stats) {
 		unsigned long long hs[4];
 		HIP_TRY(hipMemcpy(hs, s->dStats, 32, hipMemcpyDeviceToHost));

@@ -155,36 +155,39 @@ def test_host_pointer_entry_point(torch_mod):
     sc.close()
 
 
-@pytest.mark.parametrize("shared,masked,size,poison", [
-    (True, False, 64, False), (True, True, 64, False), (False, False, 64, False), (False, True, 64, False),
-    (False, True, 16, False), (True, False, 1, False),
-    (True, False, 64, True), (False, True, 64, True),       # non-finite idir -> EXACT instantiation
+@pytest.mark.parametrize("shared,masked,size,poison,coherent,want_bary", [
+    (True, False, 64, False, False, True), (True, True, 64, False, False, True), (False, False, 64, False, False, True), (False, True, 64, False, False, True),
+    (False, True, 16, False, False, True), (True, False, 1, False, False, True),
+    (True, False, 64, True, False, True), (False, True, 64, True, False, True),       # non-finite idir -> EXACT instantiation
+    # coherent packets without barycentrics: the instantiations that take the narrow-range leaf forms (shared / per-ray origins, masks)
+    (True, False, 64, False, True, False), (False, False, 64, False, True, False), (False, True, 64, False, True, False), (False, True, 16, False, True, False),
+    (False, True, 64, False, True, True),
 ])
-def test_trace_rays_bit_exact(torch_mod, shared, masked, size, poison):
+def test_trace_rays_bit_exact(torch_mod, shared, masked, size, poison, coherent, want_bary):
     name = "atrium:0.05"
     tv, sc, osc = gpu_scene(name)
     cam = util.camera_for(name, tv)
     npk = 24
     origin, dirs, idir, mask, dist, obj, bary = util.secondary_packets(osc, cam, 640, 368, npk, seed=11 + size, shared=shared, masked=masked,
-                                                                       size=size, poison=poison)
+                                                                       size=size, poison=poison, coherent=coherent)
     d2, o2, b2 = dist.copy(), obj.copy(), bary.copy()
     ost = osc.trace_rays(origin, dirs, idir, mask, d2, o2, b2, npk, size, shared, mode=O.MODE_IEEE)
     from snail_amd.scene import Context
     tt = torch_mod.from_numpy
-    ctx = Context(tt(origin).cuda(), tt(dirs).cuda(), tt(idir).cuda(), tt(dist.copy()).cuda(), tt(obj.copy()).cuda(), tt(bary.copy()).cuda(),
+    ctx = Context(tt(origin).cuda(), tt(dirs).cuda(), tt(idir).cuda(), tt(dist.copy()).cuda(), tt(obj.copy()).cuda(), tt(bary.copy()).cuda() if want_bary else None,
                   size=size, shared_origin=shared, mask=None if mask is None else tt(mask).cuda())
     stats = sc.new_stats()
     sc.traverse_primary(ctx, stats=stats)
     torch_mod.cuda.synchronize()
     util.assert_bit_equal(ctx.object.cpu().numpy(), o2, "object")
     util.assert_bit_equal(ctx.distance.cpu().numpy(), d2, "distance")
-    util.assert_bit_equal(ctx.barycentric.cpu().numpy(), b2, "barycentric")
+    if want_bary: util.assert_bit_equal(ctx.barycentric.cpu().numpy(), b2, "barycentric")
     st = stats.cpu().numpy().astype(np.uint64)
     assert st[0] == ost[0] and st[1] == ost[1], (st, ost)
     assert (o2 != 0).any() or poison
     # host-pointer variant gives the same bytes
     d3, o3, b3 = dist.copy(), obj.copy(), bary.copy()
-    sc.trace_rays_host(origin, dirs, idir, mask, d3, o3, b3, npk, size, shared)
+    sc.trace_rays_host(origin, dirs, idir, mask, d3, o3, b3 if want_bary else None, npk, size, shared)
     util.assert_bit_equal(d3, d2, "host distance"); util.assert_bit_equal(o3, o2, "host object")
     sc.close()
 

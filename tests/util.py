@@ -44,7 +44,7 @@ def assert_bit_equal(a, b, what=""):
         what, int(ne.sum()), ne.size, np.argwhere(ne)[0], a[tuple(np.argwhere(ne)[0])], b[tuple(np.argwhere(ne)[0])])
 
 
-def secondary_packets(oscene, cam, resx, resy, n_packets, seed, shared, masked, size=64, poison=False):
+def secondary_packets(oscene, cam, resx, resy, n_packets, seed, shared, masked, size=64, poison=False, coherent=False):
     """Build seeded packets the way the reference's secondary rays look (src/scene_trace.cpp:603-634):
     origins on first-hit points of primary packets, directions = mirrored primaries + jitter; idir = 1/(d+1e-8);
     masks with random dead lanes; distance = +inf / -inf(masked), object = 0 (src/scene_trace.cpp:112-115).
@@ -60,11 +60,13 @@ def secondary_packets(oscene, cam, resx, resy, n_packets, seed, shared, masked, 
         main = rng.randn(3)
         main /= np.linalg.norm(main)
         for q in range(size):
-            d = main[None, :] + 0.08 * rng.randn(4, 3) + 0.004 * np.array([[q % 4, q // 4, 0]])
+            # coherent: neighbouring quads look in neighbouring directions from nearly one point, as a mirrored packet's do -- box tests then
+            # narrow the quad range, which the scattered form hardly ever does
+            d = main[None, :] + (0.002 if coherent else 0.08) * rng.randn(4, 3) + (0.012 if coherent else 0.004) * np.array([[q % 4, q // 4, 0]])
             d /= np.linalg.norm(d, axis=1, keepdims=True)
             dirs[p * size + q] = d.T.reshape(-1).astype(np.float32)
             if not shared:
-                o = base[None, :] + 0.02 * ext * rng.randn(4, 3)
+                o = base[None, :] + (0.0005 if coherent else 0.02) * ext * rng.randn(4, 3)
                 origin[p * size + q] = o.T.reshape(-1).astype(np.float32)
         if shared:
             origin[p] = np.repeat(base.astype(np.float32), 4)
