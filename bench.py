@@ -1,8 +1,14 @@
 #!/usr/bin/env python3
 """bench.py -- the measurement contract of this repo.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1|3|4|5] [--scaling strong|weak] [--rank0-share F]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1|3|4|5] [--scaling strong|weak] [--rank0-share F] [--camera-path static|orbit]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+Both forms work for N > 1: started WITHOUT torch.distributed.run (no WORLD_SIZE in the environment), `bench.py --gpus N` starts its own N ranks
+-- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a CHILD
+process, before this process has imported torch or touched a GPU -- relays rank 0's JSON line and exits with the child's status.
+The documented multi-GPU sweep: N = 1, 2, 4, 8 with the defaults (throughput; several frames per launch and per collective) and again with
+`--frames-per-launch 1` (latency: one frame per launch and per collective); every N > 1 line carries `roofline`, `frames_in_flight` and the
+measured latency of a lone launch through the whole route (`config.lone_launch_ms`).
 
 A "step" is ONE FRAME through the hot path (RayGenerator + SafeInv + packet BVH traversal + ray/triangle
 intersection -> hit records), inputs (BVH, camera) resident in HBM before the timed region.
@@ -74,6 +80,48 @@ CONFIGS = {
 }
 
 
+def kernel_source_sha16() -> str:
+    """Hash of the kernel sources the PMC counters of profiles/traffic.json were measured on (tools/make_traffic.py stores it beside them):
+    a kernel edit without a fresh counter pass makes the bench line say `counters_stale: true` instead of pricing the new kernel with the
+    old instruction count."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("snail_hip.hip", "lbvh.inc", "render_host.inc"):
+        with open(os.path.join(ROOT, "snail_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def self_launch(n_gpus: int, argv) -> int:
+    """`python bench.py --gpus N` without torch.distributed.run: start the N ranks as a CHILD process (never an exec, and before this
+    process has imported torch or touched a GPU); the children inherit stdout, so rank 0's JSON line is this command's output."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what the host driver of this pool supports (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def orbit_cameras(scenes, FPSCamera, scene_name, n, step_deg=0.2, sweep_deg=20.0):
+    """--camera-path orbit: the view turns by `step_deg` every frame, back and forth over +-sweep_deg around the scene's bench view, so
+    that no frame is traced with a dispatch order derived from its own costs (the static view's perfect prediction)."""
+    pos, ang, pitch = scenes.stress_camera() if scene_name.startswith("stress") else scenes.atrium_camera()
+    period = int(round(4 * sweep_deg / step_deg))
+    cams = []
+    for i in range(min(n, period)):
+        k = i % period
+        tri = k if k <= period // 4 else (period // 2 - k if k <= 3 * period // 4 else k - period)     # 0 .. +q .. -q .. 0
+        cams.append(FPSCamera(pos, ang + math.radians(tri * step_deg), pitch).camera())
+    return cams
+
+
 def pmc_counters(workload_key: str):
     """Per-launch PMC figures of the dominant kernel from the committed rocprofv3 passes of this same command
     (profiles/traffic.json): HBM bytes = FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, and
@@ -82,9 +130,14 @@ def pmc_counters(workload_key: str):
     if not os.path.exists(path):
         return None
     try:
-        return json.load(open(path)).get(workload_key)
+        d = json.load(open(path))
     except Exception:
         return None
+    tr = d.get(workload_key)
+    if tr is not None:
+        tr = dict(tr)
+        tr["_stale"] = d.get("_kernel_sha16") != kernel_source_sha16()
+    return tr
 
 
 def weak_frame_size(n_gpus: int, res):
@@ -132,9 +185,15 @@ def main():
     ap.add_argument("--event-every", type=int, default=8, help="bracket every n-th traversal launch with HIP events (roofline.kernel_ms)")
     ap.add_argument("--feedback-order", type=int, default=1, help="1 (default) = dispatch packets heaviest first by the node visits of an earlier frame (DistributedRenderer feedback_order)")
     ap.add_argument("--frames-per-launch", type=int, default=0, help="trace this many frames (1..8) with one launch -- and, at N > 1, move them with one collective (DistributedRenderer frames_per_launch); 0 = enough for a launch to hold 8160 packets (one 1080p frame), at least 2, at most 8: 2 / 2 / 4 / 8 at N = 1 / 2 / 4 / 8; config 3 always 1")
-    ap.add_argument("--stagger", type=int, default=0, help="1 = de-phase the frame streams when the pipeline starts from idle (DistributedRenderer stagger; measured: no gain)")
-    ap.add_argument("--lone-frames", type=int, default=12, help="N=1: frames traced one at a time after the timed region (lone_frame_ms); 0 = skip")
+    ap.add_argument("--lone-frames", type=int, default=12, help="frames (N > 1: launches through the whole route) traced one at a time after the timed region (lone_frame_ms / lone_launch_ms); 0 = skip")
+    ap.add_argument("--camera-path", default="static", choices=["static", "orbit"], help="orbit = the camera turns 0.2 degrees every step (dispatch orders are then predictions from an older view, re-derived every --order-refresh frames of a slot, inside the timed region)")
+    ap.add_argument("--dry-run", action="store_true", help="start the ranks, rendezvous, one all-reduce over the chosen backend, print {dry_run, ranks} and exit: checks the launch path without a GPU (with --backend gloo)")
+    ap.add_argument("--order-refresh", type=int, default=16, help="frames of a slot between two derivations of its dispatch order while the camera moves (DistributedRenderer order_refresh)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as the plain command: become the launcher.  Nothing GPU-related has been imported or initialised in this process.
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     import numpy as np
     import torch
@@ -143,13 +202,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
+    rehearsal = world > 1 and args.backend == "gloo"
+    if args.dry_run:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
+        tt = torch.ones(1, dtype=torch.float64, device="cpu" if (rehearsal or world == 1) else torch.device("cuda", local_rank))
+        if world > 1:
+            dist.all_reduce(tt)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "ranks": int(tt.item()), "n_gpus": world, "backend": args.backend if world > 1 else None}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    if world > 1 and not rehearsal and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py --gpus %d over RCCL needs %d GPUs, this node shows %d (--backend gloo = a rehearsal on one GPU)" % (world, world, torch.cuda.device_count()))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    rehearsal = world > 1 and args.backend == "gloo"
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -189,9 +259,12 @@ def main():
     per_rank = ((resx + 15) // 16) * ((resy + 15) // 16) / float(world)
     auto_fpl = int(min(8, max(2, math.ceil(8160.0 / max(1.0, per_rank)))))
     rnd = DistributedRenderer(scene, resx, resy, rank, world, slots=args.streams if args.streams > 0 else None, stage_cpu=rehearsal,
-                              feedback_order=bool(args.feedback_order), lights7=lights7, rank0_share=args.rank0_share, stagger=bool(args.stagger),
-                              frames_per_launch=args.frames_per_launch if args.frames_per_launch > 0 else auto_fpl)
+                              feedback_order=bool(args.feedback_order), lights7=lights7, rank0_share=args.rank0_share,
+                              frames_per_launch=args.frames_per_launch if args.frames_per_launch > 0 else auto_fpl, order_refresh=args.order_refresh)
     primary_rays = rnd.rays_per_frame() if world > 1 else resx * ((resy + 15) // 16 * 16)
+    # the cameras of the timed steps: one fixed view, or a view that turns every step (built here, outside the timed region)
+    path = orbit_cameras(scenes, FPSCamera, scene_name, args.steps + args.warmup) if (args.camera_path == "orbit" and not args.scene) else [cam]
+    cam_at = lambda i: path[i % len(path)]
 
     def barrier():
         if world > 1:
@@ -206,8 +279,8 @@ def main():
     tot = rnd.reduce_stats(st) if world > 1 else st
     total_rays = int(tot.cpu().numpy()[2]) if (rank == 0 and cfg["lights"]) else primary_rays
     node_visits = int(tot.cpu().numpy()[1]) if rank == 0 else 0
-    for _ in range(args.warmup):
-        rnd.render(cam)
+    for i in range(args.warmup):
+        rnd.render(cam_at(i))
     rnd.flush()
     barrier()
 
@@ -221,11 +294,13 @@ def main():
     # ---- timed region: EXACTLY K steps (frames are pipelined over the renderer's HIP streams, see DistributedRenderer) ----
     # HIP events bracket every `--event-every`-th launch on the stream it is launched on (an event record is a barrier packet in the
     # stream: bracketing every launch costs ~2 % of the frame rate; the average is taken over steps / event_every launches)
-    every = max(1, args.event_every)
+    # (a launch of B frames keeps ONE pair, that of its first frame: the stride is a multiple of B)
+    every = -(-max(1, args.event_every) // rnd.batch) * rnd.batch
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if i % every == 0 else None for i in range(args.steps)]
+    cams_timed = [cam_at(args.warmup + i) for i in range(args.steps)]
     t0 = time.perf_counter()
-    for e in ev:
-        rnd.render(cam, events=e)
+    for e, c in zip(ev, cams_timed):
+        rnd.render(c, events=e)
     rnd.flush()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -234,7 +309,29 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     timed = [e for e in ev if e is not None]
-    kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in timed) / max(1, len(timed))
+    durs = []
+    for e0, e1 in timed:
+        try:
+            durs.append(e0.elapsed_time(e1))
+        except Exception:       # a pair the renderer did not record (never the case with the stride above; not worth a failed run)
+            pass
+    kern_ms = sum(durs) / max(1, len(durs))
+
+    # ---- one launch at a time through the whole route (N > 1): trace -> gather -> scatter of `frames_per_launch` frames with nothing
+    # else in flight, host clock of rank 0 between a barrier and the completed frame -- the latency side of the throughput figure ----
+    lone_launch_ms = None
+    if world > 1 and args.lone_frames > 0:
+        ts = []
+        for _ in range(args.lone_frames):
+            barrier()
+            t1 = time.perf_counter()
+            for _k in range(rnd.batch):
+                rnd.render(cam)
+            rnd.flush()
+            ts.append((time.perf_counter() - t1) * 1e3)
+        ts.sort()
+        lone_launch_ms = ts[len(ts) // 2]
+        barrier()
 
     # ---- one frame at a time (N = 1): the latency a frame has when nothing else is in flight ----
     lone_ms = None
@@ -249,33 +346,61 @@ def main():
         ts.sort()
         lone_ms = ts[len(ts) // 2]
 
+    # ---- the same K steps with ONE frame per launch (N = 1, when the timed region used several): the rate without the batching ----
+    fpl1 = None
+    if rank == 0 and world == 1 and rnd.batch > 1 and args.lone_frames > 0:
+        r1 = DistributedRenderer(scene, resx, resy, 0, 1, slots=args.streams if args.streams > 0 else None, feedback_order=bool(args.feedback_order),
+                                 frames_per_launch=1, order_refresh=args.order_refresh)
+        for i in range(max(8, min(args.warmup, 100))):
+            r1.render(cam_at(i))
+        r1.flush()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for c in cams_timed:
+            r1.render(c)
+        r1.flush()
+        torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t1
+        fpl1 = {"value": round(primary_rays * args.steps / dt1 / 1e6, 2), "ms_per_step": round(dt1 * 1e3 / args.steps, 5), "frames_per_launch": 1,
+                "frames_in_flight": r1.nslots, "note": "the same %d steps after the timed region with one frame per launch (not the headline)" % args.steps}
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         step_s = ms_per_step * 1e-3
         value = total_rays * args.steps / elapsed / 1e6
         key = "%s_%dx%d_n%d_c%d" % (scene_name, resx, resy, world, args.config)
         tr = pmc_counters(key)
+        shared_note = ""
+        if tr is None and world > 1 and args.scaling == "strong":
+            # N ranks share the SAME frame: its counters are those of the one-GPU pass of this workload (the walk of a packet does not depend
+            # on which rank traces it; the depth-shading epilogue of the tile route adds < 1 % vector instructions), priced against N GPUs' peak
+            tr = pmc_counters("%s_%dx%d_n1_c%d" % (scene_name, resx, resy, args.config))
+            shared_note = " [N = %d: the frame's counters from the one-GPU pass, peak = %d x one GPU's]" % (world, world)
         valu = tr.get("valu_insts_per_launch") if tr else None
         traffic = tr.get("bytes_per_launch") if tr else None
-        roof = {"bound": "valu_issue", "achieved": round(valu / step_s / 1e9, 1) if valu else None, "peak": round(VALU_PEAK_GINST, 1), "unit": "Gwaveinst/s",
-                "frac": round(valu / step_s / 1e9 / VALU_PEAK_GINST, 4) if valu else None,
+        peak_ginst = VALU_PEAK_GINST * world
+        hbm_peak = HBM_PEAK_GBS * world
+        roof = {"bound": "valu_issue", "achieved": round(valu / step_s / 1e9, 1) if valu else None, "peak": round(peak_ginst, 1), "unit": "Gwaveinst/s",
+                "frac": round(valu / step_s / 1e9 / peak_ginst, 4) if valu else None,
+                "counters_stale": bool(tr.get("_stale")) if tr else None,
                 "traffic": traffic * rnd.batch if traffic else None,
                 "traffic_unit": "HBM bytes per launch of %d frame(s) (rocprofv3 PMC of a one-frame launch: 2 x FETCH_SIZE + WRITE_SIZE, x frames per launch)" % rnd.batch,
                 "frames_per_launch": rnd.batch, "traffic_bytes_per_frame": traffic,
-                "hbm_peak_GBs": HBM_PEAK_GBS, "hbm_frac_traffic": round(traffic / step_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-                "valu_insts_per_launch": valu * rnd.batch if valu else None, "valu_insts_per_frame": valu, "counters_source": tr.get("source") if tr else "no PMC pass committed for workload key %s" % key,
-                "kernel": "dev::k_primary", "kernel_ms": round(kern_ms, 5), "kernel_ms_note": "HIP events around one launch (%d frame(s)) on its own stream while %d launches are in flight: overlapped, not a stand-alone duration; every fraction here uses ms_per_step (per frame) and per-frame counters" % (rnd.batch, rnd.nslots),
-                "denominator_ms": round(ms_per_step, 5), "lone_frame_ms": round(lone_ms, 5) if lone_ms is not None else None}
+                "hbm_peak_GBs": hbm_peak, "hbm_frac_traffic": round(traffic / step_s / 1e9 / hbm_peak, 4) if traffic else None,
+                "valu_insts_per_launch": valu * rnd.batch if valu else None, "valu_insts_per_frame": valu, "counters_source": (tr.get("source") + shared_note) if tr else "no PMC pass committed for workload key %s" % key,
+                "kernel": tr.get("kernel", "dev::k_primary") if tr else "dev::k_primary", "kernel_ms": round(kern_ms, 5), "kernel_ms_note": "HIP events around one launch (%d frame(s)) on its own stream while %d launches are in flight: overlapped, not a stand-alone duration; every fraction here uses ms_per_step (per frame) and per-frame counters" % (rnd.batch, rnd.nslots),
+                "denominator_ms": round(ms_per_step, 5), "lone_frame_ms": round(lone_ms, 5) if lone_ms is not None else None,
+                "one_frame_per_launch": fpl1}
         if pk is not None:
             visits, fetched = int(pk[:, 0].sum()), int(pk[:, 4].sum())
             pbytes = 32 * visits + 64 * fetched + 16 * 256 * len(pk)
             roof.update({"packet_alg_bytes_per_launch": pbytes * rnd.batch, "packet_alg_bytes_per_frame": pbytes, "packet_node_visits": visits, "packet_tri_records_fetched": fetched,
-                         "hbm_frac_packet_alg": round(pbytes / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                         "hbm_frac_packet_alg": round(pbytes / step_s / 1e9 / hbm_peak, 4),
                          "compulsory_bytes_per_frame": 32 * hbvh.n_nodes + 64 * hbvh.n_tris + 16 * primary_rays})
         if acc is not None:
             b_alg = (32.0 * float(acc[1]) + 64.0 * float(acc[2])) / float(acc[0]) + 16.0
             roof.update({"alg_single_ray_bytes_per_ray": round(b_alg, 1),
-                         "alg_single_ray_frac_of_hbm_peak": round(primary_rays * b_alg / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                         "alg_single_ray_frac_of_hbm_peak": round(primary_rays * b_alg / step_s / 1e9 / hbm_peak, 4),
                          "alg_single_ray_note": "SURVEY 8(d)'s single-ray cache-less bytes; the packet kernel fetches a node once per 256 rays, so this is informational and may exceed 1"})
         if rnd.frame is not None:
             hit_frac = float(torch.isfinite(rnd.frame.t).float().mean().item())
@@ -296,6 +421,10 @@ def main():
                        "baseline_config": args.config, "rays_per_step": total_rays, "primary_rays_per_step": primary_rays, "node_visits_per_step": node_visits,
                        "packets": "16x16 px = 1 wavefront", "bvh_nodes": hbvh.n_nodes, "bvh_depth": hbvh.depth,
                        "bvh_build_s": round(build_s, 3), "hit_fraction": round(hit_frac, 5), "frames_in_flight": rnd.nslots * rnd.batch, "frames_per_launch": rnd.batch, "launches_in_flight": rnd.nslots,
+                       "lone_launch_ms": round(lone_launch_ms, 5) if lone_launch_ms is not None else None,
+                       "lone_launch_note": ("host clock of rank 0 around %d frame(s) = one launch + one collective + scatter with nothing else in flight" % rnd.batch) if lone_launch_ms is not None else None,
+                       "camera_path": args.camera_path if len(path) > 1 else "static", "order_refresh": rnd.order_refresh if rnd.feedback else None,
+                       "ranks": world, "backend": ("gloo (rehearsal)" if rehearsal else "nccl (RCCL)") if world > 1 else None,
                        "packet_order": "heaviest first (node visits of an earlier frame)" if rnd.feedback else "built-in region interleave",
                        "traversal_stack": "VGPR pair per wave (lane i = slot i), at most bvh_depth = %d slots; LDS 0 B/wave in the main kernel (3328 B/wave only in the deferred M_EXACT pass)" % hbvh.depth,
                        "packets_per_rank": [len(p) for p in rnd.plan.packets] if world > 1 else None,

@@ -72,6 +72,10 @@ SnailScene *snail_scene_create_lbvh(const float *tri_verts, int nTris, int devic
 /* Copy a scene's node (nNodes x 32 B) and / or triangle (nTris x 64 B) records back to the host (either may be NULL). */
 int snail_scene_download(const SnailScene *, void *nodes32, void *tris64);
 int snail_scene_info(const SnailScene *, int *nNodes, int *nTris, int *depth, int *device);
+/* What snail_scene_create found: fastOK = every record finite and of sane magnitude (else every packet takes the M_EXACT walk);
+ * nestedOK = every child box lies inside its parent's box (true for the reference's builders; a tree that is not nested is walked by
+ * the node loop that rescans the whole inherited quad range at every box, exactly as src/bounding_box.cpp:71-139 does). */
+int snail_scene_flags(const SnailScene *, int *fastOK, int *nestedOK);
 
 /* ---- primary packets: RayGenerator + SafeInv + TraversePrimary<1,0> ----------------------------- */
 /* Replaces the per-packet body of RenderTask::Work (src/render.cpp:58-62,67-68,112-115) plus the
@@ -260,14 +264,6 @@ int snail_render_tiles(SnailScene *, const float cam[13], int resx, int resy, co
 int snail_render_image(SnailScene *, const float cam[13], int resx, int resy, const float *lights7, int nLights, const float ambient[3],
                        const float color[3], int flags, uint8_t *image_bgr, int pitch, uint64_t stats[4]);
 
-/* ---- pipelining support ------------------------------------------------------------------------------------------------------ */
-/* A stream-ordered pause (one sleeping wave; 0..10000 us) on the current device.  Frames pipelined over several HIP streams run best
- * when the streams are OUT of phase -- a frame's tail (its heaviest packets) then overlaps the other frames' bulk.  Streams that all
- * start from idle at the same moment stay in phase for many frames (their grids are dispatched one after the other, so the later
- * frames' heavy packets start late: 0.43 ms per round of four frames instead of 0.356, tools/timeline.py); a host staggers the first
- * launch of stream k by k x (frame time / streams), as snail_amd.render.DistributedRenderer does. */
-int snail_delay_dev(float microseconds, void *stream);
-
 /* ---- measurement support ------------------------------------------------------------------------- */
 /* Single-ray, cache-less accounting walk of SURVEY.md section 8(d) over the same padded packet set as
  * snail_trace_primary: d_out[0] += rays, [1] += sum V_n (node boxes tested), [2] += sum V_t
@@ -275,33 +271,16 @@ int snail_delay_dev(float microseconds, void *stream);
  * B_alg(ray) = 32*V_n + 64*V_t + 16. */
 int snail_account_primary(SnailScene *, const float cam[13], int resx, int resy, int x0, int y0, int w, int h, uint64_t out[4]);
 
-/* Diagnostic: one sleeping wave that reads the shader-cycle counter and the 100 MHz constant clock `microseconds` apart: d_out2[0] = shader
- * cycles, d_out2[1] = constant-clock ticks; clock = d_out2[0] / d_out2[1] x 100 MHz.  tools/ramp.py samples it beside the frames. */
-int snail_debug_clock_dev(float microseconds, uint64_t *d_out2, void *stream);
-/* Runs the kernels' reciprocal (v_rcp_f32 + one Newton step inside 2^-126 <= |x| < 2^126, the full division outside) on all 2^32 float bit
- * patterns against the correctly rounded 1.0f / x: out2[0] = results that differ (must be 0), out2[1] = inputs inside that range
- * (2 * 252 * 2^23).  Blocks the device for a few tens of milliseconds. */
-int snail_debug_recip_check(uint64_t out2[2]);
-
-/* Diagnostic: time per launch of an EMPTY kernel of `blocks` x `threads` (what the workgroup dispatcher alone sustains), averaged
- * over `reps` back-to-back launches on the default stream of the current device.  tools/dispatch_rate.py. */
-int snail_debug_dispatch_rate(int blocks, int threads, int reps, float *ms_per_launch);
-
-/* Diagnostic: per-packet cost of one full-frame primary launch (a diagnostic build of the same packet code, dev::k_primary_diag),
- * row-major over the packet grid, 8 words per packet:
+/* Per-packet accounting of one full-frame primary launch (the same packet code built with counters, dev::k_primary_diag; a measurement
+ * pass, never on a product path), row-major over the packet grid, 8 words per packet:
  * out8[p*8 + {0..5}] = {loop iterations (node visits), quad x triangle tests, shader-clock cycles of that wavefront, start time >> 6,
  * triangle records fetched (every triangle of every leaf body entered), leaf bodies entered}; words 6, 7 = 0.
- * For load-balance studies (tools/packet_costs.py) and for bench.py's packet-level algorithmic bytes
- * (32 B x node visits + 64 B x triangle records fetched + 16 B x 256 per packet); not on any product path. */
-int snail_debug_packet_costs(SnailScene *, const float cam[13], int resx, int resy, uint32_t *out8);
+ * bench.py's packet-level algorithmic bytes come from it (32 B x node visits + 64 B x triangle records fetched + 16 B x 256 per
+ * packet), and the load-balance studies of tools/packet_costs.py. */
+int snail_account_packets(SnailScene *, const float cam[13], int resx, int resy, uint32_t *out8);
 
-/* Experiment (tools/anyorder.py): `frames` full-frame primary launches back to back on one fresh stream with launch flags `flags`
- * (0, or hipExtAnyOrderLaunch = 1); *ms_total = HIP-event time around all of them.  No outputs are stored. */
-int snail_debug_anyorder(SnailScene *, const float cam[13], int resx, int resy, int frames, int flags, float *ms_total);
-
-/* Diagnostic: out = {blocks of dev::k_primary the occupancy API admits per CU, the device's block limit per CU, CUs, waves per block
- * of this build}.  tools/occupancy.py. */
-int snail_debug_occupancy(int out[4]);
+/* Diagnostics, experiments and environment switches (snail_debug_*) are NOT part of this contract: they live in
+ * include/snail_hip_debug.h and exist only in the workbench build libsnailhip_debug.so (-DSNAIL_DEBUG_API). */
 
 /* Launch geometry of the last primary launch on this scene (for profiles): waves, blocks, VGPR-independent. */
 int snail_last_launch(const SnailScene *, int *blocks, int *threadsPerBlock);

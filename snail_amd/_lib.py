@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# SNAIL_LIB_PATH: load an experimental build of the same C-ABI (tools/variants.sh) without touching the product library
+# SNAIL_LIB_PATH: load another build of the same C-ABI (an experiment of tools/variant.sh, or the workbench build libsnailhip_debug.so
+# when a whole process should run under its SNAIL_DEBUG_* environment switches) without touching the product library
 LIB_PATH = os.environ.get("SNAIL_LIB_PATH") or os.path.join(HERE, "libsnailhip.so")
 
 
@@ -28,12 +29,9 @@ SIGNATURES = {
     "snail_scene_create": (_VP, [_VP, _I, _VP, _I, _I, _I]),
     "snail_scene_destroy": (None, [_VP]),
     "snail_scene_info": (_I, [_VP, _VP, _VP, _VP, _VP]),
+    "snail_scene_flags": (_I, [_VP, _VP, _VP]),
     "snail_scene_create_lbvh": (_VP, [_VP, _I, _I, _I, _VP, _VP]),
     "snail_scene_download": (_I, [_VP, _VP, _VP]),
-    "snail_delay_dev": (_I, [C.c_float, _VP]),
-    "snail_debug_clock_dev": (_I, [C.c_float, _VP, _VP]),
-    "snail_debug_recip_check": (_I, [_VP]),
-    "snail_debug_dispatch_rate": (_I, [_I, _I, _I, _VP]),
     "snail_trace_primary": (_I, [_VP, _F13, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "snail_trace_frame_packets": (_I, [_VP, _F13, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "snail_trace_primary_dev": (_I, [_VP, _F13, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
@@ -61,11 +59,38 @@ SIGNATURES = {
     "snail_render_tiles": (_I, [_VP, _F13, _I, _I, _VP, _VP, _I, _VP, _I, _VP, _VP, _I, _VP, _VP]),
     "snail_render_image": (_I, [_VP, _F13, _I, _I, _VP, _I, _VP, _VP, _I, _VP, _I, _VP]),
     "snail_account_primary": (_I, [_VP, _F13, _I, _I, _I, _I, _I, _I, _VP]),
-    "snail_debug_packet_costs": (_I, [_VP, _F13, _I, _I, _VP]),
-    "snail_debug_occupancy": (_I, [_VP]),
-    "snail_debug_anyorder": (_I, [_VP, _F13, _I, _I, _I, _I, _VP]),
+    "snail_account_packets": (_I, [_VP, _F13, _I, _I, _VP]),
     "snail_last_launch": (_I, [_VP, _VP, _VP]),
 }
+
+# include/snail_hip_debug.h: the workbench build only (libsnailhip_debug.so, -DSNAIL_DEBUG_API)
+DEBUG_SIGNATURES = {
+    "snail_debug_delay_dev": (_I, [C.c_float, _VP]),
+    "snail_debug_clock_dev": (_I, [C.c_float, _VP, _VP]),
+    "snail_debug_recip_check": (_I, [_VP]),
+    "snail_debug_dispatch_rate": (_I, [_I, _I, _I, _VP]),
+    "snail_debug_occupancy": (_I, [_VP]),
+    "snail_debug_anyorder": (_I, [_VP, _F13, _I, _I, _I, _I, _VP]),
+}
+DEBUG_LIB_PATH = os.path.join(HERE, "libsnailhip_debug.so")
+_dbg = None
+
+
+def debug_lib():
+    """The workbench build of the same sources: the product C-ABI + include/snail_hip_debug.h + the SNAIL_DEBUG_* environment switches.
+    For tests and tools only; nothing on a product path loads it."""
+    global _dbg
+    if _dbg is None:
+        if not os.path.exists(DEBUG_LIB_PATH):
+            raise SnailError("workbench library %s is missing: `make -C snail_amd/csrc debug`" % DEBUG_LIB_PATH)
+        L = C.CDLL(DEBUG_LIB_PATH)
+        for table in (SIGNATURES, DEBUG_SIGNATURES):
+            for name, (res, args) in table.items():
+                fn = getattr(L, name)
+                fn.restype = res
+                fn.argtypes = args
+        _dbg = L
+    return _dbg
 
 
 def lib():
@@ -84,6 +109,11 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        for name, (res, args) in DEBUG_SIGNATURES.items():     # present only when SNAIL_LIB_PATH names the workbench build
+            fn = getattr(L, name, None)
+            if fn is not None:
+                fn.restype = res
+                fn.argtypes = args
         _lib = L
     return _lib
 

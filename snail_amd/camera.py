@@ -26,19 +26,24 @@ class Camera:
     plane_dist: float = 1.0
 
     def __setattr__(self, name, value):
+        if name in ("pos", "right", "up", "front"):
+            # own read-only copies: the flat form below is cached, so an in-place edit of a field array (cam.pos[0] = x, or of an array the
+            # caller still holds) must fail loudly instead of leaving the cache stale; assign a new array to move the camera
+            value = np.array(value, dtype=F32).reshape(3)
+            value.setflags(write=False)
         object.__setattr__(self, name, value)
         if name != "_a13":
             object.__setattr__(self, "_a13", None)     # a changed field invalidates the cached flat form
 
     def as_array13(self) -> np.ndarray:
-        """pos, right, up, front, plane_dist -- the flat layout the C-ABI takes (cached: a frame loop asks for it several times per frame;
-        treat the returned array as read-only)."""
+        """pos, right, up, front, plane_dist -- the flat layout the C-ABI takes (cached, read-only: a frame loop asks for it several times per frame)."""
         a = self.__dict__.get("_a13")
         if a is None:
             a = np.ascontiguousarray(np.concatenate([
                 np.asarray(self.pos, dtype=F32), np.asarray(self.right, dtype=F32),
                 np.asarray(self.up, dtype=F32), np.asarray(self.front, dtype=F32),
                 np.asarray([self.plane_dist], dtype=F32)]).astype(F32))
+            a.setflags(write=False)
             object.__setattr__(self, "_a13", a)
         return a
 

@@ -37,6 +37,9 @@
 #include <vector>
 
 #include "../../include/snail_hip.h"
+#ifdef SNAIL_DEBUG_API
+#include "../../include/snail_hip_debug.h"
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // error plumbing
@@ -1530,7 +1533,7 @@ __global__ __launch_bounds__(64 * SNAIL_BLOCK_WAVES) __attribute__((amdgpu_waves
 	}
 	primaryPacket<DEEP, false>(A, li, fi, lds);
 }
-// the diagnostic build of the same packet code (snail_debug_packet_costs): per-packet cost records; never on a product path
+// the diagnostic build of the same packet code (snail_account_packets): per-packet cost records; never on a product path
 template <bool DEEP>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SNAIL_PRIMARY_WAVES))) void k_primary_diag(PrimaryArgs A) {
 	__shared__ float lds[LDS_FLOATS_PER_WAVE];
@@ -2301,8 +2304,9 @@ __global__ __launch_bounds__(256) void k_planar_to_frame(const int4 *tiles, cons
 	}
 }
 
+#ifdef SNAIL_DEBUG_API // the workbench build (libsnailhip_debug.so, include/snail_hip_debug.h): diagnostics and experiments only
 // A stream-ordered pause of `ticks` periods of the 100 MHz constant clock (s_memrealtime): one wave that sleeps in 64-cycle naps.
-// Used to de-phase the frame streams when a pipeline starts from idle (snail_delay_dev).  Ends after `ticks` whatever happens.
+// (snail_debug_delay_dev: de-phasing experiments of pipelined frame streams).  Ends after `ticks` whatever happens.
 __global__ __launch_bounds__(64) void k_delay(unsigned ticks) {
 	const u64 t0 = __builtin_amdgcn_s_memrealtime();
 	while((unsigned)(__builtin_amdgcn_s_memrealtime() - t0) < ticks) __builtin_amdgcn_s_sleep(1);
@@ -2335,6 +2339,7 @@ __global__ __launch_bounds__(256) void k_recip_check(unsigned base, unsigned lon
 
 // diagnostic: what the workgroup dispatcher alone sustains (tools/dispatch_rate.py)
 __global__ void k_nop(int *sink) { if(sink && threadIdx.x == 0 && blockIdx.x == 0x7fffffff) *sink = 1; }
+#endif // SNAIL_DEBUG_API
 
 // ---- single-ray accounting walk: V_n, V_t per ray ----------------------------
 struct AccountArgs {
@@ -2426,6 +2431,7 @@ struct SnailScene {
 	int nNodes = 0, nTris = 0, depth = 0;
 	uint4 *dNodes = nullptr, *dTris = nullptr;
 	int fastOK = 0; // every triangle record finite and of sane magnitude (see file header)
+	int nestedOK = 1; // every child box lies inside its parent's (stackPack)
 	int lastBlocks = 0, lastThreads = 0;
 	unsigned long long *dStats = nullptr; // 4 x u64 scratch for the host-pointer entry points
 	enum { kDeferSlots = 8 };
@@ -2495,17 +2501,30 @@ bool originSane(const float *o) {
 	return true;
 }
 
-// depth > 62 needs the second stack register pair (DEEP instantiations).  SNAIL_DEBUG_FORCE_DEEP=1 selects them for any scene
-// (the deep-BVH stack study of BASELINE config 5, tools/quick_time.py)
+// Environment switches exist in the workbench build only (-DSNAIL_DEBUG_API): the product library reads no environment.
+#ifdef SNAIL_DEBUG_API
+int debugEnvInt(const char *name) { const char *v = getenv(name); return v ? atoi(v) : 0; }
+#else
+constexpr int debugEnvInt(const char *) { return 0; }
+#endif
+
+// depth > 62 needs the second stack register pair (DEEP instantiations).  Workbench build: SNAIL_DEBUG_FORCE_DEEP=1 selects them for
+// any scene (the deep-BVH stack study of BASELINE config 5, tools/quick_time.py; the test of the walks ordinary scenes never select)
 bool useDeep(const SnailScene *s) {
-	static const bool force = getenv("SNAIL_DEBUG_FORCE_DEEP") && atoi(getenv("SNAIL_DEBUG_FORCE_DEEP")) != 0;
+	static const bool force = debugEnvInt("SNAIL_DEBUG_FORCE_DEEP") != 0;
 	return force || s->depth > 62;
 }
 
-// one-word stack entries need node indices below 2^20.  SNAIL_DEBUG_NO_PACK=1 keeps the two-word form (A/B measurements)
+// One-word stack entries (and with them the record-prefetching node loop) need node indices below 2^20 -- and a NESTED tree: inside
+// the prefetching loop EXEC is the set of quads that survived the parent (a quad that fails a box fails every box inside it), so a
+// child's first / last come from the survivors only, whereas the reference rescans the whole inherited range
+// (src/bounding_box.cpp:71-139).  Trees of the reference's builders and of the LBVH refit are nested by construction; a caller's
+// tree that is not (snail_scene_create checks every child box against its parent's) takes the two-word loop, whose EXEC is the
+// inherited range [first, last] -- the reference's rescan exactly.  Workbench build: SNAIL_DEBUG_NO_PACK=1 keeps the two-word form.
 int stackPack(const SnailScene *s) {
-	static const bool off = getenv("SNAIL_DEBUG_NO_PACK") && atoi(getenv("SNAIL_DEBUG_NO_PACK")) != 0;
-	return !off && s->nNodes <= (1 << 20) ? 1 : 0;
+	static const bool off = debugEnvInt("SNAIL_DEBUG_NO_PACK") != 0;
+	static const bool assumeNested = debugEnvInt("SNAIL_DEBUG_ASSUME_NESTED") != 0;   // (tests/nonnested_env.py: shows that the check below matters)
+	return !off && (s->nestedOK || assumeNested) && s->nNodes <= (1 << 20) ? 1 : 0;
 }
 
 int checkScene(const SnailScene *s, const char *fn) {
@@ -2576,13 +2595,13 @@ int launchPrimaryFrames(SnailScene *s, const FrameSet &FS, int resx, int resy, i
 	A.defer = s->dDefer[slot];
 	if(!s->deferDone[slot]) HIP_TRY(hipEventCreateWithFlags(&s->deferDone[slot], hipEventDisableTiming));
 	if(s->deferUsed[slot]) HIP_TRY(hipStreamWaitEvent(stream, s->deferDone[slot], 0));
-	// SNAIL_DEBUG_DYNLDS=<bytes>: occupancy experiments only (unused dynamic LDS limits waves per CU)
-	static const int dynLds = getenv("SNAIL_DEBUG_DYNLDS") ? atoi(getenv("SNAIL_DEBUG_DYNLDS")) : 0;
+	// workbench build, SNAIL_DEBUG_DYNLDS=<bytes>: occupancy experiments only (unused dynamic LDS limits waves per CU)
+	static const int dynLds = debugEnvInt("SNAIL_DEBUG_DYNLDS");
 	// a scene with sane records defers (practically) nothing: a handful of blocks suffices; an unsafe scene defers every packet
 	const int exactBlocks = A.fastOK ? (blocks < 8 ? blocks : 8) : (blocks < 2048 ? blocks : 2048);
 	static_assert(128 % SNAIL_BLOCK_WAVES == 0, "the slot count is a multiple of 128");
 	const dim3 grid(gridBlocks / SNAIL_BLOCK_WAVES), block(64 * SNAIL_BLOCK_WAVES);
-	if(dCost) { // diagnostic launch (snail_debug_packet_costs)
+	if(dCost) { // diagnostic launch (snail_account_packets)
 		if(useDeep(s)) hipLaunchKernelGGL(dev::k_primary_diag<true>, dim3(blocks), dim3(64), 0, stream, A);
 		else hipLaunchKernelGGL(dev::k_primary_diag<false>, dim3(blocks), dim3(64), 0, stream, A);
 	} else if(useDeep(s)) hipLaunchKernelGGL(dev::k_primary<true>, grid, block, dynLds, stream, A);
@@ -2744,7 +2763,7 @@ SnailScene *snail_scene_create(const void *nodes32, int nNodes, const void *tris
 	// ... and that no walk can run away: every node is reached at most once from the root (no cycle, no shared subtree: a back-edge
 	// would keep every wave in its loop for ever) and no leaf lies deeper than the caller says (the traversal stack is sized by
 	// `depth`: lane i of a VGPR pair = slot i, a second pair beyond 62 levels; a deeper tree would wrap the lane select)
-	int realDepth = 0;
+	int realDepth = 0, nestedOK = 1;
 	{
 		std::vector<uint8_t> seen((size_t)nNodes, 0);
 		std::vector<std::pair<int, int>> todo; // (node, level), root = level 0 as BVH::depth counts (src/bvh/tree.cpp:54-59)
@@ -2757,7 +2776,16 @@ SnailScene *snail_scene_create(const void *nodes32, int nNodes, const void *tris
 			if(level > realDepth) realDepth = level;
 			if(level > depth) { snail_set_error("snail_scene_create: node %d lies at level %d, deeper than the declared depth %d", i, level, depth); return nullptr; }
 			const uint32_t sub = nw[(size_t)i * 8 + 6];
-			if(!(sub & 0x80000000u)) { todo.emplace_back((int)sub + 1, level + 1); todo.emplace_back((int)sub, level + 1); }
+			if(!(sub & 0x80000000u)) {
+				todo.emplace_back((int)sub + 1, level + 1); todo.emplace_back((int)sub, level + 1);
+				// child box inside the parent's box, per axis (a NaN bound fails the comparison and counts as not nested)
+				const float *pb = (const float *)nodes32 + (size_t)i * 8;
+				for(int c = 0; c < 2; c++) {
+					const float *cb = (const float *)nodes32 + ((size_t)sub + c) * 8;
+					for(int k = 0; k < 3; k++)
+						if(!(cb[k] >= pb[k]) || !(cb[3 + k] <= pb[3 + k])) nestedOK = 0;
+				}
+			}
 		}
 	}
 	int fastOK = 1;
@@ -2777,7 +2805,7 @@ SnailScene *snail_scene_create(const void *nodes32, int nNodes, const void *tris
 	DeviceGuard guard(device);
 	if(!guard.ok) { snail_set_error("snail_scene_create: hipSetDevice(%d) failed", device); return nullptr; }
 	SnailScene *s = new SnailScene();
-	s->device = device; s->nNodes = nNodes; s->nTris = nTris; s->depth = realDepth; s->fastOK = fastOK; // the measured depth (<= declared) picks the stack form
+	s->device = device; s->nNodes = nNodes; s->nTris = nTris; s->depth = realDepth; s->fastOK = fastOK; s->nestedOK = nestedOK; // the measured depth (<= declared) picks the stack form
 	hipError_t e;
 	if((e = hipMalloc((void **)&s->dNodes, (size_t)nNodes * 32)) != hipSuccess || (e = hipMalloc((void **)&s->dTris, (size_t)nTris * 64)) != hipSuccess ||
 	   (e = hipMalloc((void **)&s->dStats, 4 * sizeof(unsigned long long))) != hipSuccess ||
@@ -2845,6 +2873,13 @@ int snail_scene_info(const SnailScene *s, int *nNodes, int *nTris, int *depth, i
 	if(nTris) *nTris = s->nTris;
 	if(depth) *depth = s->depth;
 	if(device) *device = s->device;
+	return 0;
+}
+
+int snail_scene_flags(const SnailScene *s, int *fastOK, int *nestedOK) {
+	if(!s) { snail_set_error("snail_scene_flags: null scene"); return 1; }
+	if(fastOK) *fastOK = s->fastOK;
+	if(nestedOK) *nestedOK = s->nestedOK;
 	return 0;
 }
 
@@ -3243,8 +3278,9 @@ int snail_planar_to_frame_dev(const int32_t *dTiles, const int64_t *dInOffsets, 
 	return 0;
 }
 
-int snail_delay_dev(float microseconds, void *stream) {
-	if(!(microseconds >= 0.0f) || microseconds > 10000.0f) { snail_set_error("snail_delay_dev: delay outside 0..10000 us"); return 1; }
+#ifdef SNAIL_DEBUG_API
+int snail_debug_delay_dev(float microseconds, void *stream) {
+	if(!(microseconds >= 0.0f) || microseconds > 10000.0f) { snail_set_error("snail_debug_delay_dev: delay outside 0..10000 us"); return 1; }
 	const unsigned ticks = (unsigned)(microseconds * 100.0f);
 	if(ticks == 0) return 0;
 	hipLaunchKernelGGL(dev::k_delay, dim3(1), dim3(64), 0, (hipStream_t)stream, ticks);
@@ -3338,18 +3374,20 @@ int snail_debug_occupancy(int out[4]) {
 	return 0;
 }
 
-int snail_debug_packet_costs(SnailScene *s, const float cam[13], int resx, int resy, uint32_t *out8) {
-	if(int rc = checkScene(s, "snail_debug_packet_costs")) return rc;
-	if(!out8) { snail_set_error("snail_debug_packet_costs: null output"); return 1; }
+#endif // SNAIL_DEBUG_API
+
+int snail_account_packets(SnailScene *s, const float cam[13], int resx, int resy, uint32_t *out8) {
+	if(int rc = checkScene(s, "snail_account_packets")) return rc;
+	if(!out8) { snail_set_error("snail_account_packets: null output"); return 1; }
 	DeviceGuard guard(s->device);
 	const int np = ((resx + 15) / 16) * ((resy + 15) / 16);
 	DevBuf c;
-	if(c.upload(nullptr, (size_t)np * 32)) { snail_set_error("snail_debug_packet_costs: allocation failed"); return 2; }
+	if(c.upload(nullptr, (size_t)np * 32)) { snail_set_error("snail_account_packets: allocation failed"); return 2; }
 	HIP_TRY(hipMemset(c.p, 0, (size_t)np * 32));
 	int rc = launchPrimary(s, cam, resx, resy, 0, 0, resx, resy, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, (unsigned *)c.p);
 	if(rc) return rc;
 	HIP_TRY(hipDeviceSynchronize());
-	if(c.download(out8, (size_t)np * 32)) { snail_set_error("snail_debug_packet_costs: download failed"); return 2; }
+	if(c.download(out8, (size_t)np * 32)) { snail_set_error("snail_account_packets: download failed"); return 2; }
 	return 0;
 }
 

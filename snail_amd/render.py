@@ -165,7 +165,7 @@ class DistributedRenderer:
                  payload: str = "rgb8", slots: int | None = None, stage_cpu: bool = False, force_collective: bool = False, lights7=None,
                  ambient=(0.1, 0.1, 0.1), color=(1.0, 1.0, 1.0), reflections: bool = False, feedback_order: bool = True, order_refresh: int = 16,
                  inline_collective: bool | None = None, rank0_share: float = 1.0, plan_ranks: int | None = None, plan_rank: int | None = None,
-                 stagger: bool = False, frames_per_launch: int = 1):
+                 frames_per_launch: int = 1):
         import torch
         self.torch = torch
         self.scene = scene
@@ -199,6 +199,7 @@ class DistributedRenderer:
         # is the fourth (asynchronous gather)
         self.nslots = max(1, slots) if slots is not None else (3 if self.multi and not self.inline else 4)
         self.streams = _stream_pool(torch, dev, self.nslots)
+        self._raw_stream_switch = self._probe_raw_stream_switch(self.streams[0]) if self.multi else False
         self.step = 0
         # frames_per_launch = B > 1 (single-GPU hit-record route): render() collects B cameras and traces them with ONE launch
         # (Scene.trace_primary_batch): the heaviest packets of all B frames start first, and a frame's tail -- its heaviest packets, ~0.2 ms
@@ -211,14 +212,7 @@ class DistributedRenderer:
         batch_ok = lights7 is None and (not multi_now or (payload == "rgb8" and (self.inline or stage_cpu)))
         self.batch = max(1, min(8, int(frames_per_launch))) if batch_ok else 1
         self.pending_cams, self.pending_events, self.pending_stats = [], None, None
-        # stagger: streams that all start from idle at the same moment stay in phase for many frames -- their grids are dispatched one
-        # after the other, so the later frames' heaviest packets start late and every round of `slots` frames ends in a common tail
-        # (0.43 ms per round of four 1080p frames instead of 0.356 once the phases have drifted apart, tools/timeline.py).  The first
-        # launch of stream k after an idle period is therefore preceded by a stream-ordered pause of k x 0.75 x (time per frame), the
-        # time per frame being the best one observed over the bursts so far (snail_delay_dev: one sleeping wave).
-        # (measured: no gain -- the streams re-lock within a few frames and the ramp costs more than it saves; kept as an option, default off)
-        self.stagger = bool(stagger) and self.nslots > 1
-        self.idle, self.burst_t0, self.burst_frames, self.frame_s_est = True, 0.0, 0, None
+        self.idle = True
         # one frame buffer per slot, for both payloads: the scatters of consecutive frames run on different streams and may overlap;
         # frame / frame_rgb8 name the buffer of the frame enqueued last (complete after flush(), or once the slot's stream has drained)
         # one rank with lights7: the staged config-3 pipeline writes the rgb8 frame directly (Scene.render_whitted), no hit-record frame
@@ -329,11 +323,7 @@ class DistributedRenderer:
         slot = self.step % self.nslots
         self.step += 1
         st = self.streams[slot]
-        if self.idle:
-            self.idle, self.burst_t0, self.burst_frames = False, time.perf_counter(), 0
-        if self.stagger and 0 < self.burst_frames < self.nslots and self.frame_s_est is not None:
-            sc.delay(self.burst_frames * 0.75 * self.frame_s_est * 1e6, stream=st)
-        self.burst_frames += 1
+        self.idle = False
         if not self.multi:      # every call below takes the stream explicitly: no stream context to enter (host time per frame matters)
             if events: events[0].record(st)
             if self.whitted_single:
@@ -359,17 +349,33 @@ class DistributedRenderer:
     def _on_stream(self, st, fn, *args):
         """fn(*args) with `st` as the current stream (what torch.distributed launches its collectives on), the caller's stream restored after"""
         torch = self.torch
-        try:
-            prev = torch._C._cuda_getCurrentStream(st.device_index)      # (stream_id, device_index, device_type) of the caller's stream
-            set_raw = torch._C._cuda_setStream
-        except AttributeError:                                           # another torch build: the documented (slower) way
+        if not self._raw_stream_switch:                                  # another torch build: the documented (slower) way
             with torch.cuda.stream(st):
                 return fn(*args)
+        prev = torch._C._cuda_getCurrentStream(st.device_index)          # (stream_id, device_index, device_type) of the caller's stream
+        set_raw = torch._C._cuda_setStream
         set_raw(stream_id=st.stream_id, device_index=st.device_index, device_type=st.device_type)
         try:
             return fn(*args)
         finally:
             set_raw(stream_id=prev[0], device_index=prev[1], device_type=prev[2])
+
+    def _probe_raw_stream_switch(self, st) -> bool:
+        """Once per renderer: do the private accessors behave as _on_stream assumes (a 3-tuple, keyword arguments, the switch observable
+        through the public API and undone afterwards)?  Anything else -> torch.cuda.stream(st)."""
+        torch = self.torch
+        try:
+            prev = torch._C._cuda_getCurrentStream(st.device_index)
+            if len(prev) != 3:
+                return False
+            torch._C._cuda_setStream(stream_id=st.stream_id, device_index=st.device_index, device_type=st.device_type)
+            try:
+                ok = torch.cuda.current_stream(st.device_index).cuda_stream == st.cuda_stream
+            finally:
+                torch._C._cuda_setStream(stream_id=prev[0], device_index=prev[1], device_type=prev[2])
+            return bool(ok)
+        except Exception:
+            return False
 
     def _render_multi(self, cam, stats, events, slot, st):
         torch = self.torch
@@ -432,9 +438,7 @@ class DistributedRenderer:
         slot = self.step % self.nslots
         self.step += 1
         st = self.streams[slot]
-        if self.idle:
-            self.idle, self.burst_t0, self.burst_frames = False, time.perf_counter(), 0
-        self.burst_frames += len(cams)
+        self.idle = False
         if self.multi:
             return self._on_stream(st, self._launch_batch_multi, cams, events, stats, slot, st)
         outs = self.batch_frames[slot][:len(cams)]
@@ -494,9 +498,5 @@ class DistributedRenderer:
                 self._finish(slot)
         for st in self.streams:
             st.synchronize()
-        if not self.idle:
-            if self.burst_frames >= self.nslots:
-                est = (time.perf_counter() - self.burst_t0) / self.burst_frames
-                self.frame_s_est = est if self.frame_s_est is None else min(self.frame_s_est, est)
-            self.idle = True
+        self.idle = True
         return self.frame_rgb8 if self.frame_rgb8 is not None else self.frame

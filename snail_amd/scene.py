@@ -225,11 +225,6 @@ class Scene:
         _lib.check(rc, "snail_order_from_cost_dev")
         return order
 
-    @staticmethod
-    def delay(microseconds: float, stream=None):
-        """A stream-ordered pause (snail_delay_dev): de-phases pipelined frame streams that start from idle."""
-        _lib.check(_lib.lib().snail_delay_dev(float(min(max(microseconds, 0.0), 10000.0)), _stream_ptr(stream)), "snail_delay_dev")
-
     def trace_packets(self, cam: Camera, resx: int, resy: int, packet_xy, out=None, stats=None, stream=None, order=None, slot_cost=None):
         """Trace an explicit packet list (int32 device tensor [n,2] of top-left pixels); results are
         packet-major [n,256] in the reference's quad order (t, u, v, tri_id).  `order` / `slot_cost`: optional int32 device tensors
@@ -438,14 +433,20 @@ class Scene:
         return out
 
     def packet_costs(self, cam: Camera, resx: int, resy: int) -> np.ndarray:
-        """Per-packet diagnostics of one full-frame primary launch (snail_debug_packet_costs; a diagnostic build of the packet code,
-        never a product path): uint32 [packets, 8] = {node visits, quad x triangle tests, shader cycles, start >> 6, triangle records
+        """Per-packet diagnostics of one full-frame primary launch (snail_account_packets; the packet code built with counters,
+        a measurement pass, never a product path): uint32 [packets, 8] = {node visits, quad x triangle tests, shader cycles, start >> 6, triangle records
         fetched, leaf bodies, 0, 0}, row-major over the packet grid."""
         np_ = ((resx + 15) // 16) * ((resy + 15) // 16)
         out = np.zeros((np_, 8), dtype=np.uint32)
         cam13 = np.ascontiguousarray(cam.as_array13(), dtype=np.float32)
-        _lib.check(_lib.lib().snail_debug_packet_costs(self._h, _lib.ptr(cam13), resx, resy, _lib.ptr(out)), "snail_debug_packet_costs")
+        _lib.check(_lib.lib().snail_account_packets(self._h, _lib.ptr(cam13), resx, resy, _lib.ptr(out)), "snail_account_packets")
         return out
+
+    def flags(self):
+        """(fastOK, nestedOK) as snail_scene_create found them (snail_scene_flags)."""
+        f, n = C.c_int(0), C.c_int(0)
+        _lib.check(_lib.lib().snail_scene_flags(self._h, C.addressof(f), C.addressof(n)), "snail_scene_flags")
+        return bool(f.value), bool(n.value)
 
     def last_launch(self):
         b, t = C.c_int(0), C.c_int(0)

@@ -85,6 +85,15 @@ class OracleScene:
         self.nodes = np.ascontiguousarray(nodes[:nn])
         self.depth = depth.value
 
+    @classmethod
+    def from_arrays(cls, tris, nodes, depth, perm=None):
+        """An oracle scene over a CALLER's tree (hand-made test trees): the same walk, no build."""
+        self = cls.__new__(cls)
+        self.tris = np.ascontiguousarray(np.asarray(tris).view(TRI_DTYPE))
+        self.nodes = np.ascontiguousarray(np.asarray(nodes).view(NODE_DTYPE))
+        self.depth, self.perm = int(depth), perm
+        return self
+
     def fnv_nodes(self) -> int:
         return lib().orc_fnv_nodes(_p(self.nodes), len(self.nodes))
 

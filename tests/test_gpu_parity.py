@@ -409,10 +409,58 @@ def test_walk_variants_selected_by_scene_size(torch_mod, env):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "walk_variants_env.py")], capture_output=True, text=True, timeout=300, cwd=root,
-                       env=dict(os.environ, **env))
+                       env=dict(os.environ, SNAIL_LIB_PATH=os.path.join(root, "snail_amd", "libsnailhip_debug.so"), **env))   # the switches exist in the workbench build only
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["primary"] and d["whitted_refl"] and d["rays"] and d["shadow"], d
+
+
+def test_non_nested_caller_tree(torch_mod):
+    """The C-ABI takes caller trees verbatim; nothing in the reference's walk needs a child box to lie inside its parent's (every box test
+    rescans the whole inherited quad range, src/bounding_box.cpp:71-139), while the record-prefetching node loop keeps only the parent's
+    survivors in EXEC.  snail_scene_create therefore checks nesting and routes a tree that is not nested to the loop that rescans the
+    range: primary frame, the light pipeline with the mirrored bounce, generic and shadow packets -- all bit-identical to the oracle's walk
+    of the SAME tree, TreeStats included.  The workbench build with SNAIL_DEBUG_ASSUME_NESTED=1 (the prefetching loop forced onto this
+    tree) must differ: the scene discriminates."""
+    import json
+    import subprocess
+    import sys
+    from snail_amd.scene import Scene
+    name, resx, resy = "atrium:0.02", 328, 200
+    tv, hb, _ = util.scene_pair(name)
+    hb2 = util.non_nested_tree(hb)
+    osc = O.OracleScene.from_arrays(hb2.tris, hb2.nodes, hb2.depth, hb2.perm)
+    cam = util.camera_for(name, tv)
+    ok = Scene(hb, 0)
+    assert ok.flags() == (True, True)
+    ok.close()
+    sc = Scene(hb2, 0)
+    assert sc.flags() == (True, False)
+    stats = sc.new_stats()
+    frame = sc.trace_primary(cam, resx, resy, stats=stats)
+    torch_mod.cuda.synchronize()
+    ref = osc.render_primary(cam.as_array13(), resx, resy, mode=O.MODE_IEEE)
+    compare_frames(frame, ref, "non-nested tree, primary")
+    assert np.array_equal(stats.cpu().numpy().astype(np.uint64), ref[4]), (stats.cpu().numpy(), ref[4])
+    # ... and the walk of the reference's own tree differs from it (the shrunk boxes cull what the real ones do not): not a no-op edit
+    assert not np.array_equal(ref[4], util.scene_pair(name)[2].render_primary(cam.as_array13(), resx, resy, mode=O.MODE_IEEE)[4])
+    bmin, bmax = hb.bbox()
+    c, e = (bmin + bmax) * 0.5, (bmax - bmin)
+    lights = np.array([[c[0], c[1] + 0.35 * e[1], c[2], 1.0, 0.9, 0.8, 2.0 * float(e.max())]], dtype=np.float32)
+    wst = sc.new_stats()
+    img = sc.render_whitted(cam, resx, resy, lights, stats=wst, reflections=True)
+    torch_mod.cuda.synchronize()
+    oimg, ost = osc.render_whitted(cam.as_array13(), resx, resy, lights, reflections=True)
+    assert img.cpu().numpy().tobytes() == oimg.tobytes(), "non-nested tree: light pipeline + mirrored bounce"
+    assert np.array_equal(wst.cpu().numpy().astype(np.uint64), ost), (wst.cpu().numpy(), ost)
+    sc.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for assume, want_equal in (("0", True), ("1", False)):
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "nonnested_env.py")], capture_output=True, text=True, timeout=300, cwd=root,
+                           env=dict(os.environ, SNAIL_LIB_PATH=os.path.join(root, "snail_amd", "libsnailhip_debug.so"), SNAIL_DEBUG_ASSUME_NESTED=assume))
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["flags"] == [True, False] and d["equal_to_oracle"] is want_equal, d
 
 
 def test_invalid_arguments_fail_loudly(torch_mod):
@@ -1179,7 +1227,7 @@ def test_hit_reciprocal_equals_ieee_division_for_every_float(torch_mod):
     import ctypes
     from snail_amd import _lib
     out = (ctypes.c_uint64 * 2)()
-    assert _lib.lib().snail_debug_recip_check(out) == 0
+    assert _lib.debug_lib().snail_debug_recip_check(out) == 0      # (the workbench build of the same sources: same recipExact())
     assert out[0] == 0, "%d of 2^32 reciprocals differ from 1.0f / x" % out[0]
     assert out[1] == 2 * 252 * (1 << 23)
 

@@ -23,8 +23,19 @@ def test_capi_exports_every_declared_symbol():
     lib = snail_amd.lib()
     for name in declared:
         assert hasattr(lib, name), "libsnailhip.so does not export " + name
-    from snail_amd._lib import SIGNATURES
+    from snail_amd._lib import SIGNATURES, DEBUG_SIGNATURES
     assert sorted(SIGNATURES) == declared          # the Python binding covers the whole header
+    # the contract carries no workbench: nothing named snail_debug_* in the product header, the product library or its binding
+    assert not [n for n in declared if "debug" in n]
+    assert not hasattr(lib, "snail_debug_recip_check") and not hasattr(lib, "snail_debug_delay_dev")
+    # ... and the workbench build exports the product C-ABI plus everything include/snail_hip_debug.h declares
+    dhdr = open(os.path.join(ROOT, "include", "snail_hip_debug.h")).read()
+    ddecl = sorted(set(re.findall(r"\b(snail_debug_[a-z_0-9]+)\s*\(", dhdr)))
+    assert sorted(DEBUG_SIGNATURES) == ddecl and len(ddecl) >= 6
+    from snail_amd._lib import debug_lib
+    dl = debug_lib()
+    for name in declared + ddecl:
+        assert hasattr(dl, name), "libsnailhip_debug.so does not export " + name
 
 
 def test_missing_extension_fails_loudly(monkeypatch, tmp_path):
@@ -234,3 +245,81 @@ def test_tile_layout_offsets():
     assert first.tolist() == np.concatenate([[0], np.cumsum(npk)[:-1]]).tolist()
     assert off.tolist() == np.concatenate([[0], np.cumsum([3 * w * h for _, _, w, h in tiles.tolist()])[:-1]]).tolist()
     assert total == 3 * 40 * 100 and len(R.tile_packets(tiles)) == sum(npk)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` WITHOUT torch.distributed.run (the shape of the driver's scaling command) must start its N ranks itself
+    -- as a child process, before anything touches a GPU -- and relay rank 0's JSON line and the exit status.  --dry-run stops after the
+    rendezvous and one all-reduce (gloo here), so this runs without a GPU."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-run"], capture_output=True, text=True,
+                       timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout           # ONE JSON line: rank 0's
+    d = json.loads(lines[0])
+    assert d == {"dry_run": True, "ranks": 2, "n_gpus": 2, "backend": "gloo"}
+    # the status of a failing child is relayed too (here: the ranks refuse to run without a GPU)
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0"], capture_output=True,
+                           text=True, timeout=300, env=env, cwd=ROOT)
+        assert r.returncode != 0 and "needs an MI355X" in (r.stdout + r.stderr)
+
+
+def test_kernel_resource_budget():
+    """The register budget the measurements rest on, from the compiler's own report (`make -C snail_amd/csrc asm`,
+    -Rpass-analysis=kernel-resource-usage): the hand-written node loop pins s[68:91] through clobber lists and the primary kernel sits at
+    its occupancy step -- a compiler or source change that spills, or that costs a wave, must fail HERE and not show up as a slower bench."""
+    import subprocess
+    csrc = os.path.join(ROOT, "snail_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "asm"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rep = open(os.path.join(csrc, "snail_hip.resources")).read()
+    kernels = {}
+    cur = None
+    for line in rep.splitlines():
+        m = re.search(r"remark:\s+Function Name: (\S+)", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\S+) \[-Rpass", line)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = m.group(2)
+    budget = json_budget()
+    for name, want in budget.items():
+        hits = [k for k in kernels if name in k]
+        assert hits, "no kernel matching %s in the resource report" % name
+        for k in hits:
+            got = kernels[k]
+            assert int(got["VGPRs"]) <= want["vgprs"], (k, got)
+            assert int(got["Occupancy"]) >= want["waves"], (k, got)
+            assert int(got["VGPRs Spill"]) <= want.get("vgpr_spill", 0) and int(got["SGPRs Spill"]) <= want.get("sgpr_spill", 0), (k, got)
+            # (the asm statements clobber s68..s91 by name; a build in which the allocator ran out of room shows up as SGPR spills above)
+
+
+def json_budget():
+    """mangled-name fragment -> {vgprs (max), waves per SIMD (min), vgpr_spill (max)}; DESIGN.md section 3 quotes these"""
+    return {
+        "k_primaryILb0E": {"vgprs": 80, "waves": 6},
+        "k_shadowILb0E": {"vgprs": 80, "waves": 6, "vgpr_spill": 8, "sgpr_spill": 8},      # (compiled to a six-wave budget: a few cold spills)
+        "k_lightILb0ELi0E": {"vgprs": 80, "waves": 6, "vgpr_spill": 8, "sgpr_spill": 8},
+        "k_lightILb0ELi1E": {"vgprs": 80, "waves": 6, "vgpr_spill": 8, "sgpr_spill": 8},
+    }
+
+
+def test_counters_carry_the_kernel_hash():
+    """profiles/traffic.json stores the hash of the kernel sources its PMC counters were measured on; bench.py compares it with the
+    sources it runs and says `counters_stale` when they differ (the roofline must not price a new kernel with an old instruction count)."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    d = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    assert re.fullmatch(r"[0-9a-f]{16}", d.get("_kernel_sha16", "")), "tools/make_traffic.py stores _kernel_sha16"
+    tr = b.pmc_counters("atrium_1920x1080_n1_c1")
+    assert tr is not None and tr["_stale"] == (d["_kernel_sha16"] != b.kernel_source_sha16())

@@ -1,5 +1,8 @@
 """Do consecutive dispatches of ONE stream overlap when launched with hipExtAnyOrderLaunch (AQL barrier bit cleared)?  hip_ext.h says the
 flag is not supported on GFX9xx; this measures it: 20 full-frame primary launches back to back on one stream, with flags 0 and 1."""
+import os as _os
+_os.environ.setdefault("SNAIL_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "snail_amd", "libsnailhip_debug.so"))  # workbench build (snail_debug_*)
+
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

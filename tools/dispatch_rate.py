@@ -1,5 +1,8 @@
 """What the workgroup dispatcher sustains with empty kernels: ms per launch and workgroups per microsecond for the grid shapes
 of the primary kernel (one wave per block) and fatter blocks."""
+import os as _os
+_os.environ.setdefault("SNAIL_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "snail_amd", "libsnailhip_debug.so"))  # workbench build (snail_debug_*)
+
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

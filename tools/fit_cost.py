@@ -11,7 +11,7 @@ for name in ("atrium", "stress"):
     out = np.zeros((ph * pw, 8), dtype=np.uint32)
     cam13 = np.ascontiguousarray(cam.as_array13(), dtype=np.float32)
     for rep in range(3):
-        _lib.check(_lib.lib().snail_debug_packet_costs(sc._h, _lib.ptr(cam13), resx, resy, _lib.ptr(out)), "costs")
+        _lib.check(_lib.lib().snail_account_packets(sc._h, _lib.ptr(cam13), resx, resy, _lib.ptr(out)), "costs")
     it, isc, cyc = (out[:, k].astype(np.float64) for k in range(3))
     A = np.stack([it, isc, np.ones_like(it)], 1)
     coef, *_ = np.linalg.lstsq(A, cyc, rcond=None)

@@ -16,7 +16,7 @@ pw, ph = (resx + 15) // 16, (resy + 15) // 16
 out = np.zeros((ph * pw, 8), dtype=np.uint32)
 cam13 = np.ascontiguousarray(cam.as_array13(), dtype=np.float32)
 for rep in range(2):
-    _lib.check(_lib.lib().snail_debug_packet_costs(sc._h, _lib.ptr(cam13), resx, resy, _lib.ptr(out)), "costs")
+    _lib.check(_lib.lib().snail_account_packets(sc._h, _lib.ptr(cam13), resx, resy, _lib.ptr(out)), "costs")
 iters = out[:, 0].astype(np.int64)                     # node visits: a cost proxy that a product path could return for free
 ys, xs = np.divmod(np.arange(pw * ph), pw)
 xy_all = np.stack([xs * 16, ys * 16], axis=1).astype(np.int32)

@@ -19,4 +19,9 @@ for a in sys.argv[1:]:
                         "separate passes with --kernel-trace only, mean over the dev::k_primary<false> dispatches (one frame each) of `python bench.py --steps 10 --warmup 2 --no-cpu-baseline --frames-per-launch 1` of this workload; "
                         "SQ_INSTS_VALU from the sq1 pass" % (os.path.basename(f), v["FETCH_SIZE"], v["WRITE_SIZE"])}
     print(key, d[key]["bytes_per_launch"], d[key]["valu_insts_per_launch"])
+import hashlib
+h = hashlib.sha256()
+for f in ("snail_hip.hip", "lbvh.inc", "render_host.inc"):     # bench.py kernel_source_sha16(): the sources these counters were measured on
+    h.update(open(os.path.join(ROOT, "snail_amd", "csrc", f), "rb").read())
+d["_kernel_sha16"] = h.hexdigest()[:16]
 json.dump(d, open(path, "w"), indent=1)

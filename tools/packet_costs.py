@@ -1,4 +1,4 @@
-"""Load-balance study: per-packet cost of one primary frame (diagnostic entry snail_debug_packet_costs)."""
+"""Load-balance study: per-packet cost of one primary frame (diagnostic entry snail_account_packets)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -14,7 +14,7 @@ pw, ph = (resx + 15) // 16, (resy + 15) // 16
 out = np.zeros((ph * pw, 8), dtype=np.uint32)
 cam13 = np.ascontiguousarray(cam.as_array13(), dtype=np.float32)
 for rep in range(3):
-    _lib.check(_lib.lib().snail_debug_packet_costs(sc._h, _lib.ptr(cam13), resx, resy, _lib.ptr(out)), "costs")
+    _lib.check(_lib.lib().snail_account_packets(sc._h, _lib.ptr(cam13), resx, resy, _lib.ptr(out)), "costs")
 it, isect, cyc, start = (out[:, k].astype(np.float64) for k in range(4))
 print("packets", len(out), "iters mean %.1f max %d" % (it.mean(), it.max()), "isect mean %.1f max %d" % (isect.mean(), isect.max()))
 q = np.percentile(cyc, [5, 25, 50, 75, 90, 99, 100])

@@ -1,6 +1,9 @@
 """How the frame rate develops from an idle GPU: after `idle` seconds without work, 600 pipelined frames with a HIP event after every
 10th; prints ms per frame for each chunk of 10 (on the event's stream: coarse, but the trend is what matters) and the GPU clock that
 rocm-smi reports before / after.  Usage: python tools/ramp.py [idle_seconds]"""
+import os as _os
+_os.environ.setdefault("SNAIL_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "snail_amd", "libsnailhip_debug.so"))  # workbench build (snail_debug_*)
+
 import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -14,7 +14,7 @@ stag = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 tv = scenes.scene_by_name("atrium"); h = HostBVH.build(tv)
 cam = FPSCamera(*scenes.atrium_camera()).camera()
 sc = Scene(h, 0)
-rnd = DistributedRenderer(sc, 1920, 1080, 0, 1, slots=ns, stagger=bool(stag))
+rnd = DistributedRenderer(sc, 1920, 1080, 0, 1, slots=ns)
 for rep in range(3):
     for _ in range(warm): rnd.render(cam)
     rnd.flush(); torch.cuda.synchronize()
