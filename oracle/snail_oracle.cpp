@@ -10,6 +10,7 @@
 
 #include "snail_oracle.h"
 
+#include <emmintrin.h>
 #include <xmmintrin.h>
 
 #include <algorithm>
@@ -814,6 +815,8 @@ uint64_t fnv1a(uint64_t h, const void *p, size_t n) {
 	return h;
 }
 
+#include "snail_sse4.inc"
+
 } // namespace
 
 extern "C" {
@@ -897,6 +900,11 @@ void orc_render_primary(const OrcNode *nodes, const OrcTri *tris, const OrcCamer
 						int h, float *t, float *u, float *v, int32_t *triId, uint64_t *stats, int mode, int threads) {
 	if(mode == ORC_MODE_SSE) renderPrimary<ORC_MODE_SSE>(nodes, tris, cam, resx, resy, x0, y0, w, h, t, u, v, triId, stats, threads);
 	else renderPrimary<ORC_MODE_IEEE>(nodes, tris, cam, resx, resy, x0, y0, w, h, t, u, v, triId, stats, threads);
+}
+
+void orc_render_primary_sse4(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam, int resx, int resy, int x0, int y0, int w,
+							 int h, float *t, float *u, float *v, int32_t *triId, uint64_t *stats, int threads) {
+	sse4::renderPrimary(nodes, tris, cam, resx, resy, x0, y0, w, h, t, u, v, triId, stats, threads);
 }
 
 void orc_account_primary(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam, int resx, int resy, int x0, int y0, int w,

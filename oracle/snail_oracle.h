@@ -84,6 +84,13 @@ void orc_render_primary(const OrcNode *nodes, const OrcTri *tris, const OrcCamer
                         float *t, float *u, float *v, int32_t *triId, uint64_t *stats,
                         int mode, int threads);
 
+/* orc_render_primary in ORC_MODE_SSE written FOUR LANES WIDE with SSE intrinsics (oracle/snail_sse4.inc: one SSE quad per __m128, as the
+ * reference's f32x4 code runs: src/bounding_box.cpp:61-142, src/triangle.cpp:3-63): bit-identical outputs and TreeStats
+ * (tests/test_oracle_semantics.py::test_sse4_port_equals_scalar_oracle); this is the timed CPU baseline of bench.py ("port-sse4"). */
+void orc_render_primary_sse4(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam,
+                             int resx, int resy, int x0, int y0, int w, int h,
+                             float *t, float *u, float *v, int32_t *triId, uint64_t *stats, int threads);
+
 /* Single-ray, cache-less accounting walk of SURVEY.md section 8(d): for every pixel of the rect (padded
  * to whole packets as above) walk the tree with that ray alone (child order from its own direction
  * signs, strict-< closest-hit pruning) and count V_n (node boxes tested) and V_t (triangles tested).

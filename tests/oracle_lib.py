@@ -22,8 +22,8 @@ _lib = None
 
 
 def build():
-    src = os.path.join(ORACLE_DIR, "snail_oracle.cpp")
-    if (not os.path.exists(LIB_PATH)) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("snail_oracle.cpp", "snail_sse4.inc", "snail_oracle.h")]
+    if (not os.path.exists(LIB_PATH)) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
 
 
@@ -44,6 +44,7 @@ def lib():
         L.orc_trace_rays.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, u64p, i32]
         L.orc_trace_shadow.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, u64p, i32]
         L.orc_render_primary.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, u64p, i32, i32]
+        L.orc_render_primary_sse4.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, u64p, i32]
         L.orc_account_primary.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, u64p, i32, i32]
         L.orc_shade_depth.argtypes = [vp, i32, vp, i32]
         L.orc_planar_encode_tile.argtypes = [vp, i32, i32, i32, i32, i32, vp]
@@ -110,6 +111,18 @@ class OracleScene:
         stats = np.zeros(4, dtype=np.uint64)
         lib().orc_render_primary(_p(self.nodes), _p(self.tris), _p(cam), resx, resy, x0, y0, w, h,
                                  _p(t), _p(u), _p(v), _p(tid), _p(stats), mode, threads)
+        return t, u, v, tid, stats
+
+    def render_primary_sse4(self, cam13: np.ndarray, resx, resy, rect=None, threads=8):
+        """render_primary(mode=MODE_SSE) through the 4-wide SSE-intrinsics port (orc_render_primary_sse4): same outputs, same TreeStats"""
+        x0, y0, w, h = rect if rect else (0, 0, resx, resy)
+        cam = np.ascontiguousarray(cam13, dtype=np.float32)
+        t = np.full((resy, resx), np.nan, dtype=np.float32)
+        u = np.zeros((resy, resx), dtype=np.float32)
+        v = np.zeros((resy, resx), dtype=np.float32)
+        tid = np.zeros((resy, resx), dtype=np.int32)
+        stats = np.zeros(4, dtype=np.uint64)
+        lib().orc_render_primary_sse4(_p(self.nodes), _p(self.tris), _p(cam), resx, resy, x0, y0, w, h, _p(t), _p(u), _p(v), _p(tid), _p(stats), threads)
         return t, u, v, tid, stats
 
     def account_primary(self, cam13, resx, resy, rect=None, mode=MODE_IEEE, threads=8):

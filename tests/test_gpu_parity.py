@@ -329,18 +329,27 @@ def sse_path_counts(torch_mod, name, resx=1920, resy=1080):
 @pytest.mark.parametrize("name", ["atrium", "stress"])
 def test_sse_path_full_size_counted(torch_mod, name):
     """north_star's bar against the reference's SSE arithmetic at BASELINE size (1920x1080; atrium = configs 1-3, stress = config 5):
-    hit/miss flips and triId mismatches are COUNTED and asserted against committed bounds (tests/golden/sse_bounds.json, recorded on an
-    MI355X box by tools/sse_counts.py; x86 vendors differ in rcpps / rsqrtps, hence bounds, not equalities), every mismatch is a
-    near-tie in t, and t / u / v stay within 1e-4."""
+    hit/miss flips, triId mismatches and out-of-tolerance pixels are COUNTED and compared with the committed counts of
+    tests/golden/sse_bounds.json (recorded on MI355X boxes by tools/sse_counts.py, keyed by the host CPU's rcpps / rsqrtps fingerprint):
+    EQUAL on a CPU the file knows; on another CPU (x86 vendors differ in the low bits of rcpps / rsqrtps) within 1.5 x + 16 of the
+    largest recorded count.  Every mismatch of the same-rays leg is a tie in t, and t / u / v stay within 1e-4 there without exception."""
     import json
+    from tests.test_oracle_pins import rcp_fingerprint
     res = sse_path_counts(torch_mod, name)
-    bounds = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sse_bounds.json")))[name]
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sse_bounds.json")))
+    keys = ("hit_miss_flips", "triId_mismatches", "t_outside_tol_same_tri", "uv_outside_tol_same_tri", "mismatches_not_near_tie")
+    known = gold["by_cpu"].get(rcp_fingerprint())
+    assert gold["by_cpu"], "tests/golden/sse_bounds.json holds no recorded counts"
     for legname in ("same_rays", "device_rays"):
-        r, b = res[legname], bounds[legname]
+        r = res[legname]
         assert r["rays"] == (1920 * 1080 if legname == "device_rays" else 1920 * 1088)
         assert r["hits"] > 0.5 * r["rays"]
-        for key in ("hit_miss_flips", "triId_mismatches", "t_outside_tol_same_tri", "uv_outside_tol_same_tri", "mismatches_not_near_tie"):
-            assert r[key] <= b[key + "_max"], (legname, key, r)
+        for key in keys:
+            if known is not None:
+                assert r[key] == known[name][legname][key], (legname, key, r[key], known[name][legname][key])
+            else:
+                worst = max(e[name][legname][key] for e in gold["by_cpu"].values())
+                assert r[key] <= gold["elsewhere"]["factor"] * worst + gold["elsewhere"]["plus"], (legname, key, r[key], worst)
     # same rays: nothing but Inv(det) differs (src/triangle.cpp:55) -- the bar holds without exception: no ray changes between hit and
     # miss, t / u / v within 1e-4 wherever the triangle is the same, and a different triangle only where the two distances tie
     s_ = res["same_rays"]
@@ -685,12 +694,22 @@ def test_two_rank_bench_rehearsal(torch_mod, extra, scaling, res):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--backend", "gloo", "--scene", "atrium:0.05"] + extra
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
+    tail = ["--gpus", "2", "--steps", "6", "--warmup", "2", "--backend", "gloo", "--scene", "atrium:0.05"] + extra
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    if extra in ([], ["--frames-per-launch", "1"]):
+        # the PLAIN command, as the driver's scaling run issues it: bench.py starts its own two ranks (a child torch.distributed.run)
+        cmd = [sys.executable, os.path.join(root, "bench.py")] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+               os.path.join(root, "bench.py")] + tail
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["config"]["ranks"] == 2 and d["config"]["frames_in_flight"] >= 1 and d["config"]["lone_launch_ms"] > 0
+    assert d["config"]["frames_per_launch"] == (1 if "--frames-per-launch" in extra or "--config" in extra else d["config"]["frames_per_launch"])
+    assert "roofline" in d and d["roofline"]["peak"] == pytest.approx(2 * 1228.8)
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and d["scaling"] == scaling
     assert d["config"]["primary_rays_per_step"] == (res[0] // 16) * ((res[1] + 15) // 16) * 256
     assert sum(d["config"]["packets_per_rank"]) * 256 == d["config"]["primary_rays_per_step"]

@@ -144,3 +144,18 @@ def test_planar_tile_format_known_answer_and_round_trip():
     assert planes[0][0] == 200 and planes[0][16 * 64] == 76 and planes[0][2 * 16 * 64] == 66
     assert all(len(p) == 3 * 16 * 64 for p in planes)
     assert np.array_equal(O.planar_decode(planes, tiles, 48, 64), frame)
+
+
+@pytest.mark.parametrize("name,resx,resy", [("box", 256, 256), ("atrium:0.05", 328, 200), ("stress:0.05", 200, 120), ("chain", 96, 64)])
+def test_sse4_port_equals_scalar_oracle(name, resx, resy):
+    """The 4-wide SSE-intrinsics port of the primary path (oracle/snail_sse4.inc: what bench.py times as `cpu_baseline`, kind "port-sse4")
+    is the scalar restatement in ORC_MODE_SSE bit for bit: t, u, v, triId of every pixel and the TreeStats counters."""
+    from tests import util
+    tv, hb, osc = util.scene_pair(name)
+    cam = util.camera_for(name, tv)
+    a = osc.render_primary(cam.as_array13(), resx, resy, mode=O.MODE_SSE, threads=4)
+    b = osc.render_primary_sse4(cam.as_array13(), resx, resy, threads=4)
+    for x, y, what in zip(a[:4], b[:4], "t u v triId".split()):
+        util.assert_bit_equal(x, y, "%s %s" % (name, what))
+    assert np.array_equal(a[4], b[4]), (a[4], b[4])
+    assert np.isfinite(a[0]).sum() > 0
