@@ -107,12 +107,15 @@ public:
 	}
 
 	// ---- frame prefetch ----
-	template <class CameraT> void BeginFrame(const CameraT &cam, int resx, int resy) {
+	// (const over mutable state: the prefetched frame is a cache of what TraversePrimary would compute, and the reference's renderers
+	// take the scene by const reference, src/render.h:16-23)
+	template <class CameraT> void BeginFrame(const CameraT &cam, int resx, int resy) const {
 		TraceFrame(scene, cam, resx, resy, frame);
 		haveFrame = true;
 		statsPending.store(true);   // the frame's TreeStats (one launch = one total) go to the first packet that is copied out
 	}
-	void EndFrame() { haveFrame = false; }
+	void EndFrame() const { haveFrame = false; }
+	bool HaveFrame() const { return haveFrame; }
 	// the host's packet loop (RenderTask::Work, src/render.cpp:67-68) announces the packet it is about to trace
 	void SetPacket(int x, int y) const { curPacket = haveFrame ? (long)frame.packetIndex(x, y) : -1; }
 
@@ -161,8 +164,8 @@ public:
 private:
 	const RefBVH *ref = nullptr;
 	SnailScene *scene = nullptr;
-	FrameHits frame;
-	bool haveFrame = false;
+	mutable FrameHits frame;
+	mutable bool haveFrame = false;
 	mutable std::atomic<bool> statsPending{false};
 	static inline thread_local long curPacket = -1;   // per render thread (thread_pool workers, src/thread_pool.cpp)
 };
@@ -252,6 +255,23 @@ private:
 // scene.ambientLight, the default material's colour (Scene::Scene sets (1,1,1), src/scene.cpp:6-10; SimpleMaterial::color is private,
 // hence a parameter), gVals[1] (depth shading) and gVals[7] (one mirrored bounce).  Textured materials / full shading data (gVals[6])
 // stay with the host path (HipBVH under the reference's own Render).
+// The reference's renderer reads more global switches than that (src/rtbase.cpp:16, toggled by F-keys, broadcast to the render nodes
+// every frame: src/server.cpp:372-376).  Those the device pipeline does NOT implement -- a call with one of them set must not come back
+// as a plain frame with status 0: the Render(...) overloads below hand such a call to the reference's own renderer over the
+// prefetched HipBVH path (the reference's RenderTask::Work then does its 4x antialiasing, full shading, tints ... itself, and its
+// TraversePrimary calls copy pre-traced packets), or abort with this message when SNAIL_ADAPTER_NO_HOST_RENDERER is defined.
+//   gVals[9]  4x antialiasing: four sub-packets per packet at twice the resolution + 2x2 box filter   src/render.cpp:60,71-110
+//   gVals[6]  full shading (materials, textures, transparency selection) when the scene carries shading data   src/scene_trace.cpp:145
+//   gVals[5]  TreeStats visualisation   src/scene_trace.cpp:513-517
+//   gVals[8]  per-rank tint of the render nodes' tiles (colorizeNodes: the tile-list Render only)   src/render.cpp:118-132
+inline const char *UnsupportedSwitch(const int *gv, bool hasShadingData, bool tileList) {
+	if(gv[9]) return "gVals[9] (4x antialiasing, src/render.cpp:60,71-110)";
+	if(gv[6] && hasShadingData) return "gVals[6] (full shading: materials / textures, src/scene_trace.cpp:145)";
+	if(gv[5]) return "gVals[5] (TreeStats visualisation, src/scene_trace.cpp:513-517)";
+	if(gv[8] && tileList) return "gVals[8] (per-rank tint of the tiles, src/render.cpp:118-132)";
+	return nullptr;
+}
+
 struct RenderMode {
 	bool depthShading = false;  // gVals[1]
 	bool reflections = false;   // gVals[7]
@@ -315,10 +335,29 @@ inline StatsT RenderImage(const SceneT &scene, const CameraT &camera, ImageT &im
 // the reference's `template <class AccStruct> TreeStats Render(const Scene<AccStruct>&, ...)`, so a call with a
 // Scene<snail::HipBVH<BVH>> resolves here and the whole tile list / image is rendered by the device pipeline.
 #ifdef SNAIL_ADAPTER_RENDER_OVERLOADS
+// A call the device pipeline cannot honour (snail::UnsupportedSwitch): the reference's own renderer does the frame, fed by ONE prefetch
+// launch -- Render<snail::HipBVH<RefBVH>>(...) with the template argument spelled out names the reference's generic template
+// (src/render.h:16-23; instantiate it for snail::HipBVH<BVH> beside src/render.cpp:283-287), whose RenderTask::Work
+// announces each packet with geometry.SetPacket(x, y).  With 4x antialiasing the rays are generated for twice the resolution
+// (src/render.cpp:60-62), so that is the frame that is prefetched.
+#ifdef SNAIL_ADAPTER_NO_HOST_RENDERER
+#define SNAIL_HOST_RENDER(why, scale, w, h, call)                                                                                           \
+	do { std::fprintf(stderr, "FATAL: snail Render(): %s is set and the device pipeline does not implement it (and SNAIL_ADAPTER_NO_HOST_RENDERER)\n", why); std::abort(); } while(0)
+#else
+#define SNAIL_HOST_RENDER(why, scale, w, h, call)                                                                                           \
+	do {                                                                                                                                   \
+		scene.geometry.BeginFrame(camera, (int)(w) * (scale), (int)(h) * (scale));                                                         \
+		const TreeStats st_ = call;                                                                                                        \
+		scene.geometry.EndFrame();                                                                                                         \
+		return st_;                                                                                                                        \
+	} while(0)
+#endif
 template <class RefBVH>
 inline TreeStats Render(const Scene<snail::HipBVH<RefBVH>> &scene, const Camera &camera, uint resx, uint resy, unsigned char *data, const vector<int> &coords,
 						const vector<int> &offsets, const Options options, uint rank, uint threads) {
-	(void)rank; (void)threads; // debug tint (gVals[8]) and the host thread pool have no device counterpart
+	if(const char *why = snail::UnsupportedSwitch(gVals, scene.geometry.HasShadingData(), true))
+		SNAIL_HOST_RENDER(why, gVals[9] ? 2 : 1, resx, resy, Render<snail::HipBVH<RefBVH>>(scene, camera, resx, resy, data, coords, offsets, options, rank, threads));
+	(void)rank; (void)threads; // (no tint requested; the host thread pool has no device counterpart)
 	snail::RenderMode mode;
 	mode.depthShading = gVals[1] != 0;
 	mode.reflections = gVals[7] != 0 || options.reflections;
@@ -326,10 +365,13 @@ inline TreeStats Render(const Scene<snail::HipBVH<RefBVH>> &scene, const Camera 
 }
 template <class RefBVH>
 inline TreeStats Render(const Scene<snail::HipBVH<RefBVH>> &scene, const Camera &camera, MipmapTexture &image, const Options options, uint threads) {
+	if(const char *why = snail::UnsupportedSwitch(gVals, scene.geometry.HasShadingData(), false))
+		SNAIL_HOST_RENDER(why, gVals[9] ? 2 : 1, image.Width(), image.Height(), Render<snail::HipBVH<RefBVH>>(scene, camera, image, options, threads));
 	(void)threads;
 	snail::RenderMode mode;
 	mode.depthShading = gVals[1] != 0;
 	mode.reflections = gVals[7] != 0 || options.reflections;
 	return snail::RenderImage<TreeStats>(scene, camera, image, mode);
 }
+#undef SNAIL_HOST_RENDER
 #endif

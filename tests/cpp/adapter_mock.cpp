@@ -78,12 +78,19 @@ template <class AccStruct> struct Scene {       // src/scene.h:26-58: the member
 	vector<Light> lights;
 };
 // the reference's own generic Render templates (src/render.h:16-23): must LOSE overload resolution against the adapter's
+// ... for a call the device pipeline implements; a call with a switch it does not implement (gVals[5], [6], [8], [9]) must ARRIVE here,
+// with the frame the reference's RenderTask::Work is going to ask for already prefetched (twice the resolution under 4x antialiasing)
+static int g_expectHostRender = 0;
 template <class AccStruct>
-TreeStats Render(const Scene<AccStruct> &, const Camera &, uint, uint, unsigned char *, const vector<int> &, const vector<int> &, const Options, uint, uint) {
-	std::puts("generic tile Render called"); std::exit(3);
+TreeStats Render(const Scene<AccStruct> &scene, const Camera &, uint, uint, unsigned char *, const vector<int> &, const vector<int> &, const Options, uint, uint) {
+	if(!g_expectHostRender) { std::puts("generic tile Render called"); std::exit(3); }
+	std::printf("host tile Render: prefetched %d x %d %d\n", scene.geometry.Frame().resx, scene.geometry.Frame().resy, (int)scene.geometry.HaveFrame());
+	TreeStats st; st.it = 777; return st;
 }
-template <class AccStruct> TreeStats Render(const Scene<AccStruct> &, const Camera &, MipmapTexture &, const Options, uint) {
-	std::puts("generic image Render called"); std::exit(3);
+template <class AccStruct> TreeStats Render(const Scene<AccStruct> &scene, const Camera &, MipmapTexture &, const Options, uint) {
+	if(!g_expectHostRender) { std::puts("generic image Render called"); std::exit(3); }
+	std::printf("host image Render: prefetched %d x %d %d\n", scene.geometry.Frame().resx, scene.geometry.Frame().resy, (int)scene.geometry.HaveFrame());
+	TreeStats st; st.it = 778; return st;
 }
 
 #define SNAIL_ADAPTER_RENDER_OVERLOADS
@@ -187,6 +194,23 @@ int main(int argc, char **argv) {
 		const TreeStats si = Render(scene, cam, img, Options(), 4u);
 		f = std::fopen((d + "out_image.bin").c_str(), "wb"); dump(f, img.bytes); std::fclose(f);
 		std::fprintf(fs, "image %u %u %u %u %d\n", si.in, si.it, si.rays, si.sk, img.pitch);
+	}
+	// ---- a switch the device pipeline does not implement: the call must reach the reference's own renderer (the generic templates above),
+	// prefetched; meta[7] = index into gVals (5, 6, 8, 9), 0 = skip ----
+	if(meta.size() > 7 && meta[7] > 0) {
+		const int sw = meta[7];
+		gVals[7] = 0; gVals[1] = 0; gVals[sw] = 1;
+		if(sw == 6) bvh.shTris.resize(bvh.tris.size());        // full shading needs shading data (src/scene_trace.cpp:145)
+		g_expectHostRender = 1;
+		const std::vector<int> coords = slurp<int>(d + "tiles.bin"), offsets = slurp<int>(d + "offsets.bin");
+		std::vector<unsigned char> data(1 << 20, 0);
+		const TreeStats st = Render(scene, cam, (uint)resx, (uint)resy, data.data(), coords, offsets, Options(), 0u, 4u);
+		MipmapTexture img; img.w = resx; img.h = resy; img.pitch = resx * 3; img.bytes.assign((size_t)img.pitch * resy, 0);
+		// (gVals[8], the tint, belongs to the tile-list renderer only -- colorizeNodes: with it set the image call stays on the device)
+		g_expectHostRender = sw == 8 ? 0 : 1;
+		const TreeStats si = Render(scene, cam, img, Options(), 4u);
+		std::printf("switch %d: tile stats %u image stats %u frame left %d\n", sw, st.it, si.it, (int)acc.HaveFrame());
+		gVals[sw] = 0; g_expectHostRender = 0;
 	}
 	std::fclose(fs);
 	std::printf("adapter ok: %d x %d, normal of tri 0 = %g %g %g\n", resx, resy, acc.GetNormal(0, 0).x, acc.GetNormal(0, 0).y, acc.GetNormal(0, 0).z);

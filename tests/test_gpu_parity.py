@@ -632,6 +632,38 @@ def test_cpp_adapter_end_to_end(torch_mod, tmp_path, refl, depth_mode):
         assert 0 < stats["tiles"][1] < int(wst[1]) and stats["tiles"][2] >= len(R.tile_packets(tiles)) * 256
 
 
+@pytest.mark.parametrize("sw", [5, 6, 8, 9])
+def test_cpp_adapter_render_honours_or_hands_over(torch_mod, tmp_path, sw):
+    """Render(...) with the reference's signatures must not silently drop a switch of the reference's renderer that the device pipeline
+    does not implement (gVals[5] stats heat-map, [6] full shading on a scene with shading data, [8] per-rank tint of the tile list, [9] 4x
+    antialiasing): such a call is handed to the reference's OWN renderer (here: the mock's generic Render templates) with the frame it
+    will ask for prefetched by one launch -- at twice the resolution under antialiasing (src/render.cpp:60-62) -- and the prefetch is
+    released afterwards."""
+    import subprocess
+    from snail_amd import render as R
+    from tests.test_host_side import build_adapter_mock
+    name = "atrium:0.02"
+    tv, hb, osc = util.scene_pair(name)
+    cam = util.camera_for(name, tv)
+    resx, resy = 128, 64
+    d = tmp_path
+    hb.nodes.tofile(str(d / "nodes.bin")); hb.tris.tofile(str(d / "tris.bin"))
+    np.ascontiguousarray(cam.as_array13(), dtype=np.float32).tofile(str(d / "cam.bin"))
+    tiles = R.divide_image(resx, resy)
+    tiles.astype(np.int32).tofile(str(d / "tiles.bin")); (np.arange(len(tiles), dtype=np.int32) * (3 * 16 * 64)).tofile(str(d / "offsets.bin"))
+    np.array([hb.depth, resx, resy, 0, 0, 0, 1, sw], dtype=np.int32).tofile(str(d / "meta.bin"))
+    exe = build_adapter_mock(tmp_path)
+    r = subprocess.run([exe, str(d)], capture_output=True, text=True)
+    assert r.returncode == 0 and "adapter ok" in r.stdout, r.stdout + r.stderr
+    scale = 2 if sw == 9 else 1
+    assert "host tile Render: prefetched %d x %d 1" % (resx * scale, resy * scale) in r.stdout, r.stdout
+    if sw == 8:     # the tint belongs to the tile-list renderer only: the image call stays on the device
+        assert "host image Render" not in r.stdout and "switch 8: tile stats 777 image stats" in r.stdout
+    else:
+        assert "host image Render: prefetched %d x %d 1" % (resx * scale, resy * scale) in r.stdout, r.stdout
+        assert "switch %d: tile stats 777 image stats 778 frame left 0" % sw in r.stdout, r.stdout
+
+
 def test_depth_shading_and_tile_pipeline(torch_mod):
     """f2 row: gVals[1] depth shading + ConvColor + RGB8 store, and the multi-rank tile pipeline executed rank by
     rank in one process (plan -> trace_packets -> shade_depth -> scatter); the collective itself is covered on
