@@ -194,6 +194,7 @@ def main():
     ap.add_argument("--frames-per-launch", type=int, default=0, help="trace this many frames (1..8) with one launch -- and, at N > 1, move them with one collective (DistributedRenderer frames_per_launch); 0 = enough for a launch to hold 8160 packets (one 1080p frame), at least 2, at most 8: 2 / 2 / 4 / 8 at N = 1 / 2 / 4 / 8; config 3 always 1")
     ap.add_argument("--lone-frames", type=int, default=12, help="frames (N > 1: launches through the whole route) traced one at a time after the timed region (lone_frame_ms / lone_launch_ms); 0 = skip")
     ap.add_argument("--camera-path", default="static", choices=["static", "orbit"], help="orbit = the camera turns 0.2 degrees every step (dispatch orders are then predictions from an older view, re-derived every --order-refresh frames of a slot, inside the timed region)")
+    ap.add_argument("--settle-ms", type=float, default=0.0, help="untimed frames for this many milliseconds BEFORE the W warm-up steps (the part's clocks ramp for tens of ms after an idle start: profiles/README.md)")
     ap.add_argument("--dry-run", action="store_true", help="start the ranks, rendezvous, one all-reduce over the chosen backend, print {dry_run, ranks} and exit: checks the launch path without a GPU (with --backend gloo)")
     ap.add_argument("--order-refresh", type=int, default=16, help="frames of a slot between two derivations of its dispatch order while the camera moves (DistributedRenderer order_refresh)")
     args = ap.parse_args()
@@ -286,6 +287,14 @@ def main():
     tot = rnd.reduce_stats(st) if world > 1 else st
     total_rays = int(tot.cpu().numpy()[2]) if (rank == 0 and cfg["lights"]) else primary_rays
     node_visits = int(tot.cpu().numpy()[1]) if rank == 0 else 0
+    settle_frames = 0
+    if args.settle_ms > 0:
+        t_end = time.perf_counter() + args.settle_ms * 1e-3
+        while time.perf_counter() < t_end:
+            for _ in range(8 * rnd.batch):
+                rnd.render(cam)
+            settle_frames += 8 * rnd.batch
+        # (no flush: the warm-up steps follow in the same pipeline)
     for i in range(args.warmup):
         rnd.render(cam_at(i))
     rnd.flush()
@@ -430,6 +439,7 @@ def main():
                        "bvh_build_s": round(build_s, 3), "hit_fraction": round(hit_frac, 5), "frames_in_flight": rnd.nslots * rnd.batch, "frames_per_launch": rnd.batch, "launches_in_flight": rnd.nslots,
                        "lone_launch_ms": round(lone_launch_ms, 5) if lone_launch_ms is not None else None,
                        "lone_launch_note": ("host clock of rank 0 around %d frame(s) = one launch + one collective + scatter with nothing else in flight" % rnd.batch) if lone_launch_ms is not None else None,
+                       "settle_ms": args.settle_ms, "settle_frames": settle_frames,
                        "camera_path": args.camera_path if len(path) > 1 else "static", "order_refresh": rnd.order_refresh if rnd.feedback else None,
                        "ranks": world, "backend": ("gloo (rehearsal)" if rehearsal else "nccl (RCCL)") if world > 1 else None,
                        "packet_order": "heaviest first (node visits of an earlier frame)" if rnd.feedback else "built-in region interleave",

@@ -1015,7 +1015,15 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 // A register set never has two requests in flight (scalar loads return out of order): every request into N or T follows an
 // s_waitcnt lgkmcnt(0) that covers the previous one, and the statement is left with nothing in flight.  T does not survive the C++
 // leaf code between two statements: L_entry requests it again (its line was fetched a leaf body ago).
-//   topw = the stack word (node | first << 20 | last << 26) of the top entry, kept in an SGPR: one lane read per pop as before
+//   topw = the stack word (record slot | first << 20 | last << 26) of the top entry, kept in an SGPR: one lane read per pop as before
+// The loop reads its own copy of the tree (SnailScene::dPF, built by snail_scene_create / the LBVH builder; dev::pfEncode):
+//   [slot 0: unused][slot i + 1: node i] ... [triangle records], ONE allocation, so that one base register addresses both, and
+//   a child pair (sub, sub + 1; sub is odd) shares ONE 64-B line: the near child's request brings the far child's record as well;
+//   words 6, 7 of an inner record = byte offset of the child that is visited first when sign[axis] is clear, 1 << axis: the near child
+//   is that offset ^ (sign[axis] ? 32 : 0), the far child near ^ 32 -- five scalar instructions where the reference's encoding took eight,
+//   and no shift on the far child's request; of a leaf record = 0x80000000 | byte offset of its first triangle record, count: the
+//   "near child" request of a leaf -- issued BEFORE its box test, as for any node -- fetches that triangle's line, which the leaf code
+//   would otherwise wait for from cold (a leaf's triangle loads are the longest stall of a packet's walk).
 #define SNAIL_MOV_REC(D0, D1, D2, D3, S0, S1, S2, S3)                                                                                       \
 	" s_mov_b64 " D0 ", " S0 "\n s_mov_b64 " D1 ", " S1 "\n s_mov_b64 " D2 ", " S2 "\n s_mov_b64 " D3 ", " S3 "\n"
 #define SNAIL_A_FROM_T SNAIL_MOV_REC("s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]", "s[68:69]", "s[70:71]", "s[72:73]", "s[74:75]")
@@ -1025,11 +1033,11 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 // rounds monotonically -- so first / last come out as with the whole range); a pop rebuilds EXEC from the popped range.
 #define SNAIL_PF_VISIT(X, Y, OTHERSET, SUB, AUX, PRE, SLAB, TAIL, CNTVISIT, NX, FX, NY, FY, NZ, FZ)                                          \
 				 "L_visit" X "_%=:\n" CNTVISIT                                                                                              \
-				 " s_lshr_b32 %[cur], %[sign16], " AUX "\n s_xor_b32 %[cur], %[cur], " AUX "\n s_bfe_u32 %[cur], %[cur], 0x10010\n"         \
-				 " s_add_u32 %[fl], " SUB ", 1\n s_sub_u32 %[fl], %[fl], %[cur]\n" /* far child */                                          \
-				 " s_add_u32 %[cur], " SUB ", %[cur]\n" /* near child */                                                                    \
-				 " s_max_i32 %[cur], %[cur], 0\n s_lshl_b32 %[off], %[cur], 5\n" /* a leaf's sub is negative: its "near child" is the root */ \
-				 " s_load_dwordx8 " OTHERSET ", %[base], %[off]\n"                                                                         \
+				 " s_and_b32 %[cur], " AUX ", %[sign16]\n s_cselect_b32 %[cur], 32, 0\n" /* sign[axis] of lane 0 -> 32 or 0 */               \
+				 " s_xor_b32 %[cur], " SUB ", %[cur]\n" /* near child's byte offset (a leaf: its first triangle's, maybe + 32) */             \
+				 " s_xor_b32 %[fl], %[cur], 32\n" /* far child's: the other half of the pair's 64-B line */                                  \
+				 " s_bitset0_b32 %[cur], 31\n" /* a leaf's request fetches its first triangle record's line ahead of the leaf code */        \
+				 " s_load_dwordx8 " OTHERSET ", %[base], %[cur]\n"                                                                         \
 				 PRE(NX, FX, NY, FY, NZ, FZ)                                                                                               \
 				 SLAB("0", NX, FX, NY, FY, NZ, FZ) TAIL("0", "s0") SLAB("1", NX, FX, NY, FY, NZ, FZ) TAIL("1", "s1")                       \
 				 SLAB("2", NX, FX, NY, FY, NZ, FZ) TAIL("2", "s2") SLAB("3", NX, FX, NY, FY, NZ, FZ) TAIL("3", "s3")                       \
@@ -1041,14 +1049,14 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 " s_mov_b64 exec, vcc\n"                                                                                                  \
 				 " s_cmp_lt_i32 " SUB ", 0\n s_cbranch_scc1 L_leaf" X "_%=\n"                                                               \
 				 " s_lshl_b32 %[off], %[last], 6\n s_or_b32 %[off], %[off], %[first]\n s_lshl_b32 %[off], %[off], 20\n"                    \
-				 " s_or_b32 %[topw], %[off], %[fl]\n"                                                                                      \
+				 " s_lshr_b32 %[topw], %[fl], 5\n s_or_b32 %[topw], %[topw], %[off]\n" /* stack word: record slot | first << 20 | last << 26 */ \
 				 " v_writelane_b32 %[stkN], %[topw], m0\n" /* m0 = sp throughout this statement */                                                           \
 				 " s_add_u32 m0, m0, 1\n"                                                                                            \
-				 " s_lshl_b32 %[off], %[fl], 5\n"                                                                                          \
 				 " s_waitcnt lgkmcnt(0)\n"                                                                                                 \
-				 " s_load_dwordx8 s[68:75], %[base], %[off]\n" /* the far child is the new top entry */                                    \
+				 " s_load_dwordx8 s[68:75], %[base], %[fl]\n" /* the far child is the new top entry */                                    \
 				 " s_branch L_visit" Y "_%=\n"                                                                                              \
-				 "L_leaf" X "_%=:\n s_mov_b32 %[leafSub], " SUB "\n s_mov_b32 %[leafAux], " AUX "\n s_waitcnt lgkmcnt(0)\n s_branch L_end_%=\n"
+				 "L_leaf" X "_%=:\n s_bfe_u32 %[leafSub], " SUB ", 0x190006\n s_sub_u32 %[leafSub], %[leafSub], 0x80000\n s_bitset1_b32 %[leafSub], 31\n" /* 0x80000000 | first triangle: (offset - 2^25) / 64 */ \
+				 " s_mov_b32 %[leafAux], " AUX "\n s_waitcnt lgkmcnt(0)\n s_branch L_end_%=\n"
 // set A = s[84:91] (planes NXA.., sub s90, aux s91), set B = s[76:83] (planes NXB.., sub s82, aux s83)
 #define SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)                 \
 	asm volatile(" s_mov_b32 m0, %[sp]\n"                                                                                                 \
@@ -1144,8 +1152,13 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 // the root is pushed here, and every push is popped).  SHADOW=true: any hit of a shadow packet (masked lanes -inf; the walk ends
 // when a triangle occludes the whole packet, so every visit is counted).  COH: one asm statement per sign octant, picked by a
 // wave-uniform switch at every (re-)entry, i.e. once per leaf; the leaf code exists once.
+#ifndef SNAIL_NODE_PREFETCH
+#define SNAIL_NODE_PREFETCH 1 // 0 = the loop without record prefetch for one-word stacks too (A/B measurements)
+#endif
+// the node array a PACK instantiation of the hand-written walks is given: the prefetching loop's own copy of the tree
+#define SNAIL_PACK_NODES(A) (SNAIL_NODE_PREFETCH ? (A).pf : (A).nodes)
 template <bool SHADOW, bool COH, bool PACK, bool MASK, bool BARY, bool POSDIST>
-__device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes, const uint4 *__restrict__ tris, int size, int lane,
+__device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /* PACK: the prefetching loop's copy, SnailScene::dPF */, const uint4 *__restrict__ tris, int size, int lane,
 											  const float (&org)[3][4], Quad &Q, unsigned mask4, int (&tid)[4], float (&bu)[4], float (&bv)[4], float *lds,
 											  Counters &st, const int oct) {
 	Interval iv;
@@ -1162,9 +1175,10 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes, c
 #pragma unroll
 	for(int k = 0; k < 3; k++) { iv.minIDir[k] = iv.maxIDir[k] = 0.0f; iv.minOrg[k] = iv.maxOrg[k] = org[k][0]; }
 	const int signBits = __builtin_amdgcn_readfirstlane((Q.d[0][0] < 0.0f ? 1 : 0) | (Q.d[1][0] < 0.0f ? 2 : 0) | (Q.d[2][0] < 0.0f ? 4 : 0));
-	const int sign16 = signBits << 16;
+	constexpr bool PF = PACK && SNAIL_NODE_PREFETCH;   // the record-prefetching loop over its own copy of the tree
+	const int sign16 = PF ? signBits : signBits << 16; // (PF: sign bit k against an inner record's 1 << axis)
 	const u64 nodeBase = (u64)nodes;
-	int stkN = PACK ? (int)((unsigned)(size - 1) << 26) : 0, stkF = (size - 1) << 8; // slot 0 = the root with the full quad range
+	int stkN = PACK ? (int)((unsigned)(size - 1) << 26) | (PF ? 1 : 0) : 0, stkF = (size - 1) << 8; // stack slot 0 = the root (PF: record slot 1) with the full quad range
 	int sp = 1, first = 0, last = size - 1, cnt = 0;
 	for(;;) {
 		int leafSub, leafAux, sCur, sFl, sOff, sWidth;
@@ -1180,10 +1194,7 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes, c
 			else if(POSDIST) { SNAIL_DESCEND_ASM_S(POP, PUSH, SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_POS, SNAIL_COUNT, "", "s84", "s87", "s85", "s88", "s86", "s89"); } \
 			else { SNAIL_DESCEND_ASM_S(POP, PUSH, SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, "", "s84", "s87", "s85", "s88", "s86", "s89"); } \
 		}
-#ifndef SNAIL_NODE_PREFETCH
-#define SNAIL_NODE_PREFETCH 1 // 0 = the loop without record prefetch for one-word stacks too (A/B measurements)
-#endif
-		if(PACK && SNAIL_NODE_PREFETCH) {
+		if(PF) {
 			int sTopw;
 			if(COH) {
 				if(SHADOW) { SNAIL_DESCEND_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_ANY, "", SNAIL_COUNT, oct) }
@@ -1209,27 +1220,26 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes, c
 // closest hit of a packet with per-ray origins (TraversePrimaryN<0,mask>), node loop in assembly as in walkSharedAsm; any
 // distance on entry (masked lanes -inf), `size` quads
 template <bool MASK, bool COH, bool BARY, bool PACK>
-__device__ __forceinline__ void walkPerRayAsm(const uint4 *__restrict__ nodes, const uint4 *__restrict__ tris, int size, int lane, const float (&org)[3][4],
+__device__ __forceinline__ void walkPerRayAsm(const uint4 *__restrict__ nodes /* PACK and not COH: the prefetching loop's copy */, const uint4 *__restrict__ tris, int size, int lane, const float (&org)[3][4],
 											  Quad &Q, unsigned mask4, int (&tid)[4], float (&bu)[4], float (&bv)[4], Counters &st, const int oct) {
 	const int signBits = __builtin_amdgcn_readfirstlane((Q.d[0][0] < 0.0f ? 1 : 0) | (Q.d[1][0] < 0.0f ? 2 : 0) | (Q.d[2][0] < 0.0f ? 4 : 0));
-	const int sign16 = signBits << 16;
+	constexpr bool PF = PACK && SNAIL_NODE_PREFETCH && !COH;   // (coherent packets keep the plain two-word loop over the caller's records)
+	const int sign16 = PF ? signBits : signBits << 16;
 	const u64 nodeBase = (u64)nodes;
-	int stkN = PACK ? (int)((unsigned)(size - 1) << 26) : 0, stkF = (size - 1) << 8; // slot 0 = the root with the full quad range
+	int stkN = PF ? (int)((unsigned)(size - 1) << 26) | 1 : 0, stkF = (size - 1) << 8; // stack slot 0 = the root (PF: record slot 1) with the full quad range
 	int sp = 1, first = 0, last = size - 1, cnt = 0;
 	for(;;) {
 		int leafSub, leafAux, sCur, sFl, sOff, sWidth;
 		u64 sRng, sAlive;
 		float vt[17];
-		if(PACK && SNAIL_NODE_PREFETCH && !COH) {
+		if(PF) {
 			// non-coherent packets (the heavy ones among the mirrored packets): one-word stack entries + node records fetched ahead.  The
 			// coherent form would need the prefetching loop once per sign octant, and this compiler cannot place eight (or even two)
 			// copies of it beside the per-ray leaf code ("illegal VGPR to SGPR copy": the scalar-register pressure of the 16-SGPR triangle
 			// record plus three node record sets); coherent packets keep the plain loop.
 			int sTopw;
 			SNAIL_DESCEND_PF_PLAIN(SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, "");
-		} else if(PACK && COH) { SNAIL_DESCEND_OCT_S(SNAIL_POP_1W, SNAIL_PUSH_1W, SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_COH, SNAIL_TAIL_ANY, SNAIL_COUNT, "", oct) }
-		else if(PACK) { SNAIL_DESCEND_ASM_S(SNAIL_POP_1W, SNAIL_PUSH_1W, SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, "", "s84", "s87", "s85", "s88", "s86", "s89"); }
-		else if(COH) { SNAIL_DESCEND_OCT(SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_COH, SNAIL_TAIL_ANY, SNAIL_COUNT, "", oct) }
+		} else if(COH) { SNAIL_DESCEND_OCT(SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_COH, SNAIL_TAIL_ANY, SNAIL_COUNT, "", oct) }
 		else { SNAIL_DESCEND_ASM(SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, "", "s84", "s87", "s85", "s88", "s86", "s89"); }
 		if(leafSub == 0) break;
 		leafPerRay<MASK, COH ? M_COH : M_FAST, BARY>(tris, leafAux, (int)((unsigned)leafSub & 0x7fffffffu), lane, first, last, org, Q, mask4, tid, bu, bv, st);
@@ -1326,6 +1336,7 @@ struct FrameOut {
 };
 struct PrimaryArgs {
 	const uint4 *nodes, *tris;
+	const uint4 *pf; // the record-prefetching loop's copy of the tree (SnailScene::dPF; used when `pack` is set)
 	int nFrames;
 	GenConst g[SNAIL_MAX_BATCH];
 	FrameOut out[SNAIL_MAX_BATCH];
@@ -1433,9 +1444,10 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 	} else if(DEEP) { // depth > 62: the C++ walk with its second stack register pair
 		if(mode == M_COH) walk<true, false, false, M_COH, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, oct);
 		else walk<true, false, false, M_FAST, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st);
-	} else if(A.pack) {
-		if(mode == M_COH) walkSharedAsm<false, true, true, false, false, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, oct);
-		else walkSharedAsm<false, false, true, false, false, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, 0);
+	} else if(A.pack && !DIAG) { // (the counting build walks with the plain loop: same visits, same tests -- and this compiler cannot place the
+		// record-prefetching loop's three record sets beside the extra counters: "illegal VGPR to SGPR copy")
+		if(mode == M_COH) walkSharedAsm<false, true, true, false, false, true>(SNAIL_PACK_NODES(A), A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, oct);
+		else walkSharedAsm<false, false, true, false, false, true>(SNAIL_PACK_NODES(A), A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, 0);
 	} else if(mode == M_COH) walkSharedAsm<false, true, false, false, false, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, oct);
 	else walkSharedAsm<false, false, false, false, false, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, 0);
 	// The epilogue reads its arguments (output planes, layout) through an opaque copy of the kernel-argument pointer: otherwise their loads
@@ -1543,11 +1555,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SNAIL_PRIMAR
 // Dispatch order from per-slot costs: slots in (approximately) descending cost -- a counting sort over 4096 cost classes, one
 // workgroup, no scratch.  The hardware dispatcher hands blocks to CUs in index order, so this is longest-processing-time-first
 // scheduling of the packets; ties and the order inside a class are arbitrary (results never depend on the dispatch order).
-// 256 threads = one wave per SIMD, so the workgroup fits beside frames that hold 5 of the 8 wave slots of every SIMD.  Alone it
-// takes 20 us; beside four frames in flight its waves get a sixth of their SIMDs' issue slots and it takes ~110 us (the same with
-// 1024 threads) -- on its slot's stream once every few frames, while the other streams keep the machine full.
-#define ORDER_THREADS 256
+// 512 threads = two waves per SIMD, so the workgroup fits beside frames that hold 6 of the 8 wave slots of every SIMD.  Alone it
+// takes 20 us; beside four frames in flight its waves used to get a sixth of their SIMDs' issue slots (53-110 us with 256 or 1024
+// threads, round 2): it now runs at s_setprio 3 -- above every traversal wave of its SIMDs (priority, then age) -- on its slot's
+// stream once every `order_refresh` frames of a moving camera, while the other streams keep the machine full.
+#define ORDER_THREADS 512
 __global__ __launch_bounds__(ORDER_THREADS) void k_order_from_cost(const int *__restrict__ cost, int n, int *__restrict__ order) {
+	__builtin_amdgcn_s_setprio(3);
 	constexpr int T = ORDER_THREADS, PER = 4096 / T;
 	__shared__ int bins[4096];
 	__shared__ int part[T];
@@ -1627,6 +1641,7 @@ enum { SRC_PRIMARY = 0, SRC_MIRROR = 1 };
 enum { DST_FRAME = 0, DST_MIRROR = 1, DST_COLOR = 2, DST_CONTINUE = 3 };
 struct ShadeArgs {
 	const uint4 *nodes, *tris;
+	const uint4 *pf; // the record-prefetching loop's copy of the tree (SnailScene::dPF; used when `pack` is set)
 	GenConst g;
 	int resx, resy, pw, ph, fastOK;
 	const int2 *packetXY; // explicit packet list (tile sharding): packet li = packetXY[li], intermediates and output indexed by li; or null = the frame's grid
@@ -1827,8 +1842,8 @@ __device__ __forceinline__ void lightPacket(const ShadeArgs &A, const int li, co
 			if(mode == M_COH) walk<true, false, true, M_COH, false, DEEP, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st, oct);
 			else walk<true, false, true, M_FAST, false, DEEP, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st);
 		} else if(A.pack) {
-			if(mode == M_COH) walkSharedAsm<true, true, true, false, false, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st, oct);
-			else walkSharedAsm<true, false, true, false, false, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st, 0);
+			if(mode == M_COH) walkSharedAsm<true, true, true, false, false, false>(SNAIL_PACK_NODES(A), A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st, oct);
+			else walkSharedAsm<true, false, true, false, false, false>(SNAIL_PACK_NODES(A), A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st, 0);
 		} else if(mode == M_COH) walkSharedAsm<true, true, false, false, false, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st, oct);
 		else walkSharedAsm<true, false, false, false, false, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st, 0);
 	}
@@ -2034,6 +2049,7 @@ __global__ __launch_bounds__(64) void k_final(ShadeArgs A) {
 // ---- generic packets: TraversePrimary<SHARED,MASK>(Context&) --------------------------------------
 struct RaysArgs {
 	const uint4 *nodes, *tris;
+	const uint4 *pf; // the record-prefetching loop's copy of the tree (SnailScene::dPF; used when `pack` is set)
 	int nPackets, size, fastOK;
 	int pack; // at most 2^20 node slots: one-word stack entries + record prefetch in the per-ray-origin walk
 	const float *origin, *dir, *idir;
@@ -2093,7 +2109,7 @@ __device__ __forceinline__ void raysPacket(const RaysArgs &A, const int p, float
 		if(!SHARED && !DEEP) { // per-ray origins: the hand-written node loop
 			if(A.pack) {
 				if(mode == M_COH) walkPerRayAsm<MASK, true, BARY, true>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, st, oct);
-				else walkPerRayAsm<MASK, false, BARY, true>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, st, 0);
+				else walkPerRayAsm<MASK, false, BARY, true>(SNAIL_PACK_NODES(A), A.tris, size, lane, org, Q, mask4, tid, bu, bv, st, 0);
 			} else if(mode == M_COH) walkPerRayAsm<MASK, true, BARY, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, st, oct);
 			else walkPerRayAsm<MASK, false, BARY, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, st, 0);
 		} else if(SHARED && !DEEP) { // shared origin, any distances on entry
@@ -2341,6 +2357,24 @@ __global__ __launch_bounds__(256) void k_recip_check(unsigned base, unsigned lon
 __global__ void k_nop(int *sink) { if(sink && threadIdx.x == 0 && blockIdx.x == 0x7fffffff) *sink = 1; }
 #endif // SNAIL_DEBUG_API
 
+// ---- the record-prefetching loop's copy of the node records (SNAIL_PF_VISIT): slot i + 1 <- node i, words 6 / 7 re-encoded ----
+// (one thread per node; used for trees that were built on the device -- snail_scene_create encodes on the host, same function)
+__host__ __device__ inline void pfEncode(const unsigned (&in)[8], unsigned (&out)[8], unsigned trisOff) {
+	for(int k = 0; k < 6; k++) out[k] = in[k];
+	if(in[6] & 0x80000000u) { out[6] = 0x80000000u | (trisOff + ((in[6] & 0x7fffffffu) << 6)); out[7] = in[7]; }   // leaf: first triangle's byte offset, count
+	else { out[6] = (in[6] + 1u + (in[7] >> 16)) << 5; out[7] = 1u << (in[7] & 3u); }   // inner: the child taken first when sign[axis] is clear; 1 << axis
+}
+__global__ __launch_bounds__(256) void k_pf_encode(const uint4 *__restrict__ nodes, int nNodes, unsigned trisOff, uint4 *__restrict__ pf) {
+	const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+	if(i >= nNodes) return;
+	const uint4 a = nodes[(size_t)i * 2], b = nodes[(size_t)i * 2 + 1];
+	const unsigned in[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+	unsigned out[8];
+	pfEncode(in, out, trisOff);
+	pf[(size_t)(i + 1) * 2] = make_uint4(out[0], out[1], out[2], out[3]);
+	pf[(size_t)(i + 1) * 2 + 1] = make_uint4(out[4], out[5], out[6], out[7]);
+}
+
 // ---- single-ray accounting walk: V_n, V_t per ray ----------------------------
 struct AccountArgs {
 	const uint4 *nodes, *tris;
@@ -2429,9 +2463,14 @@ struct SnailScene {
 	int device = 0;
 	TileJob *tileJob = nullptr, *frameJob = nullptr;
 	int nNodes = 0, nTris = 0, depth = 0;
-	uint4 *dNodes = nullptr, *dTris = nullptr;
+	uint4 *dNodes = nullptr, *dTris = nullptr;   // the caller's records; dTris points INTO dPF (one allocation, see below)
+	// [slot 0: unused][slot i + 1: node i, re-encoded for the record-prefetching loop (dev::pfEncode)] ... [triangle records at trisOff]
+	char *dPF = nullptr;
+	int trisOff = 0;
+	int pfOK = 0;     // the prefetching loop may walk this tree: nested, every child pair starts at an odd index, offsets fit (stackPack)
 	int fastOK = 0; // every triangle record finite and of sane magnitude (see file header)
 	int nestedOK = 1; // every child box lies inside its parent's (stackPack)
+	int pfOKButNesting = 0;
 	int lastBlocks = 0, lastThreads = 0;
 	unsigned long long *dStats = nullptr; // 4 x u64 scratch for the host-pointer entry points
 	enum { kDeferSlots = 8 };
@@ -2515,7 +2554,9 @@ bool useDeep(const SnailScene *s) {
 	return force || s->depth > 62;
 }
 
-// One-word stack entries (and with them the record-prefetching node loop) need node indices below 2^20 -- and a NESTED tree: inside
+// One-word stack entries (and with them the record-prefetching node loop over its own copy of the tree, SnailScene::dPF) need record
+// slots below 2^20, child pairs at odd indices (the reference's builders and the LBVH allocate children in pairs from index 1 on, so a
+// pair shares one 64-B line of the copy and "the other child" is offset ^ 32), byte offsets below 2^31 -- and a NESTED tree: inside
 // the prefetching loop EXEC is the set of quads that survived the parent (a quad that fails a box fails every box inside it), so a
 // child's first / last come from the survivors only, whereas the reference rescans the whole inherited range
 // (src/bounding_box.cpp:71-139).  Trees of the reference's builders and of the LBVH refit are nested by construction; a caller's
@@ -2524,11 +2565,11 @@ bool useDeep(const SnailScene *s) {
 int stackPack(const SnailScene *s) {
 	static const bool off = debugEnvInt("SNAIL_DEBUG_NO_PACK") != 0;
 	static const bool assumeNested = debugEnvInt("SNAIL_DEBUG_ASSUME_NESTED") != 0;   // (tests/nonnested_env.py: shows that the check below matters)
-	return !off && (s->nestedOK || assumeNested) && s->nNodes <= (1 << 20) ? 1 : 0;
+	return !off && (s->pfOK || (assumeNested && s->pfOKButNesting)) ? 1 : 0;
 }
 
 int checkScene(const SnailScene *s, const char *fn) {
-	if(!s || !s->dNodes || !s->dTris) { snail_set_error("%s: invalid scene handle", fn); return 1; }
+	if(!s || !s->dNodes || !s->dPF || !s->dTris) { snail_set_error("%s: invalid scene handle", fn); return 1; }
 	return 0;
 }
 
@@ -2545,7 +2586,7 @@ int launchPrimaryFrames(SnailScene *s, const FrameSet &FS, int resx, int resy, i
 	if(FS.n < 1 || FS.n > SNAIL_MAX_BATCH || (SNAIL_BLOCK_WAVES > 1 && FS.n > 1)) { snail_set_error("snail_trace_primary: 1..%d frames per launch (got %d)", SNAIL_MAX_BATCH, FS.n); return 1; }
 	dev::PrimaryArgs A;
 	memset(&A, 0, sizeof(A));
-	A.nodes = s->dNodes; A.tris = s->dTris;
+	A.nodes = s->dNodes; A.tris = s->dTris; A.pf = (const uint4 *)s->dPF;
 	A.nFrames = FS.n;
 	A.fastOK = s->fastOK;
 	for(int k = 0; k < FS.n; k++) {
@@ -2679,7 +2720,7 @@ int launchRays(SnailScene *s, bool shadow, int nPackets, int size, int sharedOri
 	if(!origin || !dir || !idir || !distance || (!shadow && !object)) { snail_set_error("null ray array"); return 1; }
 	dev::RaysArgs A;
 	memset(&A, 0, sizeof(A));
-	A.nodes = s->dNodes; A.tris = s->dTris;
+	A.nodes = s->dNodes; A.tris = s->dTris; A.pf = (const uint4 *)s->dPF;
 	A.nPackets = nPackets; A.size = size; A.fastOK = s->fastOK; A.pack = stackPack(s);
 	A.origin = origin; A.dir = dir; A.idir = idir; A.mask = mask;
 	A.distance = distance; A.object = object; A.bary = bary;
@@ -2745,11 +2786,16 @@ int snail_device_count(void) {
 	return n;
 }
 
+// byte offset of the triangle records in SnailScene::dPF: a CONSTANT (2^25 = room for 2^20 record slots), so that the prefetching loop
+// turns a leaf record's triangle offset back into an index with immediates (SNAIL_PF_VISIT, L_leaf)
+static size_t pfTrisOffset(int) { return (size_t)1 << 25; }
+
 SnailScene *snail_scene_create(const void *nodes32, int nNodes, const void *tris64, int nTris, int depth, int device) {
 	if(!nodes32 || !tris64 || nNodes <= 0 || nTris <= 0) { snail_set_error("snail_scene_create: empty scene"); return nullptr; }
 	if(depth < 0 || depth > SNAIL_MAX_DEPTH) { snail_set_error("snail_scene_create: depth %d outside 0..BVH::maxDepth = %d", depth, SNAIL_MAX_DEPTH); return nullptr; }
 	// validate topology on the host so that no kernel can index out of bounds (a GPU fault resets the node)
 	const uint32_t *nw = (const uint32_t *)nodes32;
+	int pairsOdd = 1; // every child pair starts at an odd index (children are allocated in pairs from index 1 on: src/bvh/tree.cpp:153-157)
 	for(int i = 0; i < nNodes; i++) {
 		uint32_t sub = nw[i * 8 + 6], aux = nw[i * 8 + 7];
 		if(sub & 0x80000000u) {
@@ -2758,6 +2804,7 @@ SnailScene *snail_scene_create(const void *nodes32, int nNodes, const void *tris
 		} else {
 			if((uint64_t)sub + 1 >= (uint64_t)nNodes || sub == 0) { snail_set_error("snail_scene_create: node %d has child %u of %d", i, sub, nNodes); return nullptr; }
 			if((aux & 0xffff) > 2 || (aux >> 16) > 1) { snail_set_error("snail_scene_create: node %d has axis/firstNode %u/%u", i, aux & 0xffff, aux >> 16); return nullptr; }
+			if(!(sub & 1u)) pairsOdd = 0;
 		}
 	}
 	// ... and that no walk can run away: every node is reached at most once from the root (no cycle, no shared subtree: a back-edge
@@ -2806,15 +2853,34 @@ SnailScene *snail_scene_create(const void *nodes32, int nNodes, const void *tris
 	if(!guard.ok) { snail_set_error("snail_scene_create: hipSetDevice(%d) failed", device); return nullptr; }
 	SnailScene *s = new SnailScene();
 	s->device = device; s->nNodes = nNodes; s->nTris = nTris; s->depth = realDepth; s->fastOK = fastOK; s->nestedOK = nestedOK; // the measured depth (<= declared) picks the stack form
+	// ONE allocation: [slot 0][the node records re-encoded for the record-prefetching loop][triangle records]; the caller's node
+	// records, verbatim, in a second one (every other walk reads those)
+	const size_t trisOff = pfTrisOffset(nNodes), pfBytes = trisOff + (size_t)nTris * 64;
+	const bool fits = (size_t)nNodes + 1 < ((size_t)1 << 20) && pfBytes < ((size_t)1 << 31);
+	s->pfOKButNesting = pairsOdd && fits;
+	s->pfOK = s->pfOKButNesting && nestedOK;
+	s->trisOff = (int)(fits ? trisOff : 0);
+	std::vector<uint32_t> pf;
+	if(s->pfOKButNesting) {
+		pf.assign(((size_t)nNodes + 1) * 8, 0u);
+		for(int i = 0; i < nNodes; i++) {
+			unsigned in[8], out[8];
+			for(int k = 0; k < 8; k++) in[k] = nw[(size_t)i * 8 + k];
+			dev::pfEncode(in, out, (unsigned)trisOff);
+			for(int k = 0; k < 8; k++) pf[((size_t)i + 1) * 8 + k] = out[k];
+		}
+	}
 	hipError_t e;
-	if((e = hipMalloc((void **)&s->dNodes, (size_t)nNodes * 32)) != hipSuccess || (e = hipMalloc((void **)&s->dTris, (size_t)nTris * 64)) != hipSuccess ||
+	if((e = hipMalloc((void **)&s->dNodes, (size_t)nNodes * 32)) != hipSuccess || (e = hipMalloc((void **)&s->dPF, fits ? pfBytes : (size_t)nTris * 64)) != hipSuccess ||
 	   (e = hipMalloc((void **)&s->dStats, 4 * sizeof(unsigned long long))) != hipSuccess ||
 	   (e = hipMemcpy(s->dNodes, nodes32, (size_t)nNodes * 32, hipMemcpyHostToDevice)) != hipSuccess ||
-	   (e = hipMemcpy(s->dTris, tris64, (size_t)nTris * 64, hipMemcpyHostToDevice)) != hipSuccess) {
+	   (e = hipMemcpy(s->dPF + s->trisOff, tris64, (size_t)nTris * 64, hipMemcpyHostToDevice)) != hipSuccess ||
+	   (!pf.empty() && (e = hipMemcpy(s->dPF, pf.data(), pf.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)) {
 		snail_set_error("snail_scene_create: %s", hipGetErrorString(e));
 		snail_scene_destroy(s);
 		return nullptr;
 	}
+	s->dTris = (uint4 *)(s->dPF + s->trisOff);
 	return s;
 }
 
@@ -2832,11 +2898,32 @@ SnailScene *snail_scene_create_lbvh(const float *tri_verts, int nTris, int devic
 	}
 	SnailScene *s = new SnailScene();
 	s->device = device; s->nNodes = 2 * nTris - 1; s->nTris = nTris; s->depth = depth; s->fastOK = fastOK;
-	s->dNodes = dNodes; s->dTris = dTris;
-	if(hipMalloc((void **)&s->dStats, 4 * sizeof(unsigned long long)) != hipSuccess) {
-		snail_set_error("snail_scene_create_lbvh: device allocation failed");
+	s->dNodes = dNodes;
+	// the LBVH is nested by construction (bottom-up refit: a parent's box is the exact union of its children's) and its children live in
+	// slots 1 + 2i, 2 + 2i: the record-prefetching loop's copy is encoded on the device, the triangle records move behind it
+	const size_t trisOff = pfTrisOffset(s->nNodes), pfBytes = trisOff + (size_t)nTris * 64;
+	const bool fits = (size_t)s->nNodes + 1 < ((size_t)1 << 20) && pfBytes < ((size_t)1 << 31);
+	s->trisOff = (int)(fits ? trisOff : 0);
+	s->nestedOK = 1; s->pfOKButNesting = s->pfOK = fits ? 1 : 0;
+	hipError_t e;
+	if((e = hipMalloc((void **)&s->dPF, fits ? pfBytes : (size_t)nTris * 64)) != hipSuccess ||
+	   (e = hipMemcpy(s->dPF + s->trisOff, dTris, (size_t)nTris * 64, hipMemcpyDeviceToDevice)) != hipSuccess ||
+	   (e = hipMalloc((void **)&s->dStats, 4 * sizeof(unsigned long long))) != hipSuccess) {
+		(void)hipFree(dTris);
+		snail_set_error("snail_scene_create_lbvh: %s", hipGetErrorString(e));
 		snail_scene_destroy(s);
 		return nullptr;
+	}
+	(void)hipFree(dTris);
+	s->dTris = (uint4 *)(s->dPF + s->trisOff);
+	if(fits) {
+		(void)hipMemset(s->dPF, 0, 32);
+		hipLaunchKernelGGL(dev::k_pf_encode, dim3((unsigned)((s->nNodes + 255) / 256)), dim3(256), 0, 0, s->dNodes, s->nNodes, (unsigned)trisOff, (uint4 *)s->dPF);
+		if((e = hipDeviceSynchronize()) != hipSuccess) {
+			snail_set_error("snail_scene_create_lbvh: %s", hipGetErrorString(e));
+			snail_scene_destroy(s);
+			return nullptr;
+		}
 	}
 	return s;
 }
@@ -2854,7 +2941,7 @@ void snail_scene_destroy(SnailScene *s) {
 	DeviceGuard guard(s->device);
 	freeTileJobs(s);
 	if(s->dNodes) (void)hipFree(s->dNodes);
-	if(s->dTris) (void)hipFree(s->dTris);
+	if(s->dPF) (void)hipFree(s->dPF);   // (dTris points into it)
 	if(s->dStats) (void)hipFree(s->dStats);
 	for(int k = 0; k < SnailScene::kDeferSlots; k++) if(s->dDefer[k]) (void)hipFree(s->dDefer[k]);
 	for(int k = 0; k < SnailScene::kDeferSlots; k++) if(s->shade[k].hitT) (void)hipFree(s->shade[k].hitT);
@@ -3114,7 +3201,7 @@ static int renderWhitted(const char *fn, SnailScene *s, const float cam[13], int
 	const bool refl = (flags & SNAIL_WHITTED_REFLECTIONS) != 0;
 	dev::ShadeArgs A;
 	memset(&A, 0, sizeof(A));
-	A.nodes = s->dNodes; A.tris = s->dTris;
+	A.nodes = s->dNodes; A.tris = s->dTris; A.pf = (const uint4 *)s->dPF;
 	A.g = makeGen(cam, resx, resy);
 	A.resx = resx; A.resy = resy; A.pw = (resx + 15) / 16; A.ph = (resy + 15) / 16;
 	A.fastOK = s->fastOK && originSane(cam);
@@ -3192,7 +3279,7 @@ int snail_trace_transparency_dev(SnailScene *s, const float cam[13], int resx, i
 	DeviceGuard guard(s->device);
 	dev::ShadeArgs A;
 	memset(&A, 0, sizeof(A));
-	A.nodes = s->dNodes; A.tris = s->dTris;
+	A.nodes = s->dNodes; A.tris = s->dTris; A.pf = (const uint4 *)s->dPF;
 	A.g = makeGen(cam, resx, resy);
 	A.resx = resx; A.resy = resy; A.pw = (resx + 15) / 16; A.ph = (resy + 15) / 16;
 	A.fastOK = s->fastOK && originSane(cam);
@@ -3334,7 +3421,7 @@ int snail_debug_anyorder(SnailScene *s, const float cam[13], int resx, int resy,
 	DeviceGuard guard(s->device);
 	dev::PrimaryArgs A;
 	memset(&A, 0, sizeof(A));
-	A.nodes = s->dNodes; A.tris = s->dTris;
+	A.nodes = s->dNodes; A.tris = s->dTris; A.pf = (const uint4 *)s->dPF;
 	A.nFrames = 1;
 	A.g[0] = makeGen(cam, resx, resy);
 	A.resx = resx; A.resy = resy; A.w = resx; A.h = resy;
