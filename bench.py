@@ -403,7 +403,8 @@ def main():
                 "traffic_unit": "HBM bytes per launch of %d frame(s) (rocprofv3 PMC of a one-frame launch: 2 x FETCH_SIZE + WRITE_SIZE, x frames per launch)" % rnd.batch,
                 "frames_per_launch": rnd.batch, "traffic_bytes_per_frame": traffic,
                 "hbm_peak_GBs": hbm_peak, "hbm_frac_traffic": round(traffic / step_s / 1e9 / hbm_peak, 4) if traffic else None,
-                "valu_insts_per_launch": valu * rnd.batch if valu else None, "valu_insts_per_frame": valu, "counters_source": (tr.get("source") + shared_note) if tr else "no PMC pass committed for workload key %s" % key,
+                "valu_insts_per_launch": valu * rnd.batch if valu else None, "valu_insts_per_frame": valu,
+                "lanes_live_per_valu_inst": tr.get("lanes_live_per_valu_inst") if tr else None, "kernels": tr.get("kernels") if tr else None, "counters_source": (tr.get("source") + shared_note) if tr else "no PMC pass committed for workload key %s" % key,
                 "kernel": tr.get("kernel", "dev::k_primary") if tr else "dev::k_primary", "kernel_ms": round(kern_ms, 5), "kernel_ms_note": "HIP events around one launch (%d frame(s)) on its own stream while %d launches are in flight: overlapped, not a stand-alone duration; every fraction here uses ms_per_step (per frame) and per-frame counters" % (rnd.batch, rnd.nslots),
                 "denominator_ms": round(ms_per_step, 5), "lone_frame_ms": round(lone_ms, 5) if lone_ms is not None else None,
                 "one_frame_per_launch": fpl1}

@@ -347,6 +347,68 @@ __device__ __forceinline__ TriTerms triTerms(const Tri &t, float ox, float oy, f
 	return r;
 }
 
+__device__ __forceinline__ float selLanes(float a, float b, u64 lanesOfB) {
+	float r;
+	asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(lanesOfB));
+	return r;
+}
+__device__ __forceinline__ float xbar(int byteAddr, float x) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byteAddr, __float_as_int(x))); }
+// ---- the packet-level triangle cull + shared-origin terms, FOUR LANES PER TRIANGLE -----------------------------------------------------
+// triTestInterval() and triTerms() above are ~95 VALU instructions that run with one lane per triangle -- at most 4 of 64 lanes in an
+// ordinary leaf.  Here lane 4q + c (c = 0, 1, 2) works on COMPONENT c of triangle q (leaves of at most 16 triangles): it loads
+// a[c], ba[c], ca[c], n[c] and t0 / it0, forms tv[c] = o[c] - a[c], reads the other two components of tv, ba, ca from its quad neighbours
+// through DPP (quad_perm: no LDS, no extra instruction where the read folds into the multiply), and computes component c of both cross
+// products, of the scaled terms and of every per-axis product of the interval test; the three-term sums (dot products, u / v bounds)
+// are added up in lane 4q in the reference's order ((x + y) + z).  Same operations on the same operands as the one-lane form -- the
+// same bits -- at ~50 instructions per leaf instead of ~95, and a lane keeps 4 registers of triangle data (n[c], tvec0[c], tvec1[c];
+// tmul in lane 4q) instead of 10.  Returns the lanes 4q whose triangle passes the cull (bit 4q); the survivor's terms are read by
+// crossbar from lanes 4q, 4q + 1, 4q + 2.
+#ifndef SNAIL_CULL_QUAD
+#define SNAIL_CULL_QUAD 7 // bit 0: narrow closest-hit leaves, bit 1: narrow any-hit leaves, bit 2: wide leaves; 0 = one lane per triangle everywhere (A/B measurements)
+#endif
+template <int CTRL> __device__ __forceinline__ float quadRot(float v) { // lane c of a quad <- lane (c + 1) % 3 [0xC9] or (c + 2) % 3 [0xD2]; lane 3 keeps its own
+	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+struct QuadTerms {
+	float n, t0v, t1v, tmul; // component c = lane & 3 of the triangle (lane >> 2): plane normal, tvec0, tvec1; tmul valid in lane 4q
+};
+template <int M>
+__device__ __forceinline__ u64 cullQuad(const uint4 *__restrict__ tris, int count /* <= 16, uniform */, int firstTri, int lane, const float (&org)[3][4],
+										const Interval &iv, QuadTerms &T) {
+	const int c = lane & 3;
+	const bool active = lane < 4 * count;
+	T.n = T.t0v = T.t1v = T.tmul = 0.0f;
+	bool pass = false;
+	// component c of the packet constants (lane 4q + 3 idles on component 0's)
+	const float oc = selLanes(selLanes(org[0][0], org[1][0], 0x2222222222222222ull), org[2][0], 0x4444444444444444ull);
+	const float dmn = selLanes(selLanes(iv.minDir[0], iv.minDir[1], 0x2222222222222222ull), iv.minDir[2], 0x4444444444444444ull);
+	const float dmx = selLanes(selLanes(iv.maxDir[0], iv.maxDir[1], 0x2222222222222222ull), iv.maxDir[2], 0x4444444444444444ull);
+	if(active) {
+		const float *rec = (const float *)(tris + (size_t)(firstTri + (lane >> 2)) * 4);
+		const float *rc = rec + (c == 3 ? 0 : c);
+		const float ac = rc[0], bac = rc[3], cac = rc[6], nc = rc[12];
+		const float t0 = rec[9], it0 = rec[10];
+		const float tv = oc - ac;
+		const float tv1 = quadRot<0xC9>(tv), tv2 = quadRot<0xD2>(tv);
+		const float ba1 = quadRot<0xC9>(bac), ba2 = quadRot<0xD2>(bac), ca1 = quadRot<0xC9>(cac), ca2 = quadRot<0xD2>(cac);
+		const float c1 = ba1 * tv2 - ba2 * tv1; // (ba x tv)[c]   src/triangle.cpp:13-15, :124-125
+		const float c2 = tv1 * ca2 - tv2 * ca1; // (tv x ca)[c]
+		T.n = nc; T.t0v = c1 * it0; T.t1v = c2 * it0;
+		const float p = tv * nc;
+		T.tmul = -((p + quadRot<0xC9>(p)) + quadRot<0xD2>(p)); // lane 4q: -((tv.x n.x + tv.y n.y) + tv.z n.z)
+		// Triangle::TestInterval (src/triangle.cpp:110-167), per component, sums in lane 4q
+		float m;
+		if(M == M_EXACT) m = (nc < 0.0f ? dmn : dmx) * nc;
+		else m = vmax(dmn * nc, dmx * nc);
+		const float det = (m + quadRot<0xC9>(m)) + quadRot<0xD2>(m);
+		const float c1a = dmn * c1, c1b = dmx * c1, c2a = dmn * c2, c2b = dmx * c2;
+		const float u0p = Min<M>(c1a, c1b), u1p = Max<M>(c1a, c1b), v0p = Min<M>(c2a, c2b), v1p = Max<M>(c2a, c2b);
+		const float u0 = (u0p + quadRot<0xC9>(u0p)) + quadRot<0xD2>(u0p), u1 = (u1p + quadRot<0xC9>(u1p)) + quadRot<0xD2>(u1p);
+		const float v0 = (v0p + quadRot<0xC9>(v0p)) + quadRot<0xD2>(v0p), v1 = (v1p + quadRot<0xC9>(v1p)) + quadRot<0xD2>(v1p);
+		pass = (c == 0) & ((det < 0.0f) | ((Min<M>(u1, v1) >= 0.0f) & (u0 + v0 <= det * t0)));
+	}
+	return __builtin_amdgcn_ballot_w64(pass);
+}
 // ---- leaf of a NARROW closest-hit packet range --------------------------------------------------------------------------------
 // A lane holds one SSE quad = 4 rays, so intersecting a triangle costs 4 x 23 VALU instructions whatever the width of [first, last] --
 // and at the leaves that range is narrow (atrium frame: 43 % of the leaf bodies see <= 16 quads, 70 % <= 32; stress-1M: 77 % / 94 %;
@@ -367,12 +429,6 @@ __device__ __forceinline__ TriTerms triTerms(const Tri &t, float ox, float oy, f
 #ifndef SNAIL_LEAF_COMPACT
 #define SNAIL_LEAF_COMPACT 1 // 0 = every leaf in the wide form (A/B measurements)
 #endif
-__device__ __forceinline__ float selLanes(float a, float b, u64 lanesOfB) {
-	float r;
-	asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(lanesOfB));
-	return r;
-}
-__device__ __forceinline__ float xbar(int byteAddr, float x) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byteAddr, __float_as_int(x))); }
 template <int R> struct NarrowRays {
 	float d[3][R], dist[R];
 	int tid[R];
@@ -392,15 +448,21 @@ __device__ __forceinline__ void leafSharedNarrow(const uint4 *__restrict__ tris,
 	const bool live = lane < width * LPQ;           // this lane holds rays of the range
 	st.leaves++;
 	st.fetched += (unsigned)count;
+	constexpr bool quadCull = (SNAIL_CULL_QUAD & 1) != 0;   // (the caller sends leaves of more than 16 triangles to the wide form then)
 	Tri t = {};
 	TriTerms tt = {};
-	bool pass = false;
-	if(lane < count) {
-		t = loadTriVector(tris, firstTri + lane);
-		tt = triTerms(t, org[0][0], org[1][0], org[2][0]);
-		pass = triTestInterval<M>(t, iv);
+	QuadTerms qt = {};
+	u64 keep;
+	if(quadCull) keep = cullQuad<M>(tris, count, firstTri, lane, org, iv, qt);
+	else {
+		bool pass = false;
+		if(lane < count) {
+			t = loadTriVector(tris, firstTri + lane);
+			tt = triTerms(t, org[0][0], org[1][0], org[2][0]);
+			pass = triTestInterval<M>(t, iv);
+		}
+		keep = __builtin_amdgcn_ballot_w64(pass);
 	}
-	u64 keep = __builtin_amdgcn_ballot_w64(pass);
 	if(keep == 0) return;
 	NarrowRays<R> N;
 	const int srcAddr = (first + lane / LPQ) * 4;   // lanes past the range read some quad's rays and never accept
@@ -410,12 +472,23 @@ __device__ __forceinline__ void leafSharedNarrow(const uint4 *__restrict__ tris,
 #pragma unroll
 	for(int i = 0; i < R; i++) N.tid[i] = -1;
 	do {
-		const int k = __builtin_ctzll(keep);
+		const int kb = __builtin_ctzll(keep);
 		keep &= keep - 1;
-		const float nx = xbar(k * 4, t.n[0]), ny = xbar(k * 4, t.n[1]), nz = xbar(k * 4, t.n[2]);
-		const float ax = xbar(k * 4, tt.t0v[0]), ay = xbar(k * 4, tt.t0v[1]), az = xbar(k * 4, tt.t0v[2]);
-		const float bx = xbar(k * 4, tt.t1v[0]), by = xbar(k * 4, tt.t1v[1]), bz = xbar(k * 4, tt.t1v[2]);
-		const float tmul = xbar(k * 4, tt.tmul);
+		float nx, ny, nz, ax, ay, az, bx, by, bz, tmul;
+		int k;
+		if(quadCull) {
+			k = kb >> 2;
+			nx = xbar(kb * 4, qt.n); ny = xbar(kb * 4 + 4, qt.n); nz = xbar(kb * 4 + 8, qt.n);
+			ax = xbar(kb * 4, qt.t0v); ay = xbar(kb * 4 + 4, qt.t0v); az = xbar(kb * 4 + 8, qt.t0v);
+			bx = xbar(kb * 4, qt.t1v); by = xbar(kb * 4 + 4, qt.t1v); bz = xbar(kb * 4 + 8, qt.t1v);
+			tmul = xbar(kb * 4, qt.tmul);
+		} else {
+			k = kb;
+			nx = xbar(k * 4, t.n[0]); ny = xbar(k * 4, t.n[1]); nz = xbar(k * 4, t.n[2]);
+			ax = xbar(k * 4, tt.t0v[0]); ay = xbar(k * 4, tt.t0v[1]); az = xbar(k * 4, tt.t0v[2]);
+			bx = xbar(k * 4, tt.t1v[0]); by = xbar(k * 4, tt.t1v[1]); bz = xbar(k * 4, tt.t1v[2]);
+			tmul = xbar(k * 4, tt.tmul);
+		}
 		const int idx = firstTri + k;
 		if(live)
 #pragma unroll
@@ -455,10 +528,18 @@ __device__ __forceinline__ void leafSharedNarrowShadow(const uint4 *__restrict__
 	const bool live = lane < width * LPQ;
 	st.leaves++;
 	st.fetched += (unsigned)count;
-	const bool mine = lane < count;
-	const Tri t = loadTriVector(tris, firstTri + (mine ? lane : 0));
-	const TriTerms tt = triTerms(t, org[0][0], org[1][0], org[2][0]);
-	u64 keep = __builtin_amdgcn_ballot_w64(mine & triTestInterval<M>(t, iv));
+	constexpr bool quadCull = (SNAIL_CULL_QUAD & 2) != 0;
+	Tri t = {};
+	TriTerms tt = {};
+	QuadTerms qt = {};
+	u64 keep;
+	if(quadCull) keep = cullQuad<M>(tris, count, firstTri, lane, org, iv, qt);
+	else {
+		const bool mine = lane < count;
+		t = loadTriVector(tris, firstTri + (mine ? lane : 0));
+		tt = triTerms(t, org[0][0], org[1][0], org[2][0]);
+		keep = __builtin_amdgcn_ballot_w64(mine & triTestInterval<M>(t, iv));
+	}
 	if(keep == 0) return;
 	float nd[3][R], ndist[R];
 	const int srcAddr = (first + lane / LPQ) * 4;
@@ -466,12 +547,21 @@ __device__ __forceinline__ void leafSharedNarrowShadow(const uint4 *__restrict__
 	for(int c = 0; c < 3; c++) narrowGather<R>(Q.d[c], srcAddr, nd[c]);
 	narrowGather<R>(Q.dist, srcAddr, ndist);
 	do {
-		const int k = __builtin_ctzll(keep);
+		const int kb = __builtin_ctzll(keep);
 		keep &= keep - 1;
-		const float nx = xbar(k * 4, t.n[0]), ny = xbar(k * 4, t.n[1]), nz = xbar(k * 4, t.n[2]);
-		const float ax = xbar(k * 4, tt.t0v[0]), ay = xbar(k * 4, tt.t0v[1]), az = xbar(k * 4, tt.t0v[2]);
-		const float bx = xbar(k * 4, tt.t1v[0]), by = xbar(k * 4, tt.t1v[1]), bz = xbar(k * 4, tt.t1v[2]);
-		const float tmul = xbar(k * 4, tt.tmul);
+		float nx, ny, nz, ax, ay, az, bx, by, bz, tmul;
+		if(quadCull) {
+			nx = xbar(kb * 4, qt.n); ny = xbar(kb * 4 + 4, qt.n); nz = xbar(kb * 4 + 8, qt.n);
+			ax = xbar(kb * 4, qt.t0v); ay = xbar(kb * 4 + 4, qt.t0v); az = xbar(kb * 4 + 8, qt.t0v);
+			bx = xbar(kb * 4, qt.t1v); by = xbar(kb * 4 + 4, qt.t1v); bz = xbar(kb * 4 + 8, qt.t1v);
+			tmul = xbar(kb * 4, qt.tmul);
+		} else {
+			const int k = kb;
+			nx = xbar(k * 4, t.n[0]); ny = xbar(k * 4, t.n[1]); nz = xbar(k * 4, t.n[2]);
+			ax = xbar(k * 4, tt.t0v[0]); ay = xbar(k * 4, tt.t0v[1]); az = xbar(k * 4, tt.t0v[2]);
+			bx = xbar(k * 4, tt.t1v[0]); by = xbar(k * 4, tt.t1v[1]); bz = xbar(k * 4, tt.t1v[2]);
+			tmul = xbar(k * 4, tt.tmul);
+		}
 #pragma unroll
 		for(int i = 0; i < R; i++) { // src/triangle.cpp:91-98
 			const float det = nd[0][i] * nx + nd[1][i] * ny + nd[2][i] * nz;
@@ -509,7 +599,7 @@ __device__ __forceinline__ bool leafShared(const uint4 *__restrict__ tris, int c
 		// on them would drag every counter into VGPRs)
 		const int widthU = __builtin_amdgcn_readfirstlane(width);
 		const int countU = __builtin_amdgcn_readfirstlane(count);
-		if(widthU <= 32 && countU <= 64) {
+		if(widthU <= 32 && countU <= ((SNAIL_CULL_QUAD & 1) ? 16 : 64)) {
 			const int firstU = __builtin_amdgcn_readfirstlane(first);
 			if(widthU <= 16) leafSharedNarrow<1, M>(tris, countU, firstTri, lane, firstU, firstU + widthU - 1, org, Q, tid, iv, st);
 			else leafSharedNarrow<2, M>(tris, countU, firstTri, lane, firstU, firstU + widthU - 1, org, Q, tid, iv, st);
@@ -519,7 +609,7 @@ __device__ __forceinline__ bool leafShared(const uint4 *__restrict__ tris, int c
 	if(SNAIL_LEAF_COMPACT_SHADOW && SHADOW && !MASK && !BARY) {
 		const int widthU = __builtin_amdgcn_readfirstlane(width);
 		const int countU = __builtin_amdgcn_readfirstlane(count);
-		if(widthU <= 16 && widthU < size && countU <= 64) {   // (one ray per lane only: the two-ray form takes these kernels past 80 VGPRs)
+		if(widthU <= 16 && widthU < size && countU <= ((SNAIL_CULL_QUAD & 2) ? 16 : 64)) {   // (one ray per lane only: the two-ray form takes these kernels past 80 VGPRs)
 			const int firstU = __builtin_amdgcn_readfirstlane(first);
 			leafSharedNarrowShadow<1, M>(tris, countU, firstTri, lane, firstU, firstU + widthU - 1, org, Q, iv, st);
 			return false;
@@ -527,15 +617,72 @@ __device__ __forceinline__ bool leafShared(const uint4 *__restrict__ tris, int c
 	}
 	const u64 curRange = rangeMask(first, last);
 	st.leaves++;
+	constexpr bool LANE_MASK = SNAIL_LEAF_MASK && !SHADOW;
+	// one surviving triangle against the packet's quads (src/triangle.cpp:44-60 / :91-98); returns true when a shadow packet is fully occluded
+	auto collide = [&](const float nx, const float ny, const float nz, const float ax, const float ay, const float az, const float bx, const float by, const float bz,
+					   const float tmul, const int idx) -> bool {
+		bool all4 = true;
+		if(!LANE_MASK || inRange)
+#pragma unroll
+		for(int l = 0; l < 4; l++) {
+			const float det = Q.d[0][l] * nx + Q.d[1][l] * ny + Q.d[2][l] * nz;
+			const float v = Q.d[0][l] * ax + Q.d[1][l] * ay + Q.d[2][l] * az;
+			const float u = Q.d[0][l] * bx + Q.d[1][l] * by + Q.d[2][l] * bz;
+			if(SHADOW) { // src/triangle.cpp:91-98
+				bool test = (Min<M>(u, v) >= 0.0f) & (u + v <= det);
+				test = test & (tmul > 0.0f) & (tmul < Q.dist[l] * det);
+				all4 = all4 & test;
+				if(inRange && test) Q.dist[l] = -inf;
+			} else { // src/triangle.cpp:44-60
+				const float duv = det - u - v;
+				const float uvmin = Min3<M>(u, v, duv), uvmax = Max3<M>(u, v, duv);
+				bool test = ((uvmax <= 0.0f) | (uvmin >= 0.0f)) & inRange;
+				if(MASK) test = test & (((mask4 >> l) & 1u) != 0);
+				if(test) {
+					const float idet = recipExact(det);
+					const float dd = idet * tmul;
+					if(dd < Q.dist[l] && dd > 0.0f) {
+						Q.dist[l] = dd; tid[l] = idx;
+						if(BARY) { bu[l] = u * idet; bv[l] = v * idet; }
+					}
+				}
+			}
+		}
+		if(SHADOW) {
+			const bool full = width == size && (__builtin_amdgcn_ballot_w64(all4) & curRange) == curRange;
+			if(full) { st.skips++; return true; }
+		}
+		st.intersects += width;
+		return false;
+	};
+	if(SNAIL_CULL_QUAD & 4) {
+		// cull and shared-origin terms with four lanes per triangle (cullQuad), 16 triangles at a time (an ordinary leaf holds <= 4);
+		// survivors broadcast from lanes 4k .. 4k + 2, in triangle order
+		const int countU = __builtin_amdgcn_readfirstlane(count);
+		st.fetched += (unsigned)countU;
+		for(int base = 0; base < countU; base += 16) {
+			QuadTerms qt;
+			u64 keep = cullQuad<M>(tris, countU - base < 16 ? countU - base : 16, firstTri + base, lane, org, iv, qt);
+			while(keep) {
+				const int kb = __builtin_ctzll(keep);
+				keep &= keep - 1;
+				const float nx = xbar(kb * 4, qt.n), ny = xbar(kb * 4 + 4, qt.n), nz = xbar(kb * 4 + 8, qt.n);
+				const float ax = xbar(kb * 4, qt.t0v), ay = xbar(kb * 4 + 4, qt.t0v), az = xbar(kb * 4 + 8, qt.t0v);
+				const float bx = xbar(kb * 4, qt.t1v), by = xbar(kb * 4 + 4, qt.t1v), bz = xbar(kb * 4 + 8, qt.t1v);
+				const float tmul = xbar(kb * 4, qt.tmul);
+				if(collide(nx, ny, nz, ax, ay, az, bx, by, bz, tmul, firstTri + base + (kb >> 2))) return true;
+			}
+		}
+		return false;
+	}
 	for(int base = 0; base < count; base += 64) {
 		const int chunk = count - base < 64 ? count - base : 64;
 		st.fetched += (unsigned)chunk;
 		const bool mine = lane < chunk;
-		// Closest-hit packets: only the lanes that own a triangle (typically <= 4 of 64) fetch it and evaluate the cull and the shared-origin
-		// terms, and only the quads of the range [first, last] intersect a survivor: the other lanes' results were never read, now they are
-		// not computed either (EXEC off: the instruction count is the same, the switched lanes are not -- this part is power-limited,
-		// profiles/README.md).  Any-hit packets keep every lane on: their test is three compares shorter and the masks cost more than they save.
-		constexpr bool LANE_MASK = SNAIL_LEAF_MASK && !SHADOW;
+		// Leaves of more than 16 triangles: one lane per triangle.  Closest-hit packets: only the lanes that own a triangle fetch it and
+		// evaluate the cull and the shared-origin terms, and only the quads of the range [first, last] intersect a survivor (EXEC off: the
+		// instruction count is the same, the switched lanes are not -- this part is power-limited, profiles/README.md).  Any-hit packets
+		// keep every lane on: their test is three compares shorter and the masks cost more than they save.
 		Tri t = {};
 		TriTerms tt = {};
 		bool pass = false;
@@ -569,39 +716,7 @@ __device__ __forceinline__ bool leafShared(const uint4 *__restrict__ tris, int c
 			const float bx = BCAST(tt.t1v[0]), by = BCAST(tt.t1v[1]), bz = BCAST(tt.t1v[2]);
 			const float tmul = BCAST(tt.tmul);
 #undef BCAST
-			const int idx = firstTri + base + k;
-			bool all4 = true;
-			if(!LANE_MASK || inRange)
-#pragma unroll
-			for(int l = 0; l < 4; l++) {
-				const float det = Q.d[0][l] * nx + Q.d[1][l] * ny + Q.d[2][l] * nz;
-				const float v = Q.d[0][l] * ax + Q.d[1][l] * ay + Q.d[2][l] * az;
-				const float u = Q.d[0][l] * bx + Q.d[1][l] * by + Q.d[2][l] * bz;
-				if(SHADOW) { // src/triangle.cpp:91-98
-					bool test = (Min<M>(u, v) >= 0.0f) & (u + v <= det);
-					test = test & (tmul > 0.0f) & (tmul < Q.dist[l] * det);
-					all4 = all4 & test;
-					if(inRange && test) Q.dist[l] = -inf;
-				} else { // src/triangle.cpp:44-60
-					const float duv = det - u - v;
-					const float uvmin = Min3<M>(u, v, duv), uvmax = Max3<M>(u, v, duv);
-					bool test = ((uvmax <= 0.0f) | (uvmin >= 0.0f)) & inRange;
-					if(MASK) test = test & (((mask4 >> l) & 1u) != 0);
-					if(test) {
-						const float idet = recipExact(det);
-						const float dd = idet * tmul;
-						if(dd < Q.dist[l] && dd > 0.0f) {
-							Q.dist[l] = dd; tid[l] = idx;
-							if(BARY) { bu[l] = u * idet; bv[l] = v * idet; }
-						}
-					}
-				}
-			}
-			if(SHADOW) {
-				const bool full = width == size && (__builtin_amdgcn_ballot_w64(all4) & curRange) == curRange;
-				if(full) { st.skips++; return true; }
-			}
-			st.intersects += width;
+			if(collide(nx, ny, nz, ax, ay, az, bx, by, bz, tmul, firstTri + base + k)) return true;
 		}
 	}
 	return false;
@@ -1507,7 +1622,7 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 }
 
 #ifndef SNAIL_PRIMARY_WAVES
-#define SNAIL_PRIMARY_WAVES 5 // occupancy target of the primary kernel (6 measured equal, 4 slower: profiles/README.md)
+#define SNAIL_PRIMARY_WAVES 6 // occupancy target of the primary kernel (76 VGPRs by itself; 7 = 72 VGPRs measured separately: profiles/README.md)
 #endif
 // SNAIL_BLOCK_WAVES packets per workgroup (one per wave; waves end independently, nothing of the block is shared): the XCD's
 // region turn is kept -- wave w of hardware block B takes entry (B >> 3) * W + w of XCD (B & 7)'s list.
@@ -2129,8 +2244,11 @@ __device__ __forceinline__ void raysPacket(const RaysArgs &A, const int p, float
 		}
 	}
 }
+#ifndef SNAIL_RAYS_WAVES
+#define SNAIL_RAYS_WAVES 6 // occupancy target of the generic-packet kernels (the per-ray-origin walk compiles to 85 VGPRs = 5 waves by itself)
+#endif
 template <bool SHARED, bool MASK, bool DEEP, bool BARY>
-__global__ __launch_bounds__(64) void k_rays(RaysArgs A) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SNAIL_RAYS_WAVES))) void k_rays(RaysArgs A) {
 	__shared__ float lds[LDS_FLOATS_PER_WAVE];
 	raysPacket<SHARED, MASK, DEEP, BARY, false>(A, interleave16((int)blockIdx.x), lds);
 }

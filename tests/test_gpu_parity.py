@@ -424,6 +424,38 @@ def test_walk_variants_selected_by_scene_size(torch_mod, env):
     assert d["primary"] and d["whitted_refl"] and d["rays"] and d["shadow"], d
 
 
+@pytest.mark.parametrize("max_leaf", [12, 16, 40, 70])
+def test_leaves_of_many_triangles(torch_mod, max_leaf):
+    """Caller trees whose leaves hold up to 12 / 16 / 40 / 70 triangles (the builder's tree with small subtrees collapsed): the packet-level
+    triangle cull runs with four lanes per triangle, 16 triangles at a time -- every quad of lanes is exercised, leaves of more than 16
+    take several rounds, and the narrow leaf forms hand them to the wide one.  Primary frame, light pipeline with the mirrored bounce
+    (any-hit leaves, per-ray-origin leaves), TreeStats: bit-identical to the oracle's walk of the same tree."""
+    from snail_amd.scene import Scene
+    name, resx, resy = "atrium:0.05", 328, 200
+    tv, hb, _ = util.scene_pair(name)
+    hb2 = util.collapsed_tree(hb, max_leaf)
+    osc = O.OracleScene.from_arrays(hb2.tris, hb2.nodes, hb2.depth, hb2.perm)
+    cam = util.camera_for(name, tv)
+    sc = Scene(hb2, 0)
+    assert sc.flags() == (True, True)
+    stats = sc.new_stats()
+    frame = sc.trace_primary(cam, resx, resy, stats=stats)
+    torch_mod.cuda.synchronize()
+    ref = osc.render_primary(cam.as_array13(), resx, resy, mode=O.MODE_IEEE)
+    compare_frames(frame, ref, "collapsed tree (leaves <= %d)" % max_leaf)
+    assert np.array_equal(stats.cpu().numpy().astype(np.uint64), ref[4]), (stats.cpu().numpy(), ref[4])
+    bmin, bmax = hb.bbox()
+    c, e = (bmin + bmax) * 0.5, (bmax - bmin)
+    lights = np.array([[c[0], c[1] + 0.35 * e[1], c[2], 1.0, 0.9, 0.8, 2.0 * float(e.max())]], dtype=np.float32)
+    wst = sc.new_stats()
+    img = sc.render_whitted(cam, resx, resy, lights, stats=wst, reflections=True)
+    torch_mod.cuda.synchronize()
+    oimg, ost = osc.render_whitted(cam.as_array13(), resx, resy, lights, reflections=True)
+    assert img.cpu().numpy().tobytes() == oimg.tobytes()
+    assert np.array_equal(wst.cpu().numpy().astype(np.uint64), ost), (wst.cpu().numpy(), ost)
+    sc.close()
+
+
 def test_non_nested_caller_tree(torch_mod):
     """The C-ABI takes caller trees verbatim; nothing in the reference's walk needs a child box to lie inside its parent's (every box test
     rescans the whole inherited quad range, src/bounding_box.cpp:71-139), while the record-prefetching node loop keeps only the parent's

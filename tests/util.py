@@ -174,3 +174,40 @@ def non_nested_tree(hb, levels=(2, 9), shrink=0.35, every=2):
                 changed += 1
     assert changed > 8
     return HostBVH(hb.tris, nodes, hb.depth, hb.perm)
+
+
+def collapsed_tree(hb, max_leaf):
+    """The product builder's tree with every subtree of at most `max_leaf` triangles collapsed into ONE leaf (triangles of a subtree are
+    contiguous in the reference's layout), re-laid out breadth first so that children stay adjacent pairs starting at odd indices.
+    Leaves of 5 .. max_leaf triangles: what the reference's builder produces only at BVH::maxDepth or where the SAH refuses to split."""
+    from snail_amd import HostBVH
+    nodes = hb.nodes
+    sub = nodes["sub"].astype(np.int64)
+    leaf = (sub & 0x80000000) != 0
+    first = np.zeros(len(nodes), dtype=np.int64); cnt = np.zeros(len(nodes), dtype=np.int64)
+    order = []
+    stack = [0]
+    while stack:                      # post-order by explicit stack
+        i = stack.pop(); order.append(i)
+        if not leaf[i]: stack += [int(sub[i]), int(sub[i]) + 1]
+    for i in reversed(order):
+        if leaf[i]: first[i], cnt[i] = int(sub[i] & 0x7fffffff), int(nodes["aux"][i])
+        else:
+            a, b = int(sub[i]), int(sub[i]) + 1
+            assert first[a] + cnt[a] == first[b]
+            first[i], cnt[i] = first[a], cnt[a] + cnt[b]
+    out = [nodes[0].copy()]; queue = [(0, 0)]; depth = 0; level = {0: 0}
+    while queue:
+        i, slot = queue.pop(0)
+        if leaf[i] or cnt[i] <= max_leaf:
+            out[slot]["sub"] = np.uint32(0x80000000 | int(first[i])); out[slot]["aux"] = int(cnt[i])
+            depth = max(depth, level[slot])
+            continue
+        a = int(sub[i]); k = len(out)
+        out.append(nodes[a].copy()); out.append(nodes[a + 1].copy())
+        out[slot]["sub"] = k
+        level[k] = level[k + 1] = level[slot] + 1
+        queue += [(a, k), (a + 1, k + 1)]
+    new = np.array(out, dtype=nodes.dtype)
+    assert int(new["aux"][(new["sub"] & 0x80000000) != 0].max()) > 4
+    return HostBVH(hb.tris, new, depth, hb.perm)
