@@ -198,6 +198,30 @@ template <bool MAX> __device__ __forceinline__ float waveReduce(float v) {
 }
 __device__ __forceinline__ float waveMin(float v) { return waveReduce<false>(v); }
 __device__ __forceinline__ float waveMax(float v) { return waveReduce<true>(v); }
+// the six reductions of a packet's direction interval (min and max of three components) at once: the same six DPP steps, written as ONE
+// instruction each -- v_min_f32_dpp d, d(shifted), d: a lane without a source keeps its value, which is what the identity operand of the
+// two-instruction form achieves -- and interleaved over the six registers, so that no step waits for the DPP read-after-write hazard
+// (the compiler's form: mov identity, nop, mov_dpp, min = 4 instructions per step and register; 36 instead of 144 per packet)
+#ifndef SNAIL_REDUCE6_ASM
+#define SNAIL_REDUCE6_ASM 1
+#endif
+__device__ __forceinline__ void waveReduce6(float (&mn)[3], float (&mx)[3]) {
+#if SNAIL_REDUCE6_ASM
+#define SNAIL_R6_STEP(CTRL)                                                                                                                 \
+	"v_min_f32_dpp %0, %0, %0 " CTRL "\n v_min_f32_dpp %1, %1, %1 " CTRL "\n v_min_f32_dpp %2, %2, %2 " CTRL "\n"                           \
+	"v_max_f32_dpp %3, %3, %3 " CTRL "\n v_max_f32_dpp %4, %4, %4 " CTRL "\n v_max_f32_dpp %5, %5, %5 " CTRL "\n"
+	asm("s_nop 1\n" SNAIL_R6_STEP("row_shr:1 row_mask:0xf bank_mask:0xf") SNAIL_R6_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+		SNAIL_R6_STEP("row_shr:4 row_mask:0xf bank_mask:0xf") SNAIL_R6_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+		SNAIL_R6_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf") SNAIL_R6_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+		: "+v"(mn[0]), "+v"(mn[1]), "+v"(mn[2]), "+v"(mx[0]), "+v"(mx[1]), "+v"(mx[2]));
+#undef SNAIL_R6_STEP
+#pragma unroll
+	for(int c = 0; c < 3; c++) { mn[c] = readlanef(mn[c], 63); mx[c] = readlanef(mx[c], 63); }
+#else
+#pragma unroll
+	for(int c = 0; c < 3; c++) { mn[c] = waveMin(mn[c]); mx[c] = waveMax(mx[c]); }
+#endif
+}
 
 __device__ __forceinline__ u64 rangeMask(int first, int last) { return ((2ull << last) - 1ull) & ~((1ull << first) - 1ull); }
 
@@ -226,14 +250,17 @@ __device__ void computeMinMax(const float (&v)[3][4], unsigned act4, int size, i
 	const float inf = __builtin_inff();
 	if(!EXACT) {
 		u64 anyAct = __ballot(act4 != 0);
+		float mn[3], mx[3];
+#pragma unroll
 		for(int c = 0; c < 3; c++) {
-			float mn = inf, mx = -inf;
+			mn[c] = inf; mx[c] = -inf;
 #pragma unroll
 			for(int l = 0; l < 4; l++)
-				if(act4 & (1u << l)) { mn = vmin(mn, v[c][l]); mx = vmax(mx, v[c][l]); }
-			outMin[c] = anyAct ? waveMin(mn) : 0.0f;
-			outMax[c] = anyAct ? waveMax(mx) : 0.0f;
+				if(act4 & (1u << l)) { mn[c] = vmin(mn[c], v[c][l]); mx[c] = vmax(mx[c], v[c][l]); }
 		}
+		waveReduce6(mn, mx);
+#pragma unroll
+		for(int c = 0; c < 3; c++) { outMin[c] = anyAct ? mn[c] : 0.0f; outMax[c] = anyAct ? mx[c] : 0.0f; }
 		return;
 	}
 	// EXACT: stage the packet in LDS, lanes 0..11 fold (component c = lane>>2, slot l = lane&3)
@@ -609,9 +636,13 @@ __device__ __forceinline__ bool leafShared(const uint4 *__restrict__ tris, int c
 	if(SNAIL_LEAF_COMPACT_SHADOW && SHADOW && !MASK && !BARY) {
 		const int widthU = __builtin_amdgcn_readfirstlane(width);
 		const int countU = __builtin_amdgcn_readfirstlane(count);
-		if(widthU <= 16 && widthU < size && countU <= ((SNAIL_CULL_QUAD & 2) ? 16 : 64)) {   // (one ray per lane only: the two-ray form takes these kernels past 80 VGPRs)
+#ifndef SNAIL_SHADOW_NARROW2
+#define SNAIL_SHADOW_NARROW2 1 // ranges of 17..32 quads with two rays per lane (fits since the four-lane cull: 76 VGPRs)
+#endif
+		if(widthU <= (SNAIL_SHADOW_NARROW2 ? 32 : 16) && widthU < size && countU <= ((SNAIL_CULL_QUAD & 2) ? 16 : 64)) {
 			const int firstU = __builtin_amdgcn_readfirstlane(first);
-			leafSharedNarrowShadow<1, M>(tris, countU, firstTri, lane, firstU, firstU + widthU - 1, org, Q, iv, st);
+			if(widthU <= 16) leafSharedNarrowShadow<1, M>(tris, countU, firstTri, lane, firstU, firstU + widthU - 1, org, Q, iv, st);
+			else leafSharedNarrowShadow<2, M>(tris, countU, firstTri, lane, firstU, firstU + widthU - 1, org, Q, iv, st);
 			return false;
 		}
 	}
