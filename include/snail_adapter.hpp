@@ -93,18 +93,29 @@ public:
 	enum { maxDepth = RefBVH::maxDepth };
 
 	HipBVH() = default;
-	~HipBVH() { if(scene) snail_scene_destroy(scene); }
+	~HipBVH() { Release(); }
 	HipBVH(const HipBVH &) = delete;
 	HipBVH &operator=(const HipBVH &) = delete;
 
 	// Call after RefBVH::Construct (the SAH build stays on the host, src/bvh/tree.cpp:293-328).
-	void Upload(const RefBVH &bvh, int device = 0) {
+	void Upload(const RefBVH &bvh, int device = 0) { Upload(bvh, std::vector<int>(1, device)); }
+	// One copy of the tree per listed device (the reference's server ships the same arrays to every render node, src/server.cpp:144-164):
+	// the tile-list renderer then deals a frame's tiles over all of them (snail::RenderTiles -> snail_render_tiles_multi); every other
+	// path (prefetched frame, immediate and batched packets, image renderer) runs on the first device.
+	void Upload(const RefBVH &bvh, const std::vector<int> &devices) {
+		if(devices.empty()) { std::fprintf(stderr, "FATAL: HipBVH::Upload: no device\n"); std::abort(); }
 		ref = &bvh;
-		if(scene) snail_scene_destroy(scene);
+		Release();
 		static_assert(sizeof(bvh.nodes[0]) == 32 && sizeof(bvh.tris[0]) == 64, "record sizes are part of the ABI");
-		scene = snail_scene_create(bvh.nodes.data(), (int)bvh.nodes.size(), bvh.tris.data(), (int)bvh.tris.size(), bvh.depth, device);
-		if(!scene) { std::fprintf(stderr, "FATAL: snail_scene_create: %s\n", snail_last_error()); std::abort(); }
+		for(int device : devices) {
+			SnailScene *h = snail_scene_create(bvh.nodes.data(), (int)bvh.nodes.size(), bvh.tris.data(), (int)bvh.tris.size(), bvh.depth, device);
+			if(!h) { std::fprintf(stderr, "FATAL: snail_scene_create(device %d): %s\n", device, snail_last_error()); std::abort(); }
+			handles.push_back(h);
+		}
+		scene = handles[0];
 	}
+	int DeviceCount() const { return (int)handles.size(); }
+	SnailScene *const *Handles() const { return handles.data(); }
 
 	// ---- frame prefetch ----
 	// (const over mutable state: the prefetched frame is a cache of what TraversePrimary would compute, and the reference's renderers
@@ -162,8 +173,13 @@ public:
 	const FrameHits &Frame() const { return frame; }
 
 private:
+	void Release() {
+		for(SnailScene *h : handles) snail_scene_destroy(h);
+		handles.clear(); scene = nullptr;
+	}
 	const RefBVH *ref = nullptr;
-	SnailScene *scene = nullptr;
+	SnailScene *scene = nullptr;          // = handles[0]
+	std::vector<SnailScene *> handles;    // one per device
 	mutable FrameHits frame;
 	mutable bool haveFrame = false;
 	mutable std::atomic<bool> statsPending{false};
@@ -253,19 +269,17 @@ private:
 // ---- the tile API of src/render.h:16-27 on the device pipeline -----------------------------------------------------------------
 // What of Scene<AccStruct> / the global switches the device pipeline honours: scene.lights (pos, color, radius: src/light.h:5-16),
 // scene.ambientLight, the default material's colour (Scene::Scene sets (1,1,1), src/scene.cpp:6-10; SimpleMaterial::color is private,
-// hence a parameter), gVals[1] (depth shading) and gVals[7] (one mirrored bounce).  Textured materials / full shading data (gVals[6])
+// hence a parameter), gVals[1] (depth shading), gVals[7] (one mirrored bounce) and gVals[9] (4x antialiasing, src/render.cpp:60-62, :71-110).  Textured materials / full shading data (gVals[6])
 // stay with the host path (HipBVH under the reference's own Render).
 // The reference's renderer reads more global switches than that (src/rtbase.cpp:16, toggled by F-keys, broadcast to the render nodes
 // every frame: src/server.cpp:372-376).  Those the device pipeline does NOT implement -- a call with one of them set must not come back
 // as a plain frame with status 0: the Render(...) overloads below hand such a call to the reference's own renderer over the
 // prefetched HipBVH path (the reference's RenderTask::Work then does its 4x antialiasing, full shading, tints ... itself, and its
 // TraversePrimary calls copy pre-traced packets), or abort with this message when SNAIL_ADAPTER_NO_HOST_RENDERER is defined.
-//   gVals[9]  4x antialiasing: four sub-packets per packet at twice the resolution + 2x2 box filter   src/render.cpp:60,71-110
 //   gVals[6]  full shading (materials, textures, transparency selection) when the scene carries shading data   src/scene_trace.cpp:145
 //   gVals[5]  TreeStats visualisation   src/scene_trace.cpp:513-517
 //   gVals[8]  per-rank tint of the render nodes' tiles (colorizeNodes: the tile-list Render only)   src/render.cpp:118-132
 inline const char *UnsupportedSwitch(const int *gv, bool hasShadingData, bool tileList) {
-	if(gv[9]) return "gVals[9] (4x antialiasing, src/render.cpp:60,71-110)";
 	if(gv[6] && hasShadingData) return "gVals[6] (full shading: materials / textures, src/scene_trace.cpp:145)";
 	if(gv[5]) return "gVals[5] (TreeStats visualisation, src/scene_trace.cpp:513-517)";
 	if(gv[8] && tileList) return "gVals[8] (per-rank tint of the tiles, src/render.cpp:118-132)";
@@ -275,6 +289,7 @@ inline const char *UnsupportedSwitch(const int *gv, bool hasShadingData, bool ti
 struct RenderMode {
 	bool depthShading = false;  // gVals[1]
 	bool reflections = false;   // gVals[7]
+	bool antialias = false;     // gVals[9]
 	float color[3] = {1.0f, 1.0f, 1.0f};
 };
 
@@ -308,8 +323,13 @@ inline StatsT RenderTiles(const SceneT &scene, const CameraT &camera, unsigned r
 	std::vector<int64_t> off(offsets.begin(), offsets.end());
 	const float amb[3] = {scene.ambientLight.x, scene.ambientLight.y, scene.ambientLight.z};
 	uint64_t st[4] = {0, 0, 0, 0};
-	SNAIL_CHECK(snail_render_tiles(scene.geometry.Handle(), c, (int)resx, (int)resy, coords.data(), off.data(), (int)(coords.size() / 4), l.data(), (int)(l.size() / 7), amb,
-								   mode.color, (mode.depthShading ? SNAIL_RENDER_DEPTH : 0) | (mode.reflections ? SNAIL_RENDER_REFLECTIONS : 0), data, st));
+	const int flags = (mode.depthShading ? SNAIL_RENDER_DEPTH : 0) | (mode.reflections ? SNAIL_RENDER_REFLECTIONS : 0) | (mode.antialias ? SNAIL_RENDER_AA4 : 0);
+	if(scene.geometry.DeviceCount() > 1)   // the tiles dealt over every device the tree was uploaded to
+		SNAIL_CHECK(snail_render_tiles_multi(scene.geometry.Handles(), scene.geometry.DeviceCount(), c, (int)resx, (int)resy, coords.data(), off.data(), (int)(coords.size() / 4),
+											 l.data(), (int)(l.size() / 7), amb, mode.color, flags, data, st));
+	else
+		SNAIL_CHECK(snail_render_tiles(scene.geometry.Handle(), c, (int)resx, (int)resy, coords.data(), off.data(), (int)(coords.size() / 4), l.data(), (int)(l.size() / 7), amb,
+									   mode.color, flags, data, st));
 	return detail::toStats<StatsT>(st);
 }
 
@@ -322,7 +342,7 @@ inline StatsT RenderImage(const SceneT &scene, const CameraT &camera, ImageT &im
 	const float amb[3] = {scene.ambientLight.x, scene.ambientLight.y, scene.ambientLight.z};
 	uint64_t st[4] = {0, 0, 0, 0};
 	SNAIL_CHECK(snail_render_image(scene.geometry.Handle(), c, (int)image.Width(), (int)image.Height(), l.data(), (int)(l.size() / 7), amb, mode.color,
-								   (mode.depthShading ? SNAIL_RENDER_DEPTH : 0) | (mode.reflections ? SNAIL_RENDER_REFLECTIONS : 0),
+								   (mode.depthShading ? SNAIL_RENDER_DEPTH : 0) | (mode.reflections ? SNAIL_RENDER_REFLECTIONS : 0) | (mode.antialias ? SNAIL_RENDER_AA4 : 0),
 								   (unsigned char *)image.DataPointer(), (int)image.Pitch(), st));
 	return detail::toStats<StatsT>(st);
 }
@@ -361,6 +381,7 @@ inline TreeStats Render(const Scene<snail::HipBVH<RefBVH>> &scene, const Camera 
 	snail::RenderMode mode;
 	mode.depthShading = gVals[1] != 0;
 	mode.reflections = gVals[7] != 0 || options.reflections;
+	mode.antialias = gVals[9] != 0;
 	return snail::RenderTiles<TreeStats>(scene, camera, resx, resy, data, coords, offsets, mode);
 }
 template <class RefBVH>
@@ -371,6 +392,7 @@ inline TreeStats Render(const Scene<snail::HipBVH<RefBVH>> &scene, const Camera 
 	snail::RenderMode mode;
 	mode.depthShading = gVals[1] != 0;
 	mode.reflections = gVals[7] != 0 || options.reflections;
+	mode.antialias = gVals[9] != 0;
 	return snail::RenderImage<TreeStats>(scene, camera, image, mode);
 }
 #undef SNAIL_HOST_RENDER

@@ -258,9 +258,18 @@ int snail_trace_transparency_dev(SnailScene *, const float cam[13], int resx, in
  * The device-side packet / tile lists are cached in the scene handle and rebuilt only when the tile list changes. */
 #define SNAIL_RENDER_REFLECTIONS 1
 #define SNAIL_RENDER_DEPTH       2
+#define SNAIL_RENDER_AA4         4   /* gVals[9]: 4x antialiasing (src/render.cpp:60-62, :71-110): four double-resolution packets per packet, reduced 2x2 */
 int snail_render_tiles(SnailScene *, const float cam[13], int resx, int resy, const int32_t *coords, const int64_t *offsets, int nTiles,
                        const float *lights7, int nLights, const float ambient[3], const float color[3], int flags, uint8_t *data,
                        uint64_t stats[4]);
+/* snail_render_tiles over SEVERAL devices of this process: scenes[d] = the same tree uploaded to device d (snail_scene_create once per
+ * device).  The reference's server deals a frame's tiles to its render nodes by shuffled round-robin and collects their buffers
+ * (src/server.cpp:233-265, :389-401); here the tiles are dealt the same way to the devices, every device renders its share at the same
+ * time, and the shares are written to `data` (host memory, as for the reference's server) -- bytes and summed counters identical to one
+ * snail_render_tiles call over the whole list.  The deal depends on (nTiles, nScenes) only, so each device's lists stay cached. */
+int snail_render_tiles_multi(SnailScene *const *scenes, int nScenes, const float cam[13], int resx, int resy, const int32_t *coords,
+                             const int64_t *offsets, int nTiles, const float *lights7, int nLights, const float ambient[3],
+                             const float color[3], int flags, uint8_t *data, uint64_t stats[4]);
 int snail_render_image(SnailScene *, const float cam[13], int resx, int resy, const float *lights7, int nLights, const float ambient[3],
                        const float color[3], int flags, uint8_t *image_bgr, int pitch, uint64_t stats[4]);
 

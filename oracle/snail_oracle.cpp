@@ -757,14 +757,47 @@ template <int MODE>
 void renderWhitted(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam, int resx, int resy, const float *lights7, int nLights,
 				   const float *ambient, const float *color, int flags, uint8_t *frame, int pitch, uint64_t *stats, int threads) {
 	const Lighting L{lights7, nLights, ambient, color, (flags & 1) != 0};
-	RayGen g = makeRayGen(*cam, resx, resy);
+	const bool aa = (flags & 2) != 0, depthShading = (flags & 4) != 0;
+	// gVals[9]: the generator works at twice the resolution (src/render.cpp:60-62)
+	RayGen g = makeRayGen(*cam, aa ? resx * 2 : resx, aa ? resy * 2 : resy);
 	int pw = (resx + 15) / 16, ph = (resy + 15) / 16;
 	threads = std::max(threads, 1);
 	std::vector<Stats> tstats(threads);
+	// one 16x16 packet through Scene::RayTrace: the light pipeline, or gVals[1]'s depth shading (src/scene_trace.cpp:128-137)
+	auto tracePacket = [&](int x, int y, float (*out)[3], Stats &st) {
+		if(!depthShading) { whittedPacket<MODE>(nodes, tris, *cam, g, x, y, L, out, st); return; }
+		float origin[12], dir[768], idir[768], dist[256], bary[512];
+		int32_t obj[256];
+		for(int c = 0; c < 3; c++) for(int l = 0; l < 4; l++) origin[c * 4 + l] = cam->pos[c];
+		genPacket<MODE>(g, x, y, dir, idir);
+		for(int i = 0; i < 256; i++) { dist[i] = kInf; obj[i] = 0; }
+		Rays r{64, true, origin, dir, idir, nullptr};
+		st.rays += 256;
+		traversePrimary<MODE>(nodes, tris, r, dist, obj, bary, st);
+		for(int i = 0; i < 256; i++) { const float d = Inv<MODE>(dist[i]); out[i][0] = d * 20.0f; out[i][1] = d * 250.0f; out[i][2] = d * 2.0f; }
+	};
 	parallelFor(pw * ph, threads, [&](int p, int tid) {
 		int px = (p % pw) * 16, py = (p / pw) * 16;
 		float col[256][3];
-		whittedPacket<MODE>(nodes, tris, *cam, g, px, py, L, col, tstats[tid]);
+		if(!aa) tracePacket(px, py, col, tstats[tid]);
+		else {
+			// 4x antialiasing (src/render.cpp:71-110): four packets of the double-resolution frame, each reduced 2x2 into one quarter of
+			// this packet: (row 2r + row 2r+1) * 0.25 per lane, then lane 0 + lane 1 and lane 2 + lane 3 -- in that order
+			const int offx[4] = {0, 16, 0, 16}, offy[4] = {0, 0, 16, 16}, coff[4] = {0, 2, 32, 34};
+			for(int k = 0; k < 4; k++) {
+				float tcol[256][3];
+				tracePacket(px * 2 + offx[k], py * 2 + offy[k], tcol, tstats[tid]);
+				for(int r = 0; r < 8; r++) for(int h = 0; h < 2; h++) {
+					const int q = 8 * r + 2 * h, dq = coff[k] + 4 * r + h;
+					for(int i = 0; i < 2; i++) for(int c = 0; c < 3; c++) {
+						float v[4];
+						for(int l = 0; l < 4; l++) v[l] = (tcol[(q + i) * 4 + l][c] + tcol[(q + i + 4) * 4 + l][c]) * 0.25f;
+						col[dq * 4 + i * 2 + 0][c] = v[0] + v[1];
+						col[dq * 4 + i * 2 + 1][c] = v[2] + v[3];
+					}
+				}
+			}
+		}
 		for(int q = 0; q < 64; q++) {
 			int yy = py + (q >> 2);
 			if(yy >= resy) continue;

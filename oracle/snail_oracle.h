@@ -116,7 +116,10 @@ void orc_shade_depth(const float *t, int n, uint8_t *bgr, int mode);
  * packet as RayGroup<0,1> (per-ray origins, lane masks = hit lanes) through the same RayTrace -- samples, lights, shadow
  * packets, no further bounce -- and blends diffuse += (reflected colour - diffuse) * 0.3 BEFORE the primary's own lights.
  * Lanes that are masked off in the reflected packet (no primary hit) carry zeros here (see above).
- * stats[4] += {intersects, iters, rays (primary + reflected lanes + shadow lanes with N.L > 0), skips}. */
+ * stats[4] += {intersects, iters, rays (primary + reflected lanes + shadow lanes with N.L > 0), skips}.
+ * flags bit 1 = gVals[9], 4x antialiasing of the tile renderer (src/render.cpp:60-62, :71-110): every 16x16 packet of the image is
+ * the 2x2 reduction of four packets of the double-resolution frame, in the reference's operation order.
+ * flags bit 2 = gVals[1], depth shading instead of the light pipeline (src/scene_trace.cpp:128-137): colour = Inv(t) * (20, 250, 2). */
 void orc_render_whitted(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam, int resx, int resy,
                         const float *lights7, int nLights, const float ambient[3], const float color[3], int flags,
                         uint8_t *frame_bgr, int pitch, uint64_t *stats, int mode, int threads);

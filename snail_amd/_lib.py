@@ -57,6 +57,7 @@ SIGNATURES = {
     "snail_render_whitted_packets_dev": (_I, [_VP, _F13, _I, _I, _VP, _I, _VP, _I, _VP, _VP, _I, _VP, _VP, _VP]),
     "snail_trace_transparency_dev": (_I, [_VP, _F13, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP]),
     "snail_render_tiles": (_I, [_VP, _F13, _I, _I, _VP, _VP, _I, _VP, _I, _VP, _VP, _I, _VP, _VP]),
+    "snail_render_tiles_multi": (_I, [_VP, _I, _F13, _I, _I, _VP, _VP, _I, _VP, _I, _VP, _VP, _I, _VP, _VP]),
     "snail_render_image": (_I, [_VP, _F13, _I, _I, _VP, _I, _VP, _VP, _I, _VP, _I, _VP]),
     "snail_account_primary": (_I, [_VP, _F13, _I, _I, _I, _I, _I, _I, _VP]),
     "snail_account_packets": (_I, [_VP, _F13, _I, _I, _VP]),

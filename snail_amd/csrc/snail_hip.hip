@@ -1793,6 +1793,7 @@ struct ShadeArgs {
 	const int2 *packetXY; // explicit packet list (tile sharding): packet li = packetXY[li], intermediates and output indexed by li; or null = the frame's grid
 	int nPackets;        // packet slots of the intermediates: list length, or pw * ph
 	unsigned char *bgrPackets; // list mode: packet-major B,G,R output [nPackets][256][3] instead of the frame
+	float *colPackets;         // list mode: the packets' colours as FLOATS [nPackets][256][3] (r, g, b) instead of bytes: the input of dev::k_aa_reduce
 	int nBlocks;         // grid.x of the per-packet kernels (packets padded to whole XCD regions)
 	int pack;            // at most 2^20 node slots: one-word stack entries in the hand-written walks
 	int nLights;
@@ -2166,6 +2167,14 @@ __global__ __launch_bounds__(64) void k_final(ShadeArgs A) {
 		}
 		return;
 	}
+	if(DST == DST_FRAME && A.colPackets) { // 4x antialiasing: the double-resolution packets' colours go on to dev::k_aa_reduce as floats
+#pragma unroll
+		for(int l = 0; l < 4; l++) {
+			float *rc = A.colPackets + (quad * 4 + l) * 3;
+			rc[0] = col[0][l]; rc[1] = col[1][l]; rc[2] = col[2][l];
+		}
+		return;
+	}
 	unsigned bytes[12];
 #pragma unroll
 	for(int l = 0; l < 4; l++) { bytes[l * 3 + 0] = (unsigned)convChannelW(col[2][l]); bytes[l * 3 + 1] = (unsigned)convChannelW(col[1][l]); bytes[l * 3 + 2] = (unsigned)convChannelW(col[0][l]); }
@@ -2190,6 +2199,42 @@ __global__ __launch_bounds__(64) void k_final(ShadeArgs A) {
 				if(xx + l < A.resx) { dd[l * 3 + 0] = (unsigned char)bytes[l * 3 + 0]; dd[l * 3 + 1] = (unsigned char)bytes[l * 3 + 1]; dd[l * 3 + 2] = (unsigned char)bytes[l * 3 + 2]; }
 		}
 	}
+}
+
+// ---- 4x antialiasing of the tile renderer (gVals[9]; src/render.cpp:60-62, :71-110) -----------------------------------------------
+// Every 16x16 packet of the image is the 2x2 reduction of FOUR packets of the double-resolution frame (sub-packet k at (2x + 16 (k & 1),
+// 2y + 16 (k >> 1)), stored at 4 p + k): out = ((top-left + bottom-left) * 0.25) + ((top-right + bottom-right) * 0.25), the reference's
+// operation order (row 2r plus row 2r + 1 per SSE lane, times 0.25, then lane 0 + lane 1 and lane 2 + lane 3), then ConvColor.
+// One wave per image packet, lane = output quad.  DEPTH: the input holds hit distances [4n][256] and the colour is gVals[1]'s depth
+// shading Inv(t) * (20, 250, 2) (src/scene_trace.cpp:128-137); else float colours [4n][256][3] written by k_final.  Output: packet-major B,G,R.
+template <bool DEPTH>
+__global__ __launch_bounds__(64) void k_aa_reduce(const float *__restrict__ in, int nPackets, unsigned char *__restrict__ bgrPackets) {
+	const int p = (int)blockIdx.x, lane = (int)threadIdx.x;
+	if(p >= nPackets) return;
+	const int row = lane >> 2, qc = lane & 3;                     // output quad: row, quad column
+	const int k = (row >= 8 ? 2 : 0) + (qc >= 2 ? 1 : 0);         // the quarter of the packet = the sub-packet it comes from
+	const int r = row & 7, h = qc & 1;
+	unsigned bytes[12];
+#pragma unroll
+	for(int j = 0; j < 4; j++) {
+		const int i = j >> 1, s2 = (j & 1) * 2;
+		const int qa = 8 * r + 2 * h + i, qb = qa + 4;              // the input quads of rows 2r and 2r + 1
+		const size_t ia = ((size_t)(4 * p + k) * 64 + qa) * 4 + s2, ib = ((size_t)(4 * p + k) * 64 + qb) * 4 + s2;
+		float c[3];
+#pragma unroll
+		for(int ch = 0; ch < 3; ch++) {
+			float a0, a1, b0, b1;
+			if(DEPTH) {
+				const float scale = ch == 0 ? 20.0f : ch == 1 ? 250.0f : 2.0f;
+				a0 = (1.0f / in[ia]) * scale; a1 = (1.0f / in[ia + 1]) * scale; b0 = (1.0f / in[ib]) * scale; b1 = (1.0f / in[ib + 1]) * scale;
+			} else { a0 = in[ia * 3 + ch]; a1 = in[(ia + 1) * 3 + ch]; b0 = in[ib * 3 + ch]; b1 = in[(ib + 1) * 3 + ch]; }
+			c[ch] = (a0 + b0) * 0.25f + (a1 + b1) * 0.25f;
+		}
+		bytes[j * 3 + 0] = (unsigned)convChannelW(c[2]); bytes[j * 3 + 1] = (unsigned)convChannelW(c[1]); bytes[j * 3 + 2] = (unsigned)convChannelW(c[0]);
+	}
+	unsigned *o = (unsigned *)(bgrPackets + ((size_t)p * 256 + (size_t)lane * 4) * 3);
+#pragma unroll
+	for(int w = 0; w < 3; w++) o[w] = bytes[4 * w] | (bytes[4 * w + 1] << 8) | (bytes[4 * w + 2] << 16) | (bytes[4 * w + 3] << 24);
 }
 
 // ---- generic packets: TraversePrimary<SHARED,MASK>(Context&) --------------------------------------
@@ -3338,10 +3383,10 @@ int snail_trace_shadow(SnailScene *s, int nPackets, int size, const float *origi
 
 static int renderWhitted(const char *fn, SnailScene *s, const float cam[13], int resx, int resy, const int32_t *dPacketXY, int nPacketsList, const float *lights7,
 						 int nLights, const float ambient[3], const float color[3], int flags, uint8_t *frame, int pitch, uint8_t *bgrPackets, uint64_t *dStats,
-						 void *stream) {
+						 void *stream, float *colPackets = nullptr) {
 	if(int rc = checkScene(s, fn)) return rc;
 	if(resx <= 0 || resy <= 0 || nLights < 0 || nLights > SNAIL_MAX_LIGHTS || (nLights && !lights7) || !ambient || !color || (flags & ~SNAIL_WHITTED_REFLECTIONS) ||
-	   (dPacketXY ? (!bgrPackets || ((unsigned long long)bgrPackets & 3)) : (!frame || pitch < resx * 3))) {
+	   (dPacketXY ? (colPackets ? false : (!bgrPackets || ((unsigned long long)bgrPackets & 3))) : (!frame || pitch < resx * 3 || colPackets))) {
 		snail_set_error("%s: bad arguments (at most %d lights; flags = SNAIL_WHITTED_REFLECTIONS or 0; 4-byte aligned output)", fn, SNAIL_MAX_LIGHTS);
 		return 1;
 	}
@@ -3359,7 +3404,7 @@ static int renderWhitted(const char *fn, SnailScene *s, const float cam[13], int
 	for(int n = 0; n < nLights; n++) for(int k = 0; k < 7; k++) A.lights[n][k] = lights7[n * 7 + k];
 	for(int c = 0; c < 3; c++) { A.ambient[c] = ambient[c]; A.color[c] = color[c]; }
 	A.frame = frame; A.pitch = pitch; A.stats = (dev::u64 *)dStats;
-	A.packetXY = (const int2 *)dPacketXY; A.bgrPackets = bgrPackets;
+	A.packetXY = (const int2 *)dPacketXY; A.bgrPackets = bgrPackets; A.colPackets = colPackets;
 	int packets, blocks;
 	if(dPacketXY) {
 		packets = nPacketsList;

@@ -381,6 +381,47 @@ class Scene:
         _lib.check(rc, "snail_trace_transparency_dev")
         return out
 
+    RENDER_REFLECTIONS, RENDER_DEPTH, RENDER_AA4 = 1, 2, 4     # include/snail_hip.h: flags of the host-pointer tile API
+
+    def render_image_host(self, cam: Camera, resx: int, resy: int, lights7=None, flags: int = 0, ambient=(0.1, 0.1, 0.1), color=(1.0, 1.0, 1.0)):
+        """snail_render_image = Render(scene, camera, image, options, threads) of src/render.h:21-23 (what a C++ host calls): the rgb8 frame
+        [resy, resx, 3] (B,G,R) in host memory and the call's TreeStats.  flags: RENDER_REFLECTIONS (gVals[7]), RENDER_DEPTH (gVals[1]),
+        RENDER_AA4 (gVals[9], 4x antialiasing)."""
+        lights = np.ascontiguousarray(lights7 if lights7 is not None else np.zeros((0, 7)), dtype=np.float32).reshape(-1, 7)
+        cam13 = np.ascontiguousarray(cam.as_array13(), dtype=np.float32)
+        amb = np.ascontiguousarray(ambient, dtype=np.float32); col = np.ascontiguousarray(color, dtype=np.float32)
+        img = np.zeros((resy, resx, 3), dtype=np.uint8)
+        stats = np.zeros(4, dtype=np.uint64)
+        rc = _lib.lib().snail_render_image(self._h, _lib.ptr(cam13), resx, resy, _lib.ptr(lights) if len(lights) else None, len(lights), _lib.ptr(amb), _lib.ptr(col),
+                                           int(flags), _lib.ptr(img), resx * 3, _lib.ptr(stats))
+        _lib.check(rc, "snail_render_image")
+        return img, stats
+
+    def render_tiles_host(self, cam: Camera, resx: int, resy: int, tiles, lights7=None, flags: int = 0, ambient=(0.1, 0.1, 0.1), color=(1.0, 1.0, 1.0), scenes=None):
+        """snail_render_tiles (or, with `scenes` = a list of Scene objects holding the same tree, snail_render_tiles_multi): the tile-list
+        renderer of src/render.h:16-19.  tiles = [n, 4] (x, y, w, h); returns (data, offsets, stats) with tile k's planes R, G-R, B-R at
+        data[offsets[k]:offsets[k] + 3 w h]."""
+        import ctypes as C_
+        t = np.ascontiguousarray(tiles, dtype=np.int32).reshape(-1, 4)
+        size = 3 * t[:, 2].astype(np.int64) * t[:, 3]
+        offsets = np.concatenate([[0], np.cumsum(size)[:-1]]).astype(np.int64)
+        data = np.zeros(int(size.sum()), dtype=np.uint8)
+        lights = np.ascontiguousarray(lights7 if lights7 is not None else np.zeros((0, 7)), dtype=np.float32).reshape(-1, 7)
+        cam13 = np.ascontiguousarray(cam.as_array13(), dtype=np.float32)
+        amb = np.ascontiguousarray(ambient, dtype=np.float32); col = np.ascontiguousarray(color, dtype=np.float32)
+        stats = np.zeros(4, dtype=np.uint64)
+        lp = _lib.ptr(lights) if len(lights) else None
+        if scenes:
+            hs = (C_.c_void_p * len(scenes))(*[sc._h.value for sc in scenes])
+            rc = _lib.lib().snail_render_tiles_multi(hs, len(scenes), _lib.ptr(cam13), resx, resy, _lib.ptr(t), _lib.ptr(offsets), len(t), lp, len(lights), _lib.ptr(amb),
+                                                     _lib.ptr(col), int(flags), _lib.ptr(data), _lib.ptr(stats))
+            _lib.check(rc, "snail_render_tiles_multi")
+        else:
+            rc = _lib.lib().snail_render_tiles(self._h, _lib.ptr(cam13), resx, resy, _lib.ptr(t), _lib.ptr(offsets), len(t), lp, len(lights), _lib.ptr(amb), _lib.ptr(col),
+                                               int(flags), _lib.ptr(data), _lib.ptr(stats))
+            _lib.check(rc, "snail_render_tiles")
+        return data, offsets, stats
+
     def trace_primary_host(self, cam: Camera, resx: int, resy: int, rect=None):
         """Host-buffer entry point (what a C++ host would call): numpy planes in, numpy planes out."""
         x0, y0, w, h = rect if rect is not None else (0, 0, resx, resy)

@@ -190,16 +190,27 @@ int main(int argc, char **argv) {
 		const TreeStats st = Render(scene, cam, (uint)resx, (uint)resy, data.data(), coords, offsets, Options(), 0u, 4u);
 		FILE *f = std::fopen((d + "out_tiles.bin").c_str(), "wb"); dump(f, data); std::fclose(f);
 		std::fprintf(fs, "tiles %u %u %u %u\n", st.in, st.it, st.rays, st.sk);
+		{ // the same call with the tree uploaded THREE times (here: to the one device there is): the tile list is dealt over the handles
+			// (snail_render_tiles_multi); bytes and counters must not change
+			Scene<snail::HipBVH<MockBVH>> scene3;
+			scene3.lights = scene.lights; scene3.ambientLight = scene.ambientLight;
+			scene3.geometry.Upload(bvh, std::vector<int>{0, 0, 0});
+			std::vector<unsigned char> data3(total, 0xAB);
+			const TreeStats s3 = Render(scene3, cam, (uint)resx, (uint)resy, data3.data(), coords, offsets, Options(), 0u, 4u);
+			const bool same = data3 == data && s3.in == st.in && s3.it == st.it && s3.rays == st.rays && s3.sk == st.sk;
+			std::fprintf(fs, "tiles_multi %d %d\n", (int)same, scene3.geometry.DeviceCount());
+		}
 		MipmapTexture img; img.w = resx; img.h = resy; img.pitch = (resx * 3 + 63) / 64 * 64; img.bytes.assign((size_t)img.pitch * resy, 0xCD);
 		const TreeStats si = Render(scene, cam, img, Options(), 4u);
 		f = std::fopen((d + "out_image.bin").c_str(), "wb"); dump(f, img.bytes); std::fclose(f);
 		std::fprintf(fs, "image %u %u %u %u %d\n", si.in, si.it, si.rays, si.sk, img.pitch);
 	}
 	// ---- a switch the device pipeline does not implement: the call must reach the reference's own renderer (the generic templates above),
-	// prefetched; meta[7] = index into gVals (5, 6, 8, 9), 0 = skip ----
+	// prefetched; meta[7] = index into gVals (5, 6, 8; 59 = gVals[5] AND gVals[9]: the stats heat-map under 4x antialiasing), 0 = skip ----
 	if(meta.size() > 7 && meta[7] > 0) {
 		const int sw = meta[7];
-		gVals[7] = 0; gVals[1] = 0; gVals[sw] = 1;
+		gVals[7] = 0; gVals[1] = 0;
+		if(sw == 59) { gVals[5] = 1; gVals[9] = 1; } else gVals[sw] = 1;
 		if(sw == 6) bvh.shTris.resize(bvh.tris.size());        // full shading needs shading data (src/scene_trace.cpp:145)
 		g_expectHostRender = 1;
 		const std::vector<int> coords = slurp<int>(d + "tiles.bin"), offsets = slurp<int>(d + "offsets.bin");
@@ -210,7 +221,8 @@ int main(int argc, char **argv) {
 		g_expectHostRender = sw == 8 ? 0 : 1;
 		const TreeStats si = Render(scene, cam, img, Options(), 4u);
 		std::printf("switch %d: tile stats %u image stats %u frame left %d\n", sw, st.it, si.it, (int)acc.HaveFrame());
-		gVals[sw] = 0; g_expectHostRender = 0;
+		if(sw == 59) { gVals[5] = 0; gVals[9] = 0; } else gVals[sw] = 0;
+		g_expectHostRender = 0;
 	}
 	std::fclose(fs);
 	std::printf("adapter ok: %d x %d, normal of tri 0 = %g %g %g\n", resx, resy, acc.GetNormal(0, 0).x, acc.GetNormal(0, 0).y, acc.GetNormal(0, 0).z);

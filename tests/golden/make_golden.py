@@ -180,6 +180,21 @@ def oracle_whitted():
     print("oracle_whitted_refl.json written")
 
 
+def oracle_whitted_aa():
+    """gVals[9], the tile renderer's 4x antialiasing (src/render.cpp:60-62, :71-110), on the frame of oracle_whitted.json at half its size:
+    light pipeline, light pipeline + mirrored bounce, depth shading."""
+    name, resx, resy = "atrium:0.05", 320, 192
+    tv, hb, osc = util.scene_pair(name)
+    cam = util.camera_for(name, tv)
+    lights = whitted_lights(osc, cam, 2)
+    out = {"scene": name, "res": [resx, resy], "lights": lights.tolist(), "modes": {}}
+    for mode in ("lights", "refl", "depth"):
+        frame, st = osc.render_whitted(cam.as_array13(), resx, resy, lights, mode=O.MODE_IEEE, reflections=mode == "refl", antialias=True, depth=mode == "depth")
+        out["modes"][mode] = {"sha_bgr": sha(frame), "stats": [int(x) for x in st], "mean_bgr": [float(x) for x in frame.reshape(-1, 3).mean(axis=0)]}
+    json.dump(out, open(os.path.join(HERE, "oracle_whitted_aa.json"), "w"), indent=1)
+    print("oracle_whitted_aa.json written")
+
+
 def oracle_transparency():
     name, resx, resy = "atrium:0.05", 320, 192
     tv, hb, osc = util.scene_pair(name)
@@ -198,4 +213,5 @@ if __name__ == "__main__":
     oracle_frames()
     oracle_packets()
     oracle_whitted()
+    oracle_whitted_aa()
     oracle_transparency()

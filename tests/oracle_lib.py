@@ -132,13 +132,14 @@ class OracleScene:
         lib().orc_account_primary(_p(self.nodes), _p(self.tris), _p(cam), resx, resy, x0, y0, w, h, _p(out), mode, threads)
         return out
 
-    def render_whitted(self, cam13, resx, resy, lights7, ambient=(0.1, 0.1, 0.1), color=(1.0, 1.0, 1.0), mode=MODE_IEEE, threads=8, reflections=False):
+    def render_whitted(self, cam13, resx, resy, lights7, ambient=(0.1, 0.1, 0.1), color=(1.0, 1.0, 1.0), mode=MODE_IEEE, threads=8, reflections=False,
+                       antialias=False, depth=False):
         cam = np.ascontiguousarray(cam13, dtype=np.float32)
         lights = np.ascontiguousarray(lights7, dtype=np.float32).reshape(-1, 7)
         amb = np.asarray(ambient, dtype=np.float32); col = np.asarray(color, dtype=np.float32)
         frame = np.zeros((resy, resx, 3), dtype=np.uint8)
         stats = np.zeros(4, dtype=np.uint64)
-        lib().orc_render_whitted(_p(self.nodes), _p(self.tris), _p(cam), resx, resy, _p(lights), len(lights), _p(amb), _p(col), 1 if reflections else 0, _p(frame), resx * 3,
+        lib().orc_render_whitted(_p(self.nodes), _p(self.tris), _p(cam), resx, resy, _p(lights), len(lights), _p(amb), _p(col), (1 if reflections else 0) | (2 if antialias else 0) | (4 if depth else 0), _p(frame), resx * 3,
                                  _p(stats), mode, threads)
         return frame, stats
 

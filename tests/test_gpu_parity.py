@@ -654,6 +654,7 @@ def test_cpp_adapter_end_to_end(torch_mod, tmp_path, refl, depth_mode):
     assert np.array_equal(img[:, :resx * 3].reshape(resy, resx, 3), want_frame)
     assert (img[:, resx * 3:] == 0xCD).all()                 # row padding untouched
     assert stats["image"][:4] == [int(wst[0]), int(wst[1]), int(wst[2]), int(wst[3])], (stats["image"], wst)
+    assert stats["tiles_multi"] == [1, 3]                     # three handles, one frame's tiles dealt over them: same bytes, same counters
     # the tile call traced this rank's tiles only: its counters are the oracle's over exactly those tiles
     if depth_mode:
         mine = np.zeros(4, dtype=np.uint64)
@@ -664,13 +665,13 @@ def test_cpp_adapter_end_to_end(torch_mod, tmp_path, refl, depth_mode):
         assert 0 < stats["tiles"][1] < int(wst[1]) and stats["tiles"][2] >= len(R.tile_packets(tiles)) * 256
 
 
-@pytest.mark.parametrize("sw", [5, 6, 8, 9])
+@pytest.mark.parametrize("sw", [5, 6, 8, 59])
 def test_cpp_adapter_render_honours_or_hands_over(torch_mod, tmp_path, sw):
     """Render(...) with the reference's signatures must not silently drop a switch of the reference's renderer that the device pipeline
-    does not implement (gVals[5] stats heat-map, [6] full shading on a scene with shading data, [8] per-rank tint of the tile list, [9] 4x
-    antialiasing): such a call is handed to the reference's OWN renderer (here: the mock's generic Render templates) with the frame it
-    will ask for prefetched by one launch -- at twice the resolution under antialiasing (src/render.cpp:60-62) -- and the prefetch is
-    released afterwards."""
+    does not implement (gVals[5] stats heat-map, [6] full shading on a scene with shading data, [8] per-rank tint of the tile list): such a
+    call is handed to the reference's OWN renderer (here: the mock's generic Render templates) with the frame it will ask for prefetched
+    by one launch -- at twice the resolution when 4x antialiasing is on as well (sw = 59: gVals[5] and gVals[9], src/render.cpp:60-62) --
+    and the prefetch is released afterwards.  (gVals[9] alone IS implemented on the device: test_antialiased_tile_renderer.)"""
     import subprocess
     from snail_amd import render as R
     from tests.test_host_side import build_adapter_mock
@@ -687,13 +688,45 @@ def test_cpp_adapter_render_honours_or_hands_over(torch_mod, tmp_path, sw):
     exe = build_adapter_mock(tmp_path)
     r = subprocess.run([exe, str(d)], capture_output=True, text=True)
     assert r.returncode == 0 and "adapter ok" in r.stdout, r.stdout + r.stderr
-    scale = 2 if sw == 9 else 1
+    scale = 2 if sw == 59 else 1
     assert "host tile Render: prefetched %d x %d 1" % (resx * scale, resy * scale) in r.stdout, r.stdout
     if sw == 8:     # the tint belongs to the tile-list renderer only: the image call stays on the device
         assert "host image Render" not in r.stdout and "switch 8: tile stats 777 image stats" in r.stdout
     else:
         assert "host image Render: prefetched %d x %d 1" % (resx * scale, resy * scale) in r.stdout, r.stdout
         assert "switch %d: tile stats 777 image stats 778 frame left 0" % sw in r.stdout, r.stdout
+
+
+@pytest.mark.parametrize("name,resx,resy,mode", [("atrium:0.05", 320, 192, "lights"), ("atrium:0.05", 320, 192, "refl"), ("atrium:0.05", 250, 130, "depth"),
+                                                 ("box", 64, 64, "lights"), ("stress:0.05", 160, 96, "lights")])
+def test_antialiased_tile_renderer(torch_mod, name, resx, resy, mode):
+    """gVals[9], the tile renderer's 4x antialiasing (src/render.cpp:60-62, :71-110), on the device: every image packet is the 2x2 reduction
+    of four packets of the double-resolution frame through the same pipeline (light pipeline with or without the mirrored bounce, or
+    gVals[1]'s depth shading), in the reference's operation order.  The rgb8 image, the tile list's planar bytes and the TreeStats are
+    the oracle's; the tile list dealt over two scene handles (snail_render_tiles_multi) gives the same bytes and counters."""
+    from snail_amd import render as R
+    from snail_amd.scene import Scene
+    tv, sc, osc = gpu_scene(name)
+    cam = util.camera_for(name, tv)
+    bmin, bmax = osc.nodes[0]["bmin"], osc.nodes[0]["bmax"]
+    c, e = (bmin + bmax) * 0.5, (bmax - bmin)
+    lights = np.array([[c[0], c[1] + 0.35 * e[1], c[2], 1.0, 0.9, 0.8, 2.0 * float(e.max())]], dtype=np.float32)
+    flags = Scene.RENDER_AA4 | (Scene.RENDER_REFLECTIONS if mode == "refl" else 0) | (Scene.RENDER_DEPTH if mode == "depth" else 0)
+    want, wst = osc.render_whitted(cam.as_array13(), resx, resy, lights, reflections=mode == "refl", antialias=True, depth=mode == "depth")
+    img, st = sc.render_image_host(cam, resx, resy, lights, flags)
+    assert np.array_equal(img, want), int((img != want).sum())
+    assert np.array_equal(st, wst), (st, wst)
+    plain, _ = osc.render_whitted(cam.as_array13(), resx, resy, lights, reflections=mode == "refl", depth=mode == "depth")
+    assert not np.array_equal(plain, want)                       # antialiasing changes the picture
+    tiles = R.divide_image(resx, resy)
+    data, offsets, tst = sc.render_tiles_host(cam, resx, resy, tiles, lights, flags)
+    for k, wp in enumerate(O.planar_encode(want, tiles)):
+        assert np.array_equal(data[offsets[k]:offsets[k] + len(wp)], wp), ("tile", k)
+    sc2 = Scene(sc.bvh, 0)
+    data2, _, tst2 = sc.render_tiles_host(cam, resx, resy, tiles, lights, flags, scenes=[sc, sc2])
+    assert np.array_equal(data2, data) and np.array_equal(tst2, tst), (tst2, tst)
+    sc2.close()
+    sc.close()
 
 
 def test_depth_shading_and_tile_pipeline(torch_mod):
@@ -850,6 +883,22 @@ def test_whitted_against_committed_fixture(torch_mod, fixture, refl):
     torch_mod.cuda.synchronize()
     assert hashlib.sha256(fr.cpu().numpy().tobytes()).hexdigest() == g["sha_bgr"]
     assert stats.cpu().numpy().tolist() == g["stats"]
+    sc.close()
+
+
+@pytest.mark.parametrize("mode", ["lights", "refl", "depth"])
+def test_antialiasing_against_committed_fixture(torch_mod, mode):
+    """HIP tile renderer with 4x antialiasing vs the bytes committed under tests/golden/oracle_whitted_aa.json."""
+    import hashlib
+    import json
+    from snail_amd.scene import Scene
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_whitted_aa.json")))
+    tv, sc, osc = gpu_scene(g["scene"])
+    cam = util.camera_for(g["scene"], tv)
+    flags = Scene.RENDER_AA4 | (Scene.RENDER_REFLECTIONS if mode == "refl" else 0) | (Scene.RENDER_DEPTH if mode == "depth" else 0)
+    img, st = sc.render_image_host(cam, g["res"][0], g["res"][1], np.asarray(g["lights"], dtype=np.float32), flags)
+    assert hashlib.sha256(img.tobytes()).hexdigest() == g["modes"][mode]["sha_bgr"]
+    assert [int(x) for x in st] == g["modes"][mode]["stats"]
     sc.close()
 
 
