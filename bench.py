@@ -32,6 +32,10 @@ Mrays = rays launched (every lane of every traced packet, hit or miss), as TreeS
 (src/scene_trace.cpp:116-117): frames are padded to whole 16x16 packets (1920x1080 -> 1920x1088); config 3 adds the shadow
 lanes with N.L > 0 (:554-557).
 
+Before the W warm-up steps the pipeline runs untimed for `--settle-ms` (default 30 ms, ~350 frames; reported as config.settle_ms / settle_frames): from an
+idle start the part's shader clock ramps for tens of milliseconds (profiles/README.md), and a short timed region would measure that ramp.  W warm-up
+steps, the barrier + synchronize, and EXACTLY K timed steps follow as the contract says.
+
 Launches: frames are pipelined over 4 HIP streams, and `--frames-per-launch B` frames (default: enough for a launch to hold a 1080p frame's worth of packets, i.e. 2 / 2 / 4 / 8 at N = 1 / 2 / 4 / 8;
 always 1 for config 3)
 share ONE launch -- the heaviest packets of all of them first, one tail and one set of launch overheads (and, at N > 1, one collective)
@@ -194,7 +198,7 @@ def main():
     ap.add_argument("--frames-per-launch", type=int, default=0, help="trace this many frames (1..8) with one launch -- and, at N > 1, move them with one collective (DistributedRenderer frames_per_launch); 0 = enough for a launch to hold 8160 packets (one 1080p frame), at least 2, at most 8: 2 / 2 / 4 / 8 at N = 1 / 2 / 4 / 8; config 3 always 1")
     ap.add_argument("--lone-frames", type=int, default=12, help="frames (N > 1: launches through the whole route) traced one at a time after the timed region (lone_frame_ms / lone_launch_ms); 0 = skip")
     ap.add_argument("--camera-path", default="static", choices=["static", "orbit"], help="orbit = the camera turns 0.2 degrees every step (dispatch orders are then predictions from an older view, re-derived every --order-refresh frames of a slot, inside the timed region)")
-    ap.add_argument("--settle-ms", type=float, default=0.0, help="untimed frames for this many milliseconds BEFORE the W warm-up steps (the part's clocks ramp for tens of ms after an idle start: profiles/README.md)")
+    ap.add_argument("--settle-ms", type=float, default=30.0, help="untimed frames for this many milliseconds BEFORE the W warm-up steps: the part's clocks ramp for tens of ms after an idle start (2.09 -> 1.91 -> 2.2 GHz over the first 600 frames, profiles/README.md), which a 20-step timed region would otherwise measure instead of the kernel; 0 = off; reported as config.settle_ms")
     ap.add_argument("--dry-run", action="store_true", help="start the ranks, rendezvous, one all-reduce over the chosen backend, print {dry_run, ranks} and exit: checks the launch path without a GPU (with --backend gloo)")
     ap.add_argument("--order-refresh", type=int, default=16, help="frames of a slot between two derivations of its dispatch order while the camera moves (DistributedRenderer order_refresh)")
     args = ap.parse_args()
@@ -287,14 +291,12 @@ def main():
     tot = rnd.reduce_stats(st) if world > 1 else st
     total_rays = int(tot.cpu().numpy()[2]) if (rank == 0 and cfg["lights"]) else primary_rays
     node_visits = int(tot.cpu().numpy()[1]) if rank == 0 else 0
-    settle_frames = 0
-    if args.settle_ms > 0:
-        t_end = time.perf_counter() + args.settle_ms * 1e-3
-        while time.perf_counter() < t_end:
-            for _ in range(8 * rnd.batch):
-                rnd.render(cam)
-            settle_frames += 8 * rnd.batch
-        # (no flush: the warm-up steps follow in the same pipeline)
+    # settle: a FIXED number of untimed frames (12 per millisecond asked for = the single-GPU rate of the headline workload), the same on
+    # every rank -- the ranks' collectives must pair up, so the count cannot depend on a rank's clock
+    settle_frames = int(args.settle_ms * 12.0) // rnd.batch * rnd.batch if args.settle_ms > 0 else 0
+    for _ in range(settle_frames):
+        rnd.render(cam)
+    # (no flush: the warm-up steps follow in the same pipeline)
     for i in range(args.warmup):
         rnd.render(cam_at(i))
     rnd.flush()

@@ -566,9 +566,10 @@ void renderPrimary(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *ca
 		for(int i = 0; i < 256; i++) { dist[i] = kInf; obj[i] = 0; }   // src/scene_trace.cpp:112-115
 		memset(bary, 0, sizeof(bary));
 		Rays r{64, true, origin, dir, idir, nullptr};
-		Stats &st = tstats[tid];
+		Stats st;                                                       // (per packet: neighbouring workers' counters share cache lines)
 		st.rays += 256;                                                 // src/scene_trace.cpp:116-117
 		traversePrimary<MODE>(nodes, tris, r, dist, obj, bary, st);
+		tstats[tid].intersects += st.intersects; tstats[tid].iters += st.iters; tstats[tid].rays += st.rays; tstats[tid].skips += st.skips;
 		for(int q = 0; q < 64; q++) {
 			int yy = py + (q >> 2);
 			if(yy >= resy || yy >= y0 + h) continue;

@@ -1406,7 +1406,7 @@ __device__ __forceinline__ void finalBarycentrics(const uint4 *__restrict__ tris
 			const float det = Q.d[0][l] * t.n[0] + Q.d[1][l] * t.n[1] + Q.d[2][l] * t.n[2];
 			const float v = Q.d[0][l] * tt.t0v[0] + Q.d[1][l] * tt.t0v[1] + Q.d[2][l] * tt.t0v[2];
 			const float u = Q.d[0][l] * tt.t1v[0] + Q.d[1][l] * tt.t1v[1] + Q.d[2][l] * tt.t1v[2];
-			const float idet = 1.0f / det;
+			const float idet = recipExact(det);   // = 1.0f / det bit for bit (see recipExact)
 			bu[l] = u * idet; bv[l] = v * idet;
 		}
 	}
