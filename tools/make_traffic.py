@@ -29,9 +29,11 @@ for a in sys.argv[1:]:
     else:
         per = collections.defaultdict(dict)      # kernel -> counter -> per-frame total
         for line in open(f):
-            p = line.split()
-            if len(p) >= 5 and p[3].startswith("mean=") and p[4].startswith("kernel="):
-                n = int(p[2][2:]); per[p[4][7:]][p[1]] = float(p[3][5:]) * n / frames
+            if "kernel=" not in line: continue
+            head, kname = line.rstrip("\n").split("kernel=", 1)
+            p = head.split()
+            if len(p) >= 4 and p[3].startswith("mean="):
+                n = int(p[2][2:]); per[kname.strip()][p[1]] = float(p[3][5:]) * n / frames
         tot = collections.defaultdict(float)
         for k, v in per.items():
             for c, x in v.items(): tot[c] += x

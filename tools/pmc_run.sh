@@ -8,7 +8,7 @@ OUT=gpurun_out/pmc_$TAG
 mkdir -p $OUT
 run() { # name, counters...
   local name=$1; shift
-  timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --lone-frames 0 --frames-per-launch 1 $EXTRA > $OUT/$name.log 2>&1
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --lone-frames 0 --frames-per-launch 1 --settle-ms 0 $EXTRA > $OUT/$name.log 2>&1
   echo "$name rc=$?"
 }
 EXTRA="$*"
