@@ -11,7 +11,7 @@ if ROOT not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # a fresh checkout has no built artefacts (*.so are git-ignored): build them once, in-tree, before collecting
-    need = [os.path.join(ROOT, "snail_amd", "libsnailhip.so"), os.path.join(ROOT, "oracle", "liboracle.so")]
+    need = [os.path.join(ROOT, "snail_amd", "libsnailhip.so"), os.path.join(ROOT, "snail_amd", "libsnailhip_debug.so"), os.path.join(ROOT, "oracle", "liboracle.so")]
     if not all(os.path.exists(p) for p in need):
         import __graft_entry__
         __graft_entry__.build()
