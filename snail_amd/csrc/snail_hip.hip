@@ -1204,10 +1204,6 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 "L_leaf" X "_%=:\n s_bfe_u32 %[leafSub], " SUB ", 0x190006\n s_sub_u32 %[leafSub], %[leafSub], 0x80000\n s_bitset1_b32 %[leafSub], 31\n" /* 0x80000000 | first triangle: (offset - 2^25) / 64 */ \
 				 " s_mov_b32 %[leafAux], " AUX "\n s_waitcnt lgkmcnt(0)\n s_branch L_end_%=\n"
 // set A = s[84:91] (planes NXA.., sub s90, aux s91), set B = s[76:83] (planes NXB.., sub s82, aux s83)
-// SNAIL_PF_NARROWCHK (defined around the instantiations that hand narrow subtrees over): a popped entry whose range holds at most 16 quads
-// leaves the statement un-visited, for dev::narrowSubtree
-#define SNAIL_PF_NARROWCHK_ON " s_cmp_lt_u32 %[width], 16\n s_cbranch_scc1 L_narrow_%=\n"
-#define SNAIL_PF_NARROWCHK ""
 #define SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)                 \
 	asm volatile(" s_mov_b32 m0, %[sp]\n"                                                                                                 \
 				 "L_entry_%=:\n"                                                                                                           \
@@ -1220,7 +1216,6 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 " s_sub_u32 m0, m0, 1\n" CNTPOP                                                                                     \
 				 " s_bfe_u32 %[first], %[topw], 0x60014\n s_lshr_b32 %[last], %[topw], 26\n"                                               \
 				 " s_sub_u32 %[width], %[last], %[first]\n"                                                                                \
-				 SNAIL_PF_NARROWCHK                                                                                                        \
 				 " s_bfm_b64 exec, %[width], %[first]\n s_bitset1_b64 exec, %[last]\n"                                                     \
 				 " s_cmp_eq_u32 m0, 0\n s_cbranch_scc1 L_last_%=\n"                                                                     \
 				 " s_sub_u32 %[off], m0, 1\n"                                                                                           \
@@ -1235,8 +1230,7 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 SNAIL_PF_VISIT("B", "A", "s[84:91]", "s82", "s83", PRE, SLAB, TAIL, CNTVISIT, NXB, FXB, NYB, FYB, NZB, FZB)                \
 				 "L_fail_%=:\n"                                                                                                            \
 				 " s_cmp_eq_u32 m0, 0\n s_cbranch_scc0 L_pop_%=\n"                                                                      \
-				 "L_done_%=:\n s_mov_b32 %[leafSub], 0\n s_mov_b32 %[leafAux], 0\n s_waitcnt lgkmcnt(0)\n s_branch L_end_%=\n"                    \
-				 "L_narrow_%=:\n s_mov_b32 %[leafSub], 1\n s_mov_b32 %[leafAux], %[topw]\n s_waitcnt lgkmcnt(0)\n" /* the popped entry goes to dev::narrowSubtree */ \
+				 "L_done_%=:\n s_mov_b32 %[leafSub], 0\n s_mov_b32 %[leafAux], 0\n s_waitcnt lgkmcnt(0)\n"                                  \
 				 "L_end_%=:\n s_mov_b64 exec, -1\n s_mov_b32 %[sp], m0\n"                                                                                        \
 				 : [sp] "+s"(sp), [first] "+s"(first), [last] "+s"(last), [cnt] "+s"(cnt), [stkN] "+v"(stkN), [stkF] "+v"(stkF),           \
 				   [leafSub] "=&s"(leafSub), [leafAux] "=&s"(leafAux), [cur] "=&s"(sCur), [fl] "=&s"(sFl), [off] "=&s"(sOff),              \
@@ -1307,128 +1301,6 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 #ifndef SNAIL_NODE_PREFETCH
 #define SNAIL_NODE_PREFETCH 1 // 0 = the loop without record prefetch for one-word stacks too (A/B measurements)
 #endif
-#ifndef SNAIL_NARROW_SUBTREES
-#define SNAIL_NARROW_SUBTREES 1 // primary packets: a popped stack entry whose range holds <= 16 quads is walked with ONE RAY PER LANE (dev::narrowSubtree)
-#endif
-
-// ---- a subtree under a NARROW range, one ray per lane ---------------------------------------------------------------------------------
-// A lane holds an SSE quad = 4 rays, so a node visit costs ~54 vector instructions whatever the width of [first, last].  When the
-// record-prefetching loop pops an entry whose range holds at most 16 quads (29 % of the inner and 67 % of the leaf visits of the stress-1M
-// frame, 10 % / 34 % of the atrium's: tests/range_hist.py), the subtree below it is walked HERE: the range's 64 rays are spread over the
-// wave once (lane j <- ray j % 4 of quad qbase + j / 4, through the LDS crossbar), a visit tests one ray per lane (6 multiplies, two
-// three-operand min / max, 3 others) and folds the lanes' verdicts into quads on the scalar side (a quad survives if any of its four lanes
-// does; first / last = the first / last surviving quad of the inherited range, src/bounding_box.cpp:71-139), leaves are intersected in place
-// (no gather, no write-back per leaf), and the rays' distances / triangle ids return to the quad lanes once, at the end.  Every ray sees
-// the operations of the wide walk in the same order; pushes go above the caller's stack pointer in the caller's stack register, and the
-// walk ends when that level is reached again.  Node records: the prefetching loop's copy (slot numbers, re-encoded link words).
-// Returns the node visits made (the caller's pop that started it is already counted: see walkSharedAsm's accounting).
-template <int M>
-__device__ __forceinline__ unsigned narrowSubtree(const uint4 *__restrict__ pf, const uint4 *__restrict__ tris, const int lane, const float (&org)[3][4], Quad &Q, int (&tid)[4],
-												   const Interval &iv, Counters &st, const int topw, const int signBits, const int oct, int &stkN, const int spBase) {
-	const int f0 = (int)(((unsigned)topw >> 20) & 63u), l0 = (int)((unsigned)topw >> 26);
-	const int qbase = f0;
-	const int myQuad = qbase + (lane >> 2);              // the quad this lane's ray belongs to (quads past l0: never live)
-	const int srcAddr = myQuad * 4;
-	float g[1], nid[3], nd[3], ndist;
-	int ntid = -1;
-#pragma unroll
-	for(int c = 0; c < 3; c++) { narrowGather<1>(Q.id[c], srcAddr, g); nid[c] = g[0]; narrowGather<1>(Q.d[c], srcAddr, g); nd[c] = g[0]; }
-	narrowGather<1>(Q.dist, srcAddr, g); ndist = g[0];
-	const int octMask[3] = {-(oct & 1), -((oct >> 1) & 1), -((oct >> 2) & 1)};
-	unsigned visits = 0;
-	int sp = spBase, cur = topw & 0xfffff, first = f0, last = l0;
-	for(;;) {
-		visits++;
-		const Node n = loadNode(pf, cur);                // record slot `cur`: 32 B at pf + cur * 32
-		const bool isLeaf = (n.sub & 0x80000000u) != 0;
-		// ---- BBox::Test, one ray per lane (the wide walk's operations: src/bounding_box.cpp:61-142) ----
-		float tn, tf;
-		if(M == M_COH) {
-			float pn[3], pfar[3];
-#pragma unroll
-			for(int k = 0; k < 3; k++) {
-				const int lo = __float_as_int(n.bmin[k]), hi = __float_as_int(n.bmax[k]);
-				const int sw = (lo ^ hi) & octMask[k];
-				pn[k] = __int_as_float(lo ^ sw) - org[k][0]; pfar[k] = __int_as_float(hi ^ sw) - org[k][0];
-			}
-			tn = vmax3(nid[0] * pn[0], nid[1] * pn[1], nid[2] * pn[2]);
-			tf = vmin3(nid[0] * pfar[0], nid[1] * pfar[1], nid[2] * pfar[2]);
-		} else {
-			float lo[3], hi[3];
-#pragma unroll
-			for(int k = 0; k < 3; k++) {
-				const float a = nid[k] * (n.bmin[k] - org[k][0]), b = nid[k] * (n.bmax[k] - org[k][0]);
-				lo[k] = vmin(a, b); hi[k] = vmax(a, b);
-			}
-			tn = vmax3(lo[0], lo[1], lo[2]);
-			tf = vmin3(hi[0], hi[1], hi[2]);
-		}
-		const float slack = vmin(tf, ndist) - vmax(tn, 0.0f);
-		const bool inRange = (unsigned)(myQuad - first) <= (unsigned)(last - first);
-		u64 m = __builtin_amdgcn_ballot_w64(inRange & (slack >= 0.0f));   // rays that pass
-		m |= m >> 1; m |= m >> 2; m &= 0x1111111111111111ull;              // quads with a passing ray, at bit 4 (q - qbase)
-		bool descend = false;
-		if(m != 0) {
-			first = qbase + (__builtin_ctzll(m) >> 2);
-			last = qbase + ((63 - __builtin_clzll(m)) >> 2);
-			if(!isLeaf) {
-				const int nearOff = (int)n.sub ^ ((n.aux & signBits) ? 32 : 0), farOff = nearOff ^ 32;
-				const int word = (int)(((unsigned)farOff >> 5) | ((unsigned)first << 20) | ((unsigned)last << 26));
-				asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(stkN) : "s"(word), "s"(sp) : "m0");
-				sp++;
-				cur = (int)((unsigned)nearOff >> 5);
-				descend = true;
-			} else {
-				// ---- the leaf, in place: packet-level cull with four lanes per triangle, survivors against this lane's ray ----
-				const int count = n.aux, firstTri = (int)((((unsigned)n.sub & 0x7fffffffu) - (1u << 25)) >> 6);
-				const int width = last - first + 1;
-				const bool live = (unsigned)(myQuad - first) <= (unsigned)(last - first);
-				st.leaves++; st.fetched += (unsigned)count;
-				for(int base = 0; base < count; base += 16) {
-					QuadTerms qt;
-					u64 keep = cullQuad<M>(tris, count - base < 16 ? count - base : 16, firstTri + base, lane, org, iv, qt);
-					while(keep) {
-						const int kb = __builtin_ctzll(keep);
-						keep &= keep - 1;
-						const float nx = xbar(kb * 4, qt.n), ny = xbar(kb * 4 + 4, qt.n), nz = xbar(kb * 4 + 8, qt.n);
-						const float ax = xbar(kb * 4, qt.t0v), ay = xbar(kb * 4 + 4, qt.t0v), az = xbar(kb * 4 + 8, qt.t0v);
-						const float bx = xbar(kb * 4, qt.t1v), by = xbar(kb * 4 + 4, qt.t1v), bz = xbar(kb * 4 + 8, qt.t1v);
-						const float tmul = xbar(kb * 4, qt.tmul);
-						if(live) { // src/triangle.cpp:44-60
-							const float det = nd[0] * nx + nd[1] * ny + nd[2] * nz;
-							const float v = nd[0] * ax + nd[1] * ay + nd[2] * az;
-							const float u = nd[0] * bx + nd[1] * by + nd[2] * bz;
-							const float duv = det - u - v;
-							const float uvmin = Min3<M>(u, v, duv), uvmax = Max3<M>(u, v, duv);
-							if((uvmax <= 0.0f) | (uvmin >= 0.0f)) {
-								const float dd = recipExact(det) * tmul;
-								if(dd < ndist && dd > 0.0f) { ndist = dd; ntid = firstTri + base + (kb >> 2); }
-							}
-						}
-						st.intersects += width;
-					}
-				}
-			}
-		}
-		if(descend) continue;
-		if(sp == spBase) break;
-		sp--;
-		const int w = __builtin_amdgcn_readlane(stkN, sp);
-		cur = w & 0xfffff; first = (int)(((unsigned)w >> 20) & 63u); last = (int)((unsigned)w >> 26);
-	}
-	// ---- back to the quad lanes (lanes outside [f0, l0] read garbage and keep their own values) ----
-	const int q = lane - f0;
-	const bool mine = (unsigned)q <= (unsigned)(l0 - f0);
-#pragma unroll
-	for(int l = 0; l < 4; l++) {
-		const int src = (q * 4 + l) * 4;
-		const float d2 = xbar(src, ndist);
-		const int nt = __builtin_amdgcn_ds_bpermute(src, ntid);
-		if(mine && nt >= 0) { Q.dist[l] = d2; tid[l] = nt; }
-	}
-	return visits;
-}
-
 // the node array a PACK instantiation of the hand-written walks is given: the prefetching loop's own copy of the tree
 #define SNAIL_PACK_NODES(A) (SNAIL_NODE_PREFETCH ? (A).pf : (A).nodes)
 template <bool SHADOW, bool COH, bool PACK, bool MASK, bool BARY, bool POSDIST>
@@ -1472,23 +1344,11 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /*
 			int sTopw;
 			if(COH) {
 				if(SHADOW) { SNAIL_DESCEND_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_ANY, "", SNAIL_COUNT, oct) }
-#if SNAIL_NARROW_SUBTREES
-#undef SNAIL_PF_NARROWCHK
-#define SNAIL_PF_NARROWCHK SNAIL_PF_NARROWCHK_ON
-#endif
 				else if(POSDIST) { SNAIL_DESCEND_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_POS, SNAIL_COUNT, "", oct) }
-#undef SNAIL_PF_NARROWCHK
-#define SNAIL_PF_NARROWCHK ""
 				else { SNAIL_DESCEND_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_ANY, SNAIL_COUNT, "", oct) }
 			} else {
 				if(SHADOW) { SNAIL_DESCEND_PF_PLAIN(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, "", SNAIL_COUNT); }
-#if SNAIL_NARROW_SUBTREES
-#undef SNAIL_PF_NARROWCHK
-#define SNAIL_PF_NARROWCHK SNAIL_PF_NARROWCHK_ON
-#endif
 				else if(POSDIST) { SNAIL_DESCEND_PF_PLAIN(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_POS, SNAIL_COUNT, ""); }
-#undef SNAIL_PF_NARROWCHK
-#define SNAIL_PF_NARROWCHK ""
 				else { SNAIL_DESCEND_PF_PLAIN(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, ""); }
 			}
 		} else if(PACK) { SNAIL_SHARED_VARIANTS(SNAIL_POP_1W, SNAIL_PUSH_1W) }
@@ -1496,13 +1356,6 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /*
 #undef SNAIL_SHARED_VARIANTS
 		if(leafSub == 0) break;
 		SNAIL_PRIO_BY_WORK(cnt);
-		if(SNAIL_NARROW_SUBTREES && PF && POSDIST && !SHADOW && leafSub == 1) {
-			// a popped entry with a range of <= 16 quads: its whole subtree with one ray per lane.  The pop is in `cnt` already; visits =
-			// 2 * pops - 1 holds for the chains the statement walks itself, so this chain's own visits are added less the one that formula
-			// books for its pop
-			st.iters += narrowSubtree<COH ? M_COH : M_FAST>(nodes, tris, lane, org, Q, tid, iv, st, leafAux, signBits, oct, stkN, sp) - 1u;
-			continue;
-		}
 		if(leafShared<MASK, SHADOW, COH ? M_COH : M_FAST, BARY>(tris, leafAux, (int)((unsigned)leafSub & 0x7fffffffu), size, lane, first, last, org, Q, mask4,
 																 tid, bu, bv, iv, st))
 			break;
