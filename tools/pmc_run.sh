@@ -18,5 +18,6 @@ run tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
 run sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SMEM SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU
 run grbm GRBM_GUI_ACTIVE GRBM_COUNT
+run lds SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS
 python tools/pmc_summary.py $OUT | tee $OUT/summary.txt
 find $OUT -name "*.csv" -size +200k -delete 2>/dev/null   # keep the merge-back small: the summary is what is kept
