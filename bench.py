@@ -90,7 +90,7 @@ def kernel_source_sha16() -> str:
     old instruction count."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("snail_hip.hip", "lbvh.inc", "render_host.inc"):
+    for f in ("snail_hip.hip", "lbvh.inc"):
         with open(os.path.join(ROOT, "snail_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

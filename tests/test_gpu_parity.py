@@ -725,6 +725,8 @@ def test_antialiased_tile_renderer(torch_mod, name, resx, resy, mode):
     sc2 = Scene(sc.bvh, 0)
     data2, _, tst2 = sc.render_tiles_host(cam, resx, resy, tiles, lights, flags, scenes=[sc, sc2])
     assert np.array_equal(data2, data) and np.array_equal(tst2, tst), (tst2, tst)
+    with pytest.raises(Exception, match="again"):
+        sc.render_tiles_host(cam, resx, resy, tiles, lights, flags, scenes=[sc, sc])      # one handle per share
     sc2.close()
     sc.close()
 
