@@ -10,12 +10,14 @@
 // src/bounding_box.cpp:61-142).  Those semantics decide which triangle wins an exact-t tie, so they are
 // kept exactly -- and they map onto a CDNA4 wavefront without any divergence:
 //   * control flow is wave-uniform: node index, stack pointer, first/last live in SGPRs;
-//   * a 32-B node record is ONE scalar load (s_load_dwordx8) through the scalar cache;
+//   * a 32-B node record is ONE scalar load (s_load_dwordx8) through the scalar cache, requested ahead of
+//     its use from a copy of the tree laid out for that (child pairs on one 64-B line, see SNAIL_PF_VISIT);
 //   * the traversal stack is a VGPR pair (lane i = stack slot i): pop = v_readlane, push = lane-predicated move;
 //   * "scan for the first/last quad with a surviving lane" is one __ballot + s_ff1/s_flbit;
-//   * per-leaf, lanes 0..count-1 each fetch one 64-B triangle (4 x dwordx4) and evaluate the
-//     packet-level Triangle::TestInterval cull and the shared-origin terms tvec0/tvec1/tmul for THEIR
-//     triangle in parallel; survivors are broadcast with ds_bpermute and intersected by all lanes.
+//   * per-leaf, the packet-level Triangle::TestInterval cull and the shared-origin terms tvec0/tvec1/tmul
+//     are computed with FOUR LANES PER TRIANGLE (one per vector component, the other components read from
+//     the quad neighbours through DPP); survivors are broadcast with ds_bpermute and intersected by all
+//     lanes -- or, under a narrow quad range, by the range's rays spread one or two per lane.
 // No MFMA: this is branchy slab / Moeller-Trumbore work.  No FMA contraction either: every mul/add is
 // rounded separately, in the reference's operand order (build with -ffp-contract=off), IEEE divide and
 // sqrt (Inv(x)=1/x, RSqrt(x)=1/sqrt(x): veclib's scalar definitions, veclib/vecbase.h:53-55).
