@@ -89,13 +89,15 @@ def _worker(rank, world, port, resx, resy, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("resx,resy", [(320, 192), (250, 130)])
-def test_two_rank_tile_gather_rebuilds_the_frame(resx, resy):
+@pytest.mark.parametrize("resx,resy,world", [(320, 192, 2), (250, 130, 2), (250, 130, 3)])
+def test_two_rank_tile_gather_rebuilds_the_frame(resx, resy, world):
+    """world_size 2 -- and 3 on a frame whose tiles do not divide evenly: the ranks' shards are padded to one size for the collective and
+    rank 0's scatter skips the pad entries."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, resx, resy, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, resx, resy, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
