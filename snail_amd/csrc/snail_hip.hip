@@ -1056,6 +1056,18 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 	"v_mul_f32 %[t1], %[iy" L "], %[pny]\n v_mul_f32 %[t4], %[iy" L "], %[pfy]\n v_min_f32 %[t0], %[t1], %[t4]\n v_max_f32 %[t4], %[t1], %[t4]\n" \
 	"v_mul_f32 %[t2], %[iz" L "], %[pnz]\n v_mul_f32 %[t5], %[iz" L "], %[pfz]\n v_min_f32 %[t1], %[t2], %[t5]\n v_max_f32 %[t5], %[t2], %[t5]\n" \
 	"v_max3_f32 %[t0], %[u0], %[t0], %[t1]\n v_min3_f32 %[t3], %[t3], %[t4], %[t5]\n"
+// shared origin with CAMERA-RELATIVE node records (SnailScene::relFor: bmin - o, bmax - o stored per node, once per origin): the plane
+// offsets of SNAIL_PRE_SHARED are the record's own words, multiplied straight out of the scalar registers -- six vector instructions
+// less per visit, and they were the head of the visit's dependency chain.  Same subtraction, same products: same bits.
+#define SNAIL_SLAB_COH_R(L, NX, FX, NY, FY, NZ, FZ)                                                                                         \
+	"v_mul_f32 %[t0], " NX ", %[ix" L "]\n v_mul_f32 %[t1], " NY ", %[iy" L "]\n v_mul_f32 %[t2], " NZ ", %[iz" L "]\n"                    \
+	"v_mul_f32 %[t3], " FX ", %[ix" L "]\n v_mul_f32 %[t4], " FY ", %[iy" L "]\n v_mul_f32 %[t5], " FZ ", %[iz" L "]\n"                    \
+	"v_max3_f32 %[t0], %[t0], %[t1], %[t2]\n v_min3_f32 %[t3], %[t3], %[t4], %[t5]\n"
+#define SNAIL_SLAB_FAST_R(L, NX, FX, NY, FY, NZ, FZ)                                                                                        \
+	"v_mul_f32 %[t0], " NX ", %[ix" L "]\n v_mul_f32 %[t3], " FX ", %[ix" L "]\n v_min_f32 %[u0], %[t0], %[t3]\n v_max_f32 %[t3], %[t0], %[t3]\n" \
+	"v_mul_f32 %[t1], " NY ", %[iy" L "]\n v_mul_f32 %[t4], " FY ", %[iy" L "]\n v_min_f32 %[t0], %[t1], %[t4]\n v_max_f32 %[t4], %[t1], %[t4]\n" \
+	"v_mul_f32 %[t2], " NZ ", %[iz" L "]\n v_mul_f32 %[t5], " FZ ", %[iz" L "]\n v_min_f32 %[t1], %[t2], %[t5]\n v_max_f32 %[t5], %[t2], %[t5]\n" \
+	"v_max3_f32 %[t0], %[u0], %[t0], %[t1]\n v_min3_f32 %[t3], %[t3], %[t4], %[t5]\n"
 // per-ray origins (mirrored / transparency packets): the plane offsets are per ray too
 #define SNAIL_SLABO_COH(L, NX, FX, NY, FY, NZ, FZ)                                                                                          \
 	"v_sub_f32 %[t0], " NX ", %[ox" L "]\n v_sub_f32 %[t1], " NY ", %[oy" L "]\n v_sub_f32 %[t2], " NZ ", %[oz" L "]\n"                    \
@@ -1179,12 +1191,18 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 // requested into the OTHER set: a descent is a jump to the other copy of the body, not a copy of eight registers.  Inside the
 // body EXEC = the lanes that survived the node (a lane that fails a box fails every box inside it -- each operation of the slab test
 // rounds monotonically -- so first / last come out as with the whole range); a pop rebuilds EXEC from the popped range.
+// SNAIL_PF_LEAFREQ: what a LEAF record's "near child" request fetches.  The loop's own copy of the tree holds the triangle records behind
+// the nodes: the leaf flag is cleared and the request is the leaf's first triangle record (ahead of the leaf code).  A camera-relative
+// node array (below) holds nodes only: the request becomes slot 0.
+#define SNAIL_PF_LEAFREQ_TRI " s_bitset0_b32 %[cur], 31\n"
+#define SNAIL_PF_LEAFREQ_SLOT0 " s_max_i32 %[cur], %[cur], 0\n"
+#define SNAIL_PF_LEAFREQ SNAIL_PF_LEAFREQ_TRI
 #define SNAIL_PF_VISIT(X, Y, OTHERSET, SUB, AUX, PRE, SLAB, TAIL, CNTVISIT, NX, FX, NY, FY, NZ, FZ)                                          \
 				 "L_visit" X "_%=:\n" CNTVISIT                                                                                              \
 				 " s_and_b32 %[cur], " AUX ", %[sign16]\n s_cselect_b32 %[cur], 32, 0\n" /* sign[axis] of lane 0 -> 32 or 0 */               \
 				 " s_xor_b32 %[cur], " SUB ", %[cur]\n" /* near child's byte offset (a leaf: its first triangle's, maybe + 32) */             \
 				 " s_xor_b32 %[fl], %[cur], 32\n" /* far child's: the other half of the pair's 64-B line */                                  \
-				 " s_bitset0_b32 %[cur], 31\n" /* a leaf's request fetches its first triangle record's line ahead of the leaf code */        \
+				 SNAIL_PF_LEAFREQ                                                                                                          \
 				 " s_load_dwordx8 " OTHERSET ", %[base], %[cur]\n"                                                                         \
 				 PRE(NX, FX, NY, FY, NZ, FZ)                                                                                               \
 				 SLAB("0", NX, FX, NY, FY, NZ, FZ) TAIL("0", "s0") SLAB("1", NX, FX, NY, FY, NZ, FZ) TAIL("1", "s1")                       \
@@ -1303,6 +1321,9 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 #ifndef SNAIL_NODE_PREFETCH
 #define SNAIL_NODE_PREFETCH 1 // 0 = the loop without record prefetch for one-word stacks too (A/B measurements)
 #endif
+#ifndef SNAIL_REL_NODES
+#define SNAIL_REL_NODES 1 // primary packets walk camera-relative node records (no plane offsets to compute per visit); 0 = the loop's plain copy
+#endif
 // the node array a PACK instantiation of the hand-written walks is given: the prefetching loop's own copy of the tree
 #define SNAIL_PACK_NODES(A) (SNAIL_NODE_PREFETCH ? (A).pf : (A).nodes)
 template <bool SHADOW, bool COH, bool PACK, bool MASK, bool BARY, bool POSDIST>
@@ -1346,11 +1367,27 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /*
 			int sTopw;
 			if(COH) {
 				if(SHADOW) { SNAIL_DESCEND_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_ANY, "", SNAIL_COUNT, oct) }
+#if SNAIL_REL_NODES
+#undef SNAIL_PF_LEAFREQ
+#define SNAIL_PF_LEAFREQ SNAIL_PF_LEAFREQ_SLOT0
+				else if(POSDIST) { SNAIL_DESCEND_PF_OCT(SNAIL_PRE_NONE, SNAIL_ORG_SHARED, SNAIL_SLAB_COH_R, SNAIL_TAIL_POS, SNAIL_COUNT, "", oct) }
+#undef SNAIL_PF_LEAFREQ
+#define SNAIL_PF_LEAFREQ SNAIL_PF_LEAFREQ_TRI
+#else
 				else if(POSDIST) { SNAIL_DESCEND_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_POS, SNAIL_COUNT, "", oct) }
+#endif
 				else { SNAIL_DESCEND_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_ANY, SNAIL_COUNT, "", oct) }
 			} else {
 				if(SHADOW) { SNAIL_DESCEND_PF_PLAIN(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, "", SNAIL_COUNT); }
+#if SNAIL_REL_NODES
+#undef SNAIL_PF_LEAFREQ
+#define SNAIL_PF_LEAFREQ SNAIL_PF_LEAFREQ_SLOT0
+				else if(POSDIST) { SNAIL_DESCEND_PF_PLAIN(SNAIL_PRE_NONE, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST_R, SNAIL_TAIL_POS, SNAIL_COUNT, ""); }
+#undef SNAIL_PF_LEAFREQ
+#define SNAIL_PF_LEAFREQ SNAIL_PF_LEAFREQ_TRI
+#else
 				else if(POSDIST) { SNAIL_DESCEND_PF_PLAIN(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_POS, SNAIL_COUNT, ""); }
+#endif
 				else { SNAIL_DESCEND_PF_PLAIN(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, ""); }
 			}
 		} else if(PACK) { SNAIL_SHARED_VARIANTS(SNAIL_POP_1W, SNAIL_PUSH_1W) }
@@ -1488,6 +1525,7 @@ struct PrimaryArgs {
 	int nFrames;
 	GenConst g[SNAIL_MAX_BATCH];
 	FrameOut out[SNAIL_MAX_BATCH];
+	const uint4 *rel[SNAIL_MAX_BATCH]; // per frame: the node records relative to that frame's camera position (SnailScene::relFor; used when `pack` is set)
 	int resx, resy, x0, y0, w, h; // rect (frame layout) ...
 	const int2 *packetXY;		  // ... or explicit packet list (packet-major layout)
 	int nPackets, pw, ph;		  // packet grid of the rect
@@ -1594,8 +1632,9 @@ __device__ __forceinline__ void primaryPacket(const PrimaryArgs &A, const int li
 		else walk<true, false, false, M_FAST, false, DEEP, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st);
 	} else if(A.pack && !DIAG) { // (the counting build walks with the plain loop: same visits, same tests -- and this compiler cannot place the
 		// record-prefetching loop's three record sets beside the extra counters: "illegal VGPR to SGPR copy")
-		if(mode == M_COH) walkSharedAsm<false, true, true, false, false, true>(SNAIL_PACK_NODES(A), A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, oct);
-		else walkSharedAsm<false, false, true, false, false, true>(SNAIL_PACK_NODES(A), A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, 0);
+		const uint4 *pn = (SNAIL_NODE_PREFETCH && SNAIL_REL_NODES) ? A.rel[fi] : SNAIL_PACK_NODES(A);   // this frame's camera-relative records
+		if(mode == M_COH) walkSharedAsm<false, true, true, false, false, true>(pn, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, oct);
+		else walkSharedAsm<false, false, true, false, false, true>(pn, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, 0);
 	} else if(mode == M_COH) walkSharedAsm<false, true, false, false, false, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, oct);
 	else walkSharedAsm<false, false, false, false, false, true>(A.nodes, A.tris, 64, lane, org, Q, 15u, tid, bu, bv, lds, st, 0);
 	// The epilogue reads its arguments (output planes, layout) through an opaque copy of the kernel-argument pointer: otherwise their loads
@@ -2571,6 +2610,20 @@ __global__ __launch_bounds__(256) void k_pf_encode(const uint4 *__restrict__ nod
 	pf[(size_t)(i + 1) * 2 + 1] = make_uint4(out[4], out[5], out[6], out[7]);
 }
 
+// slot i of the prefetching loop's copy -> slot i of a camera-relative array: bmin - o, bmax - o (the subtraction SNAIL_PRE_SHARED makes at
+// every visit, made once per node and origin), link words unchanged
+__global__ __launch_bounds__(256) void k_rel_nodes(const uint4 *__restrict__ pf, int nSlots, float ox, float oy, float oz, uint4 *__restrict__ rel) {
+	const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+	if(i >= nSlots) return;
+	const uint4 a = pf[(size_t)i * 2], b = pf[(size_t)i * 2 + 1];
+	const float o[3] = {ox, oy, oz};
+	const unsigned in[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
+	unsigned out[6];
+	for(int k = 0; k < 6; k++) out[k] = __float_as_uint(__uint_as_float(in[k]) - o[k % 3]);
+	rel[(size_t)i * 2] = make_uint4(out[0], out[1], out[2], out[3]);
+	rel[(size_t)i * 2 + 1] = make_uint4(out[4], out[5], b.z, b.w);
+}
+
 // ---- single-ray accounting walk: V_n, V_t per ray ----------------------------
 struct AccountArgs {
 	const uint4 *nodes, *tris;
@@ -2663,6 +2716,22 @@ struct SnailScene {
 	// [slot 0: unused][slot i + 1: node i, re-encoded for the record-prefetching loop (dev::pfEncode)] ... [triangle records at trisOff]
 	char *dPF = nullptr;
 	int trisOff = 0;
+	// camera-relative copies of the node slots (dev::k_rel_nodes), one per distinct origin, least-recently-used first out: a static or
+	// turning camera (and a light) costs one pass over the nodes EVER; a moving one costs one per new position
+	struct RelNodes {
+		float org[3] = {0, 0, 0};
+		uint4 *d = nullptr;
+		bool valid = false;
+		unsigned long long stamp = 0;
+		hipEvent_t filled = nullptr;
+		enum { kStreams = 8 };
+		hipStream_t usedOn[kStreams] = {};
+		hipEvent_t used[kStreams] = {};
+		int nUsed = 0;
+	};
+	enum { kRelSlots = 16 };
+	RelNodes rel[kRelSlots];
+	unsigned long long relClock = 0;
 	int pfOK = 0;     // the prefetching loop may walk this tree: nested, every child pair starts at an odd index, offsets fit (stackPack)
 	int fastOK = 0; // every triangle record finite and of sane magnitude (see file header)
 	int nestedOK = 1; // every child box lies inside its parent's (stackPack)
@@ -2764,6 +2833,50 @@ int stackPack(const SnailScene *s) {
 	return !off && (s->pfOK || (assumeNested && s->pfOKButNesting)) ? 1 : 0;
 }
 
+// The node slots relative to `org` for a launch on `stream` (stream-ordered: filled on this stream on a miss; a later user on another stream
+// waits for the fill; a slot that is recycled waits for its last users).  *which = the cache entry, for relUsed() after the consumer's launch.
+int relFor(SnailScene *s, const float org[3], hipStream_t stream, const uint4 **out, int *which) {
+	SnailScene::RelNodes *hit = nullptr, *victim = nullptr;
+	for(auto &e : s->rel) {
+		if(e.valid && memcmp(e.org, org, 12) == 0) { hit = &e; break; }
+		if(!victim || (!e.valid && victim->valid) || (e.valid == victim->valid && e.stamp < victim->stamp)) victim = &e;
+	}
+	if(hit) {
+		HIP_TRY(hipStreamWaitEvent(stream, hit->filled, 0));
+		hit->stamp = ++s->relClock;
+		*out = hit->d; *which = (int)(hit - s->rel);
+		return 0;
+	}
+	SnailScene::RelNodes &e = *victim;
+	const int nSlots = s->nNodes + 1;
+	if(!e.d) HIP_TRY(hipMalloc((void **)&e.d, (size_t)nSlots * 32));
+	if(!e.filled) HIP_TRY(hipEventCreateWithFlags(&e.filled, hipEventDisableTiming));
+	for(int k = 0; k < e.nUsed; k++) HIP_TRY(hipStreamWaitEvent(stream, e.used[k], 0));   // its last readers, on whatever streams
+	e.nUsed = 0;
+	hipLaunchKernelGGL(dev::k_rel_nodes, dim3((unsigned)((nSlots + 255) / 256)), dim3(256), 0, stream, (const uint4 *)s->dPF, nSlots, org[0], org[1], org[2], e.d);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(e.filled, stream));
+	memcpy(e.org, org, 12); e.valid = true; e.stamp = ++s->relClock;
+	*out = e.d; *which = (int)(&e - s->rel);
+	return 0;
+}
+// after the launch that reads entry `which` was enqueued on `stream`
+int relUsed(SnailScene *s, int which, hipStream_t stream) {
+	SnailScene::RelNodes &e = s->rel[which];
+	int k = 0;
+	while(k < e.nUsed && e.usedOn[k] != stream) k++;
+	if(k == e.nUsed) {
+		if(e.nUsed == SnailScene::RelNodes::kStreams) { // more streams than slots (never with the renderers of this repo): fold the oldest into this one
+			HIP_TRY(hipStreamWaitEvent(stream, e.used[0], 0));
+			k = 0;
+		} else e.nUsed++;
+		e.usedOn[k] = stream;
+		if(!e.used[k]) HIP_TRY(hipEventCreateWithFlags(&e.used[k], hipEventDisableTiming));
+	}
+	HIP_TRY(hipEventRecord(e.used[k], stream));
+	return 0;
+}
+
 int checkScene(const SnailScene *s, const char *fn) {
 	if(!s || !s->dNodes || !s->dPF || !s->dTris) { snail_set_error("%s: invalid scene handle", fn); return 1; }
 	return 0;
@@ -2795,6 +2908,12 @@ int launchPrimaryFrames(SnailScene *s, const FrameSet &FS, int resx, int resy, i
 	A.cost = dCost;
 	A.packetMajor = packetMajor ? 1 : 0;
 	A.pack = stackPack(s);
+	int relWhich[SNAIL_MAX_BATCH];
+	for(int k = 0; k < FS.n; k++) {
+		relWhich[k] = -1; A.rel[k] = nullptr;
+		if(A.pack && SNAIL_REL_NODES && SNAIL_NODE_PREFETCH)
+			if(int rc = relFor(s, FS.cam[k], stream, &A.rel[k], &relWhich[k])) return rc;   // cam[0..2] = the camera position
+	}
 	int blocks;
 	if(dPacketXY) {
 		if(nPackets <= 0) return 0;
@@ -2848,6 +2967,8 @@ int launchPrimaryFrames(SnailScene *s, const FrameSet &FS, int resx, int resy, i
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(s->deferDone[slot], stream));
 	s->deferUsed[slot] = true;
+	for(int k = 0; k < FS.n; k++)
+		if(relWhich[k] >= 0) { if(int rc = relUsed(s, relWhich[k], stream)) return rc; }
 	return 0;
 }
 
@@ -3138,6 +3259,11 @@ void snail_scene_destroy(SnailScene *s) {
 	freeTileJobs(s);
 	if(s->dNodes) (void)hipFree(s->dNodes);
 	if(s->dPF) (void)hipFree(s->dPF);   // (dTris points into it)
+	for(auto &e : s->rel) {
+		if(e.d) (void)hipFree(e.d);
+		if(e.filled) (void)hipEventDestroy(e.filled);
+		for(hipEvent_t ev : e.used) if(ev) (void)hipEventDestroy(ev);
+	}
 	if(s->dStats) (void)hipFree(s->dStats);
 	for(int k = 0; k < SnailScene::kDeferSlots; k++) if(s->dDefer[k]) (void)hipFree(s->dDefer[k]);
 	for(int k = 0; k < SnailScene::kDeferSlots; k++) if(s->shade[k].hitT) (void)hipFree(s->shade[k].hitT);
@@ -3631,6 +3757,10 @@ int snail_debug_anyorder(SnailScene *s, const float cam[13], int resx, int resy,
 	A.defer = s->dDefer[0];
 	hipStream_t st;
 	HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+	int relWhich = -1;
+	if(A.pack && SNAIL_REL_NODES && SNAIL_NODE_PREFETCH) {
+		if(int rc = relFor(s, cam, st, &A.rel[0], &relWhich)) return rc;
+	}
 	hipEvent_t e0, e1;
 	HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
 	HIP_TRY(hipDeviceSynchronize());
