@@ -1281,6 +1281,103 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 	default: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s88", "s85", "s89", "s86", "s79", "s76", "s80", "s77", "s81", "s78"); break; \
 	}
 
+// ---- the prefetching loop with the PUSH DEFERRED into the next visit (primary packets over camera-relative records) -----------------
+// A wave issues in order, so the scalar tail of a visit -- survivors -> first / last, pack the stack word, write the lane, bump the stack
+// pointer, wait, request the far child's record, branch: ~17 instructions that depend on each other -- is time in which the wave issues
+// nothing to the vector pipe (a fifth of a visit; the scalar and vector pipes run side by side only for DIFFERENT instructions of a wave's
+// stream).  Here a visit that descends only keeps (far child, first, last) and jumps; the NEXT visit -- entered through its "pending"
+// flavour -- does the push between its slab products, where the scalar instructions issue beside vector ones.  Two flavours per record set
+// (plain: after a pop; pending: after a descent); the far child's offset lives in a register of its own per set (A: %[fl], B: %[width]),
+// so that the next visit's own near / far computation does not overwrite the pending one.  Invariants are those of SNAIL_DESCEND_PF
+// (a register set never has two requests in flight; m0 = sp; topw = the top entry's word, T = its record).
+#define SNAIL_PF2_NEARFAR(SUB, AUX, FARX, OTHERSET)                                                                                          \
+				 " s_and_b32 %[cur], " AUX ", %[sign16]\n s_cselect_b32 %[cur], 32, 0\n"                                                       \
+				 " s_xor_b32 %[cur], " SUB ", %[cur]\n s_xor_b32 " FARX ", %[cur], 32\n"                                                       \
+				 " s_max_i32 %[cur], %[cur], 0\n" /* a leaf's "near child" is slot 0 */                                                     \
+				 " s_load_dwordx8 " OTHERSET ", %[base], %[cur]\n"
+#define SNAIL_PF2_TAIL(X, Y, SUB)                                                                                                           \
+				 " v_max_f32 %[s2], %[s2], %[s3]\n v_max3_f32 %[s0], %[s0], %[s1], %[s2]\n"                                                \
+				 " v_cmp_le_f32 vcc, 0, %[s0]\n"                                                                                            \
+				 " s_cbranch_vccz L_fail_%=\n"                                                                                             \
+				 " s_ff1_i32_b64 %[first], vcc\n s_flbit_i32_b64 %[last], vcc\n s_xor_b32 %[last], %[last], 63\n"                          \
+				 " s_mov_b64 exec, vcc\n"                                                                                                  \
+				 " s_cmp_lt_i32 " SUB ", 0\n s_cbranch_scc1 L_leaf" X "_%=\n"                                                               \
+				 " s_branch L_visit" Y "p_%=\n"
+#define SNAIL_PF2_VISIT(X, Y, OTHERSET, SUB, AUX, FARX, FARY, SLAB, NX, FX, NY, FY, NZ, FZ)                                                   \
+				 "L_visit" X "_%=:\n" /* plain: nothing pending */                                                                           \
+				 SNAIL_PF2_NEARFAR(SUB, AUX, FARX, OTHERSET)                                                                                 \
+				 SLAB("0", NX, FX, NY, FY, NZ, FZ) SNAIL_TAIL_POS("0", "s0") SLAB("1", NX, FX, NY, FY, NZ, FZ) SNAIL_TAIL_POS("1", "s1")     \
+				 SLAB("2", NX, FX, NY, FY, NZ, FZ) SNAIL_TAIL_POS("2", "s2") SLAB("3", NX, FX, NY, FY, NZ, FZ) SNAIL_TAIL_POS("3", "s3")     \
+				 SNAIL_PF2_TAIL(X, Y, SUB)                                                                                                   \
+				 "L_visit" X "p_%=:\n" /* pending: push (FARY, first, last) of the visit that descended here */                               \
+				 " s_waitcnt lgkmcnt(0)\n" /* this record has arrived; T's last request too */                                                \
+				 SNAIL_PF2_NEARFAR(SUB, AUX, FARX, OTHERSET)                                                                                 \
+				 " s_load_dwordx8 s[68:75], %[base], " FARY "\n" /* the pusher's far child is the new top entry */                             \
+				 SLAB("0", NX, FX, NY, FY, NZ, FZ) SNAIL_TAIL_POS("0", "s0")                                                                 \
+				 " s_lshl_b32 %[off], %[last], 6\n s_or_b32 %[off], %[off], %[first]\n s_lshl_b32 %[off], %[off], 20\n"                    \
+				 SLAB("1", NX, FX, NY, FY, NZ, FZ) SNAIL_TAIL_POS("1", "s1")                                                                 \
+				 " s_lshr_b32 %[topw], " FARY ", 5\n s_or_b32 %[topw], %[topw], %[off]\n"                                                    \
+				 " v_writelane_b32 %[stkN], %[topw], m0\n s_add_u32 m0, m0, 1\n"                                                            \
+				 SLAB("2", NX, FX, NY, FY, NZ, FZ) SNAIL_TAIL_POS("2", "s2") SLAB("3", NX, FX, NY, FY, NZ, FZ) SNAIL_TAIL_POS("3", "s3")     \
+				 SNAIL_PF2_TAIL(X, Y, SUB)                                                                                                   \
+				 "L_leaf" X "_%=:\n s_bfe_u32 %[leafSub], " SUB ", 0x190006\n s_sub_u32 %[leafSub], %[leafSub], 0x80000\n s_bitset1_b32 %[leafSub], 31\n" \
+				 " s_mov_b32 %[leafAux], " AUX "\n s_waitcnt lgkmcnt(0)\n s_branch L_end_%=\n"
+#define SNAIL_DESCEND_PF2(SLAB, NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)                                                  \
+	asm volatile(" s_mov_b32 m0, %[sp]\n"                                                                                                 \
+				 "L_entry_%=:\n"                                                                                                           \
+				 " s_cmp_eq_u32 m0, 0\n s_cbranch_scc1 L_done_%=\n"                                                                     \
+				 " s_sub_u32 %[off], m0, 1\n"                                                                                           \
+				 " v_readlane_b32 %[topw], %[stkN], %[off]\n"                                                                              \
+				 " s_and_b32 %[cur], %[topw], 0xfffff\n s_lshl_b32 %[off], %[cur], 5\n"                                                    \
+				 " s_load_dwordx8 s[68:75], %[base], %[off]\n"                                                                             \
+				 "L_pop_%=:\n" /* sp > 0, topw = the top entry, T = its record (requested) */                                              \
+				 " s_sub_u32 m0, m0, 1\n" SNAIL_COUNT                                                                                     \
+				 " s_bfe_u32 %[first], %[topw], 0x60014\n s_lshr_b32 %[last], %[topw], 26\n"                                               \
+				 " s_sub_u32 %[cur], %[last], %[first]\n"                                                                                  \
+				 " s_bfm_b64 exec, %[cur], %[first]\n s_bitset1_b64 exec, %[last]\n"                                                       \
+				 " s_cmp_eq_u32 m0, 0\n s_cbranch_scc1 L_last_%=\n"                                                                     \
+				 " s_sub_u32 %[off], m0, 1\n"                                                                                           \
+				 " v_readlane_b32 %[topw], %[stkN], %[off]\n"                                                                              \
+				 " s_and_b32 %[cur], %[topw], 0xfffff\n s_lshl_b32 %[off], %[cur], 5\n"                                                    \
+				 " s_waitcnt lgkmcnt(0)\n" SNAIL_A_FROM_T                                                                                  \
+				 " s_load_dwordx8 s[68:75], %[base], %[off]\n" /* the new top entry's record */                                            \
+				 " s_branch L_visitA_%=\n"                                                                                                 \
+				 "L_last_%=:\n"                                                                                                            \
+				 " s_waitcnt lgkmcnt(0)\n" SNAIL_A_FROM_T                                                                                  \
+				 SNAIL_PF2_VISIT("A", "B", "s[76:83]", "s90", "s91", "%[fl]", "%[width]", SLAB, NXA, FXA, NYA, FYA, NZA, FZA)                \
+				 SNAIL_PF2_VISIT("B", "A", "s[84:91]", "s82", "s83", "%[width]", "%[fl]", SLAB, NXB, FXB, NYB, FYB, NZB, FZB)                \
+				 "L_fail_%=:\n"                                                                                                            \
+				 " s_cmp_eq_u32 m0, 0\n s_cbranch_scc0 L_pop_%=\n"                                                                      \
+				 "L_done_%=:\n s_mov_b32 %[leafSub], 0\n s_mov_b32 %[leafAux], 0\n s_waitcnt lgkmcnt(0)\n"                                  \
+				 "L_end_%=:\n s_mov_b64 exec, -1\n s_mov_b32 %[sp], m0\n"                                                                                        \
+				 : [sp] "+s"(sp), [first] "+s"(first), [last] "+s"(last), [cnt] "+s"(cnt), [stkN] "+v"(stkN), [stkF] "+v"(stkF),           \
+				   [leafSub] "=&s"(leafSub), [leafAux] "=&s"(leafAux), [cur] "=&s"(sCur), [fl] "=&s"(sFl), [off] "=&s"(sOff),              \
+				   [width] "=&s"(sWidth), [topw] "=&s"(sTopw), [alive] "=&s"(sAlive), [pnx] "=&v"(vt[0]), [pny] "=&v"(vt[1]),              \
+				   [pnz] "=&v"(vt[2]), [pfx] "=&v"(vt[3]), [pfy] "=&v"(vt[4]), [pfz] "=&v"(vt[5]), [t0] "=&v"(vt[6]), [t1] "=&v"(vt[7]),   \
+				   [t2] "=&v"(vt[8]), [t3] "=&v"(vt[9]), [t4] "=&v"(vt[10]), [t5] "=&v"(vt[11]), [s0] "=&v"(vt[12]), [s1] "=&v"(vt[13]),   \
+				   [s2] "=&v"(vt[14]), [s3] "=&v"(vt[15]), [u0] "=&v"(vt[16])                                                              \
+				 : [base] "s"(nodeBase), [sign16] "s"(sign16), [lane] "v"(lane), SNAIL_ORG_SHARED(), [ix0] "v"(Q.id[0][0]), [ix1] "v"(Q.id[0][1]), [ix2] "v"(Q.id[0][2]), [ix3] "v"(Q.id[0][3]),        \
+				   [iy0] "v"(Q.id[1][0]), [iy1] "v"(Q.id[1][1]), [iy2] "v"(Q.id[1][2]), [iy3] "v"(Q.id[1][3]), [iz0] "v"(Q.id[2][0]),      \
+				   [iz1] "v"(Q.id[2][1]), [iz2] "v"(Q.id[2][2]), [iz3] "v"(Q.id[2][3]), [d0] "v"(Q.dist[0]), [d1] "v"(Q.dist[1]),          \
+				   [d2] "v"(Q.dist[2]), [d3] "v"(Q.dist[3])                                                                                \
+				 : "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", \
+				   "s88", "s89", "s90", "s91", "vcc", "scc", "m0");                                                                        \
+	asm volatile("" ::"s"(sp), "s"(first), "s"(last), "s"(cnt), "v"(stkN), "v"(stkF), "s"(leafSub), "s"(leafAux), "s"(sCur), "s"(sFl), "s"(sOff),    \
+				 "s"(sWidth), "s"(sTopw), "s"(sAlive), "v"(vt[0]), "v"(vt[1]), "v"(vt[2]), "v"(vt[3]), "v"(vt[4]), "v"(vt[5]), "v"(vt[6]), "v"(vt[7]), \
+				 "v"(vt[8]), "v"(vt[9]), "v"(vt[10]), "v"(vt[11]), "v"(vt[12]), "v"(vt[13]), "v"(vt[14]), "v"(vt[15]), "v"(vt[16]))
+#define SNAIL_DESCEND_PF2_PLAIN(SLAB) SNAIL_DESCEND_PF2(SLAB, "s84", "s87", "s85", "s88", "s86", "s89", "s76", "s79", "s77", "s80", "s78", "s81")
+#define SNAIL_DESCEND_PF2_OCT(SLAB, OCT)                                                                                                    \
+	switch(OCT) {                                                                                                                          \
+	case 0: SNAIL_DESCEND_PF2(SLAB, "s84", "s87", "s85", "s88", "s86", "s89", "s76", "s79", "s77", "s80", "s78", "s81"); break;            \
+	case 1: SNAIL_DESCEND_PF2(SLAB, "s87", "s84", "s85", "s88", "s86", "s89", "s79", "s76", "s77", "s80", "s78", "s81"); break;            \
+	case 2: SNAIL_DESCEND_PF2(SLAB, "s84", "s87", "s88", "s85", "s86", "s89", "s76", "s79", "s80", "s77", "s78", "s81"); break;            \
+	case 3: SNAIL_DESCEND_PF2(SLAB, "s87", "s84", "s88", "s85", "s86", "s89", "s79", "s76", "s80", "s77", "s78", "s81"); break;            \
+	case 4: SNAIL_DESCEND_PF2(SLAB, "s84", "s87", "s85", "s88", "s89", "s86", "s76", "s79", "s77", "s80", "s81", "s78"); break;            \
+	case 5: SNAIL_DESCEND_PF2(SLAB, "s87", "s84", "s85", "s88", "s89", "s86", "s79", "s76", "s77", "s80", "s81", "s78"); break;            \
+	case 6: SNAIL_DESCEND_PF2(SLAB, "s84", "s87", "s88", "s85", "s89", "s86", "s76", "s79", "s80", "s77", "s81", "s78"); break;            \
+	default: SNAIL_DESCEND_PF2(SLAB, "s87", "s84", "s88", "s85", "s89", "s86", "s79", "s76", "s80", "s77", "s81", "s78"); break;           \
+	}
+
 // near/far plane registers by sign octant (bit k set = idir negative on axis k: near plane = bmax[k]); s[84:86] = bmin, s[87:89] = bmax
 #define SNAIL_DESCEND_OCT(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, OCT) SNAIL_DESCEND_OCT_S(SNAIL_POP_2W, SNAIL_PUSH_2W, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, OCT)
 #define SNAIL_DESCEND_OCT_S(POP, PUSH, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, OCT)                                                                               \
@@ -1320,6 +1417,9 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 // wave-uniform switch at every (re-)entry, i.e. once per leaf; the leaf code exists once.
 #ifndef SNAIL_NODE_PREFETCH
 #define SNAIL_NODE_PREFETCH 1 // 0 = the loop without record prefetch for one-word stacks too (A/B measurements)
+#endif
+#ifndef SNAIL_DEFER_PUSH
+#define SNAIL_DEFER_PUSH 1 // primary packets over camera-relative records: the push of a descent is done inside the next visit (SNAIL_DESCEND_PF2)
 #endif
 #ifndef SNAIL_REL_NODES
 #define SNAIL_REL_NODES 1 // primary packets walk camera-relative node records (no plane offsets to compute per visit); 0 = the loop's plain copy
@@ -1370,7 +1470,11 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /*
 #if SNAIL_REL_NODES
 #undef SNAIL_PF_LEAFREQ
 #define SNAIL_PF_LEAFREQ SNAIL_PF_LEAFREQ_SLOT0
+#if SNAIL_DEFER_PUSH
+				else if(POSDIST) { SNAIL_DESCEND_PF2_OCT(SNAIL_SLAB_COH_R, oct) }
+#else
 				else if(POSDIST) { SNAIL_DESCEND_PF_OCT(SNAIL_PRE_NONE, SNAIL_ORG_SHARED, SNAIL_SLAB_COH_R, SNAIL_TAIL_POS, SNAIL_COUNT, "", oct) }
+#endif
 #undef SNAIL_PF_LEAFREQ
 #define SNAIL_PF_LEAFREQ SNAIL_PF_LEAFREQ_TRI
 #else
@@ -1382,7 +1486,11 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /*
 #if SNAIL_REL_NODES
 #undef SNAIL_PF_LEAFREQ
 #define SNAIL_PF_LEAFREQ SNAIL_PF_LEAFREQ_SLOT0
+#if SNAIL_DEFER_PUSH
+				else if(POSDIST) { SNAIL_DESCEND_PF2_PLAIN(SNAIL_SLAB_FAST_R); }
+#else
 				else if(POSDIST) { SNAIL_DESCEND_PF_PLAIN(SNAIL_PRE_NONE, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST_R, SNAIL_TAIL_POS, SNAIL_COUNT, ""); }
+#endif
 #undef SNAIL_PF_LEAFREQ
 #define SNAIL_PF_LEAFREQ SNAIL_PF_LEAFREQ_TRI
 #else
