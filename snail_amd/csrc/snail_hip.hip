@@ -1285,42 +1285,44 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 // A wave issues in order, so the scalar tail of a visit -- survivors -> first / last, pack the stack word, write the lane, bump the stack
 // pointer, wait, request the far child's record, branch: ~17 instructions that depend on each other -- is time in which the wave issues
 // nothing to the vector pipe (a fifth of a visit; the scalar and vector pipes run side by side only for DIFFERENT instructions of a wave's
-// stream).  Here a visit that descends only keeps (far child, first, last) and jumps; the NEXT visit -- entered through its "pending"
-// flavour -- does the push between its slab products, where the scalar instructions issue beside vector ones.  Two flavours per record set
-// (plain: after a pop; pending: after a descent); the far child's offset lives in a register of its own per set (A: %[fl], B: %[width]),
-// so that the next visit's own near / far computation does not overwrite the pending one.  Invariants are those of SNAIL_DESCEND_PF
+// stream).  Here a visit that descends only sets EXEC to its survivors and falls (or jumps) into the NEXT visit's "pending" copy, which does
+// the push -- first / last out of EXEC, the stack word, the lane write, the far child's record request -- and its own near / far child
+// computation BETWEEN its slab products, where scalar instructions issue beside vector ones; a pop likewise leaves the fetch of the new
+// top entry's word and record to the popped node's visit.  Three copies of the visit: after a pop (record set A), pending in B, pending
+// in A; the far child's offset lives in a register of its own per set (A: %[fl], B: %[width]),
+// so that a visit's own near / far computation does not overwrite the pending one.  Invariants are those of SNAIL_DESCEND_PF
 // (a register set never has two requests in flight; m0 = sp; topw = the top entry's word, T = its record).
 #define SNAIL_PF2_NEARFAR(SUB, AUX, FARX, OTHERSET)                                                                                          \
 				 " s_and_b32 %[cur], " AUX ", %[sign16]\n s_cselect_b32 %[cur], 32, 0\n"                                                       \
 				 " s_xor_b32 %[cur], " SUB ", %[cur]\n s_xor_b32 " FARX ", %[cur], 32\n"                                                       \
 				 " s_max_i32 %[cur], %[cur], 0\n" /* a leaf's "near child" is slot 0 */                                                     \
 				 " s_load_dwordx8 " OTHERSET ", %[base], %[cur]\n"
-#define SNAIL_PF2_TAIL(X, Y, SUB)                                                                                                           \
+// the end of a visit: EXEC <- the survivors; first / last are taken from EXEC where they are needed (the next visit's push, or the leaf)
+#define SNAIL_PF2_TAIL(X, SUB)                                                                                                              \
 				 " v_max_f32 %[s2], %[s2], %[s3]\n v_max3_f32 %[s0], %[s0], %[s1], %[s2]\n"                                                \
 				 " v_cmp_le_f32 vcc, 0, %[s0]\n"                                                                                            \
 				 " s_cbranch_vccz L_fail_%=\n"                                                                                             \
-				 " s_ff1_i32_b64 %[first], vcc\n s_flbit_i32_b64 %[last], vcc\n s_xor_b32 %[last], %[last], 63\n"                          \
 				 " s_mov_b64 exec, vcc\n"                                                                                                  \
-				 " s_cmp_lt_i32 " SUB ", 0\n s_cbranch_scc1 L_leaf" X "_%=\n"                                                               \
-				 " s_branch L_visit" Y "p_%=\n"
-#define SNAIL_PF2_VISIT(X, Y, OTHERSET, SUB, AUX, FARX, FARY, SLAB, NX, FX, NY, FY, NZ, FZ)                                                   \
-				 "L_visit" X "_%=:\n" /* plain: nothing pending */                                                                           \
-				 SNAIL_PF2_NEARFAR(SUB, AUX, FARX, OTHERSET)                                                                                 \
-				 SLAB("0", NX, FX, NY, FY, NZ, FZ) SNAIL_TAIL_POS("0", "s0") SLAB("1", NX, FX, NY, FY, NZ, FZ) SNAIL_TAIL_POS("1", "s1")     \
-				 SLAB("2", NX, FX, NY, FY, NZ, FZ) SNAIL_TAIL_POS("2", "s2") SLAB("3", NX, FX, NY, FY, NZ, FZ) SNAIL_TAIL_POS("3", "s3")     \
-				 SNAIL_PF2_TAIL(X, Y, SUB)                                                                                                   \
-				 "L_visit" X "p_%=:\n" /* pending: push (FARY, first, last) of the visit that descended here */                               \
+				 " s_cmp_lt_i32 " SUB ", 0\n s_cbranch_scc1 L_leaf" X "_%=\n"
+#define SNAIL_PF2_FIRSTLAST " s_ff1_i32_b64 %[first], exec\n s_flbit_i32_b64 %[last], exec\n s_xor_b32 %[last], %[last], 63\n"
+// a visit entered from a descent: the push of (FARY, survivors' first / last) happens here, between the slab products
+#define SNAIL_PF2_PENDING(X, OTHERSET, SUB, AUX, FARX, FARY, SLAB, NX, FX, NY, FY, NZ, FZ)                                                   \
+				 "L_visit" X "p_%=:\n"                                                                                                      \
 				 " s_waitcnt lgkmcnt(0)\n" /* this record has arrived; T's last request too */                                                \
-				 SNAIL_PF2_NEARFAR(SUB, AUX, FARX, OTHERSET)                                                                                 \
 				 " s_load_dwordx8 s[68:75], %[base], " FARY "\n" /* the pusher's far child is the new top entry */                             \
 				 SLAB("0", NX, FX, NY, FY, NZ, FZ) SNAIL_TAIL_POS("0", "s0")                                                                 \
-				 " s_lshl_b32 %[off], %[last], 6\n s_or_b32 %[off], %[off], %[first]\n s_lshl_b32 %[off], %[off], 20\n"                    \
+				 SNAIL_PF2_NEARFAR(SUB, AUX, FARX, OTHERSET)                                                                                 \
 				 SLAB("1", NX, FX, NY, FY, NZ, FZ) SNAIL_TAIL_POS("1", "s1")                                                                 \
+				 SNAIL_PF2_FIRSTLAST /* of the pusher: EXEC is still its survivor set */                                                     \
+				 " s_lshl_b32 %[off], %[last], 6\n s_or_b32 %[off], %[off], %[first]\n s_lshl_b32 %[off], %[off], 20\n"                    \
+				 SLAB("2", NX, FX, NY, FY, NZ, FZ) SNAIL_TAIL_POS("2", "s2")                                                                 \
 				 " s_lshr_b32 %[topw], " FARY ", 5\n s_or_b32 %[topw], %[topw], %[off]\n"                                                    \
 				 " v_writelane_b32 %[stkN], %[topw], m0\n s_add_u32 m0, m0, 1\n"                                                            \
-				 SLAB("2", NX, FX, NY, FY, NZ, FZ) SNAIL_TAIL_POS("2", "s2") SLAB("3", NX, FX, NY, FY, NZ, FZ) SNAIL_TAIL_POS("3", "s3")     \
-				 SNAIL_PF2_TAIL(X, Y, SUB)                                                                                                   \
-				 "L_leaf" X "_%=:\n s_bfe_u32 %[leafSub], " SUB ", 0x190006\n s_sub_u32 %[leafSub], %[leafSub], 0x80000\n s_bitset1_b32 %[leafSub], 31\n" \
+				 SLAB("3", NX, FX, NY, FY, NZ, FZ) SNAIL_TAIL_POS("3", "s3")                                                                 \
+				 SNAIL_PF2_TAIL(X, SUB)
+#define SNAIL_PF2_LEAF(X, SUB, AUX)                                                                                                         \
+				 "L_leaf" X "_%=:\n" SNAIL_PF2_FIRSTLAST                                                                                    \
+				 " s_bfe_u32 %[leafSub], " SUB ", 0x190006\n s_sub_u32 %[leafSub], %[leafSub], 0x80000\n s_bitset1_b32 %[leafSub], 31\n"   \
 				 " s_mov_b32 %[leafAux], " AUX "\n s_waitcnt lgkmcnt(0)\n s_branch L_end_%=\n"
 #define SNAIL_DESCEND_PF2(SLAB, NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)                                                  \
 	asm volatile(" s_mov_b32 m0, %[sp]\n"                                                                                                 \
@@ -1335,17 +1337,23 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 " s_bfe_u32 %[first], %[topw], 0x60014\n s_lshr_b32 %[last], %[topw], 26\n"                                               \
 				 " s_sub_u32 %[cur], %[last], %[first]\n"                                                                                  \
 				 " s_bfm_b64 exec, %[cur], %[first]\n s_bitset1_b64 exec, %[last]\n"                                                       \
-				 " s_cmp_eq_u32 m0, 0\n s_cbranch_scc1 L_last_%=\n"                                                                     \
-				 " s_sub_u32 %[off], m0, 1\n"                                                                                           \
+				 " s_waitcnt lgkmcnt(0)\n" SNAIL_A_FROM_T                                                                                  \
+				 /* the popped node's visit (record set A); the NEW top entry's word and record are fetched inside it */                  \
+				 " s_sub_u32 %[off], m0, 1\n s_max_i32 %[off], %[off], 0\n" /* (an empty stack re-reads entry 0: harmless, never used) */  \
 				 " v_readlane_b32 %[topw], %[stkN], %[off]\n"                                                                              \
+				 SLAB("0", NXA, FXA, NYA, FYA, NZA, FZA) SNAIL_TAIL_POS("0", "s0")                                                          \
 				 " s_and_b32 %[cur], %[topw], 0xfffff\n s_lshl_b32 %[off], %[cur], 5\n"                                                    \
-				 " s_waitcnt lgkmcnt(0)\n" SNAIL_A_FROM_T                                                                                  \
-				 " s_load_dwordx8 s[68:75], %[base], %[off]\n" /* the new top entry's record */                                            \
-				 " s_branch L_visitA_%=\n"                                                                                                 \
-				 "L_last_%=:\n"                                                                                                            \
-				 " s_waitcnt lgkmcnt(0)\n" SNAIL_A_FROM_T                                                                                  \
-				 SNAIL_PF2_VISIT("A", "B", "s[76:83]", "s90", "s91", "%[fl]", "%[width]", SLAB, NXA, FXA, NYA, FYA, NZA, FZA)                \
-				 SNAIL_PF2_VISIT("B", "A", "s[84:91]", "s82", "s83", "%[width]", "%[fl]", SLAB, NXB, FXB, NYB, FYB, NZB, FZB)                \
+				 " s_load_dwordx8 s[68:75], %[base], %[off]\n"                                                                             \
+				 SLAB("1", NXA, FXA, NYA, FYA, NZA, FZA) SNAIL_TAIL_POS("1", "s1")                                                          \
+				 SNAIL_PF2_NEARFAR("s90", "s91", "%[fl]", "s[76:83]")                                                                       \
+				 SLAB("2", NXA, FXA, NYA, FYA, NZA, FZA) SNAIL_TAIL_POS("2", "s2") SLAB("3", NXA, FXA, NYA, FYA, NZA, FZA) SNAIL_TAIL_POS("3", "s3") \
+				 SNAIL_PF2_TAIL("A", "s90")                                                                                                 \
+				 /* falls through: A descends into B, its push pending */                                                                   \
+				 SNAIL_PF2_PENDING("B", "s[84:91]", "s82", "s83", "%[width]", "%[fl]", SLAB, NXB, FXB, NYB, FYB, NZB, FZB)                   \
+				 /* falls through: B descends into A, its push pending */                                                                   \
+				 SNAIL_PF2_PENDING("A", "s[76:83]", "s90", "s91", "%[fl]", "%[width]", SLAB, NXA, FXA, NYA, FYA, NZA, FZA)                   \
+				 " s_branch L_visitBp_%=\n"                                                                                                \
+				 SNAIL_PF2_LEAF("A", "s90", "s91") SNAIL_PF2_LEAF("B", "s82", "s83")                                                       \
 				 "L_fail_%=:\n"                                                                                                            \
 				 " s_cmp_eq_u32 m0, 0\n s_cbranch_scc0 L_pop_%=\n"                                                                      \
 				 "L_done_%=:\n s_mov_b32 %[leafSub], 0\n s_mov_b32 %[leafAux], 0\n s_waitcnt lgkmcnt(0)\n"                                  \
