@@ -1298,12 +1298,14 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 " s_max_i32 %[cur], %[cur], 0\n" /* a leaf's "near child" is slot 0 */                                                     \
 				 " s_load_dwordx8 " OTHERSET ", %[base], %[cur]\n"
 // the end of a visit: EXEC <- the survivors; first / last are taken from EXEC where they are needed (the next visit's push, or the leaf)
-#define SNAIL_PF2_TAIL(X, SUB)                                                                                                              \
+#define SNAIL_PF2_TAIL(X, SUB) /* SCC = "this node is a leaf", set by SNAIL_PF2_ISLEAF after the visit's last other scalar instruction */ \
 				 " v_max_f32 %[s2], %[s2], %[s3]\n v_max3_f32 %[s0], %[s0], %[s1], %[s2]\n"                                                \
-				 " v_cmp_le_f32 vcc, 0, %[s0]\n"                                                                                            \
-				 " s_cbranch_vccz L_fail_%=\n"                                                                                             \
-				 " s_mov_b64 exec, vcc\n"                                                                                                  \
-				 " s_cmp_lt_i32 " SUB ", 0\n s_cbranch_scc1 L_leaf" X "_%=\n"
+				 " v_cmpx_le_f32 vcc, 0, %[s0]\n"                                                                                           \
+				 " s_cbranch_execz L_fail_%=\n"                                                                                            \
+				 " s_cbranch_scc1 L_leaf" X "_%=\n"
+#define SNAIL_PF2_ISLEAF(SUB) " s_cmp_lt_i32 " SUB ", 0\n"
+// the lane range of a stack word as an EXEC mask, kept for the top entry in %[alive] so that a pop only moves it
+#define SNAIL_PF2_ALIVE " s_sub_u32 %[cur], %[last], %[first]\n s_bfm_b64 %[alive], %[cur], %[first]\n s_bitset1_b64 %[alive], %[last]\n"
 #define SNAIL_PF2_FIRSTLAST " s_ff1_i32_b64 %[first], exec\n s_flbit_i32_b64 %[last], exec\n s_xor_b32 %[last], %[last], 63\n"
 // a visit entered from a descent: the push of (FARY, survivors' first / last) happens here, between the slab products
 #define SNAIL_PF2_PENDING(X, OTHERSET, SUB, AUX, FARX, FARY, SLAB, NX, FX, NY, FY, NZ, FZ)                                                   \
@@ -1315,9 +1317,10 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 SLAB("1", NX, FX, NY, FY, NZ, FZ) SNAIL_TAIL_POS("1", "s1")                                                                 \
 				 SNAIL_PF2_FIRSTLAST /* of the pusher: EXEC is still its survivor set */                                                     \
 				 " s_lshl_b32 %[off], %[last], 6\n s_or_b32 %[off], %[off], %[first]\n s_lshl_b32 %[off], %[off], 20\n"                    \
+				 SNAIL_PF2_ALIVE                                                                                                            \
 				 SLAB("2", NX, FX, NY, FY, NZ, FZ) SNAIL_TAIL_POS("2", "s2")                                                                 \
 				 " s_lshr_b32 %[topw], " FARY ", 5\n s_or_b32 %[topw], %[topw], %[off]\n"                                                    \
-				 " v_writelane_b32 %[stkN], %[topw], m0\n s_add_u32 m0, m0, 1\n"                                                            \
+				 " v_writelane_b32 %[stkN], %[topw], m0\n s_add_u32 m0, m0, 1\n" SNAIL_PF2_ISLEAF(SUB)                                       \
 				 SLAB("3", NX, FX, NY, FY, NZ, FZ) SNAIL_TAIL_POS("3", "s3")                                                                 \
 				 SNAIL_PF2_TAIL(X, SUB)
 #define SNAIL_PF2_LEAF(X, SUB, AUX)                                                                                                         \
@@ -1332,11 +1335,10 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 " v_readlane_b32 %[topw], %[stkN], %[off]\n"                                                                              \
 				 " s_and_b32 %[cur], %[topw], 0xfffff\n s_lshl_b32 %[off], %[cur], 5\n"                                                    \
 				 " s_load_dwordx8 s[68:75], %[base], %[off]\n"                                                                             \
-				 "L_pop_%=:\n" /* sp > 0, topw = the top entry, T = its record (requested) */                                              \
+				 " s_bfe_u32 %[first], %[topw], 0x60014\n s_lshr_b32 %[last], %[topw], 26\n" SNAIL_PF2_ALIVE                               \
+				 "L_pop_%=:\n" /* sp > 0, topw = the top entry, alive = its lanes, T = its record (requested) */                            \
 				 " s_sub_u32 m0, m0, 1\n" SNAIL_COUNT                                                                                     \
-				 " s_bfe_u32 %[first], %[topw], 0x60014\n s_lshr_b32 %[last], %[topw], 26\n"                                               \
-				 " s_sub_u32 %[cur], %[last], %[first]\n"                                                                                  \
-				 " s_bfm_b64 exec, %[cur], %[first]\n s_bitset1_b64 exec, %[last]\n"                                                       \
+				 " s_mov_b64 exec, %[alive]\n"                                                                                             \
 				 " s_waitcnt lgkmcnt(0)\n" SNAIL_A_FROM_T                                                                                  \
 				 /* the popped node's visit (record set A); the NEW top entry's word and record are fetched inside it */                  \
 				 " s_sub_u32 %[off], m0, 1\n s_max_i32 %[off], %[off], 0\n" /* (an empty stack re-reads entry 0: harmless, never used) */  \
@@ -1346,7 +1348,9 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 " s_load_dwordx8 s[68:75], %[base], %[off]\n"                                                                             \
 				 SLAB("1", NXA, FXA, NYA, FYA, NZA, FZA) SNAIL_TAIL_POS("1", "s1")                                                          \
 				 SNAIL_PF2_NEARFAR("s90", "s91", "%[fl]", "s[76:83]")                                                                       \
-				 SLAB("2", NXA, FXA, NYA, FYA, NZA, FZA) SNAIL_TAIL_POS("2", "s2") SLAB("3", NXA, FXA, NYA, FYA, NZA, FZA) SNAIL_TAIL_POS("3", "s3") \
+				 SLAB("2", NXA, FXA, NYA, FYA, NZA, FZA) SNAIL_TAIL_POS("2", "s2")                                                          \
+				 " s_bfe_u32 %[first], %[topw], 0x60014\n s_lshr_b32 %[last], %[topw], 26\n" SNAIL_PF2_ALIVE SNAIL_PF2_ISLEAF("s90")        \
+				 SLAB("3", NXA, FXA, NYA, FYA, NZA, FZA) SNAIL_TAIL_POS("3", "s3")                                                          \
 				 SNAIL_PF2_TAIL("A", "s90")                                                                                                 \
 				 /* falls through: A descends into B, its push pending */                                                                   \
 				 SNAIL_PF2_PENDING("B", "s[84:91]", "s82", "s83", "%[width]", "%[fl]", SLAB, NXB, FXB, NYB, FYB, NZB, FZB)                   \
