@@ -1196,13 +1196,12 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 // node array (below) holds nodes only: the request becomes slot 0.
 #define SNAIL_PF_LEAFREQ_TRI " s_bitset0_b32 %[cur], 31\n"
 #define SNAIL_PF_LEAFREQ_SLOT0 " s_max_i32 %[cur], %[cur], 0\n"
-#define SNAIL_PF_LEAFREQ SNAIL_PF_LEAFREQ_TRI
-#define SNAIL_PF_VISIT(X, Y, OTHERSET, SUB, AUX, PRE, SLAB, TAIL, CNTVISIT, NX, FX, NY, FY, NZ, FZ)                                          \
+#define SNAIL_PF_VISIT(X, Y, OTHERSET, SUB, AUX, PRE, SLAB, TAIL, CNTVISIT, LEAFREQ, NX, FX, NY, FY, NZ, FZ)                                          \
 				 "L_visit" X "_%=:\n" CNTVISIT                                                                                              \
 				 " s_and_b32 %[cur], " AUX ", %[sign16]\n s_cselect_b32 %[cur], 32, 0\n" /* sign[axis] of lane 0 -> 32 or 0 */               \
 				 " s_xor_b32 %[cur], " SUB ", %[cur]\n" /* near child's byte offset (a leaf: its first triangle's, maybe + 32) */             \
 				 " s_xor_b32 %[fl], %[cur], 32\n" /* far child's: the other half of the pair's 64-B line */                                  \
-				 SNAIL_PF_LEAFREQ                                                                                                          \
+				 LEAFREQ                                                                                                                   \
 				 " s_load_dwordx8 " OTHERSET ", %[base], %[cur]\n"                                                                         \
 				 PRE(NX, FX, NY, FY, NZ, FZ)                                                                                               \
 				 SLAB("0", NX, FX, NY, FY, NZ, FZ) TAIL("0", "s0") SLAB("1", NX, FX, NY, FY, NZ, FZ) TAIL("1", "s1")                       \
@@ -1224,7 +1223,7 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 "L_leaf" X "_%=:\n s_bfe_u32 %[leafSub], " SUB ", 0x190006\n s_sub_u32 %[leafSub], %[leafSub], 0x80000\n s_bitset1_b32 %[leafSub], 31\n" /* 0x80000000 | first triangle: (offset - 2^25) / 64 */ \
 				 " s_mov_b32 %[leafAux], " AUX "\n s_waitcnt lgkmcnt(0)\n s_branch L_end_%=\n"
 // set A = s[84:91] (planes NXA.., sub s90, aux s91), set B = s[76:83] (planes NXB.., sub s82, aux s83)
-#define SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)                 \
+#define SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)                 \
 	asm volatile(" s_mov_b32 m0, %[sp]\n"                                                                                                 \
 				 "L_entry_%=:\n"                                                                                                           \
 				 " s_cmp_eq_u32 m0, 0\n s_cbranch_scc1 L_done_%=\n"                                                                     \
@@ -1246,8 +1245,8 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 " s_branch L_visitA_%=\n"                                                                                                 \
 				 "L_last_%=:\n"                                                                                                            \
 				 " s_waitcnt lgkmcnt(0)\n" SNAIL_A_FROM_T                                                                                  \
-				 SNAIL_PF_VISIT("A", "B", "s[76:83]", "s90", "s91", PRE, SLAB, TAIL, CNTVISIT, NXA, FXA, NYA, FYA, NZA, FZA)                \
-				 SNAIL_PF_VISIT("B", "A", "s[84:91]", "s82", "s83", PRE, SLAB, TAIL, CNTVISIT, NXB, FXB, NYB, FYB, NZB, FZB)                \
+				 SNAIL_PF_VISIT("A", "B", "s[76:83]", "s90", "s91", PRE, SLAB, TAIL, CNTVISIT, LEAFREQ, NXA, FXA, NYA, FYA, NZA, FZA)                \
+				 SNAIL_PF_VISIT("B", "A", "s[84:91]", "s82", "s83", PRE, SLAB, TAIL, CNTVISIT, LEAFREQ, NXB, FXB, NYB, FYB, NZB, FZB)                \
 				 "L_fail_%=:\n"                                                                                                            \
 				 " s_cmp_eq_u32 m0, 0\n s_cbranch_scc0 L_pop_%=\n"                                                                      \
 				 "L_done_%=:\n s_mov_b32 %[leafSub], 0\n s_mov_b32 %[leafAux], 0\n s_waitcnt lgkmcnt(0)\n"                                  \
@@ -1267,18 +1266,18 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 	asm volatile("" ::"s"(sp), "s"(first), "s"(last), "s"(cnt), "v"(stkN), "v"(stkF), "s"(leafSub), "s"(leafAux), "s"(sCur), "s"(sFl), "s"(sOff),    \
 				 "s"(sWidth), "s"(sTopw), "s"(sAlive), "v"(vt[0]), "v"(vt[1]), "v"(vt[2]), "v"(vt[3]), "v"(vt[4]), "v"(vt[5]), "v"(vt[6]), "v"(vt[7]), \
 				 "v"(vt[8]), "v"(vt[9]), "v"(vt[10]), "v"(vt[11]), "v"(vt[12]), "v"(vt[13]), "v"(vt[14]), "v"(vt[15]), "v"(vt[16]))
-#define SNAIL_DESCEND_PF_PLAIN(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT)                                                                     \
-	SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s85", "s88", "s86", "s89", "s76", "s79", "s77", "s80", "s78", "s81")
-#define SNAIL_DESCEND_PF_OCT(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, OCT)                                                                \
+#define SNAIL_DESCEND_PF_PLAIN(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ)                                                                     \
+	SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s84", "s87", "s85", "s88", "s86", "s89", "s76", "s79", "s77", "s80", "s78", "s81")
+#define SNAIL_DESCEND_PF_OCT(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, OCT)                                                                \
 	switch(OCT) {                                                                                                                          \
-	case 0: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s85", "s88", "s86", "s89", "s76", "s79", "s77", "s80", "s78", "s81"); break; \
-	case 1: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s85", "s88", "s86", "s89", "s79", "s76", "s77", "s80", "s78", "s81"); break; \
-	case 2: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s88", "s85", "s86", "s89", "s76", "s79", "s80", "s77", "s78", "s81"); break; \
-	case 3: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s88", "s85", "s86", "s89", "s79", "s76", "s80", "s77", "s78", "s81"); break; \
-	case 4: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s85", "s88", "s89", "s86", "s76", "s79", "s77", "s80", "s81", "s78"); break; \
-	case 5: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s85", "s88", "s89", "s86", "s79", "s76", "s77", "s80", "s81", "s78"); break; \
-	case 6: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s84", "s87", "s88", "s85", "s89", "s86", "s76", "s79", "s80", "s77", "s81", "s78"); break; \
-	default: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, "s87", "s84", "s88", "s85", "s89", "s86", "s79", "s76", "s80", "s77", "s81", "s78"); break; \
+	case 0: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s84", "s87", "s85", "s88", "s86", "s89", "s76", "s79", "s77", "s80", "s78", "s81"); break; \
+	case 1: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s87", "s84", "s85", "s88", "s86", "s89", "s79", "s76", "s77", "s80", "s78", "s81"); break; \
+	case 2: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s84", "s87", "s88", "s85", "s86", "s89", "s76", "s79", "s80", "s77", "s78", "s81"); break; \
+	case 3: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s87", "s84", "s88", "s85", "s86", "s89", "s79", "s76", "s80", "s77", "s78", "s81"); break; \
+	case 4: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s84", "s87", "s85", "s88", "s89", "s86", "s76", "s79", "s77", "s80", "s81", "s78"); break; \
+	case 5: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s87", "s84", "s85", "s88", "s89", "s86", "s79", "s76", "s77", "s80", "s81", "s78"); break; \
+	case 6: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s84", "s87", "s88", "s85", "s89", "s86", "s76", "s79", "s80", "s77", "s81", "s78"); break; \
+	default: SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s87", "s84", "s88", "s85", "s89", "s86", "s79", "s76", "s80", "s77", "s81", "s78"); break; \
 	}
 
 // ---- the prefetching loop with the PUSH DEFERRED into the next visit (primary packets over camera-relative records) -----------------
@@ -1292,10 +1291,10 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 // in A; the far child's offset lives in a register of its own per set (A: %[fl], B: %[width]),
 // so that a visit's own near / far computation does not overwrite the pending one.  Invariants are those of SNAIL_DESCEND_PF
 // (a register set never has two requests in flight; m0 = sp; topw = the top entry's word, T = its record).
-#define SNAIL_PF2_NEARFAR(SUB, AUX, FARX, OTHERSET)                                                                                          \
+#define SNAIL_PF2_NEARFAR(SUB, AUX, FARX, OTHERSET, LEAFREQ)                                                                                          \
 				 " s_and_b32 %[cur], " AUX ", %[sign16]\n s_cselect_b32 %[cur], 32, 0\n"                                                       \
 				 " s_xor_b32 %[cur], " SUB ", %[cur]\n s_xor_b32 " FARX ", %[cur], 32\n"                                                       \
-				 " s_max_i32 %[cur], %[cur], 0\n" /* a leaf's "near child" is slot 0 */                                                     \
+				 LEAFREQ /* what a leaf's "near child" request fetches: SNAIL_PF_LEAFREQ_* */                                                \
 				 " s_load_dwordx8 " OTHERSET ", %[base], %[cur]\n"
 // the end of a visit: EXEC <- the survivors; first / last are taken from EXEC where they are needed (the next visit's push, or the leaf)
 #define SNAIL_PF2_TAIL(X, SUB) /* SCC = "this node is a leaf", set by SNAIL_PF2_ISLEAF after the visit's last other scalar instruction */ \
@@ -1308,26 +1307,27 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 #define SNAIL_PF2_ALIVE " s_sub_u32 %[cur], %[last], %[first]\n s_bfm_b64 %[alive], %[cur], %[first]\n s_bitset1_b64 %[alive], %[last]\n"
 #define SNAIL_PF2_FIRSTLAST " s_ff1_i32_b64 %[first], exec\n s_flbit_i32_b64 %[last], exec\n s_xor_b32 %[last], %[last], 63\n"
 // a visit entered from a descent: the push of (FARY, survivors' first / last) happens here, between the slab products
-#define SNAIL_PF2_PENDING(X, OTHERSET, SUB, AUX, FARX, FARY, SLAB, NX, FX, NY, FY, NZ, FZ)                                                   \
+#define SNAIL_PF2_PENDING(X, OTHERSET, SUB, AUX, FARX, FARY, PRE, SLAB, TAIL, CNTVISIT, LEAFREQ, NX, FX, NY, FY, NZ, FZ)                                                   \
 				 "L_visit" X "p_%=:\n"                                                                                                      \
 				 " s_waitcnt lgkmcnt(0)\n" /* this record has arrived; T's last request too */                                                \
 				 " s_load_dwordx8 s[68:75], %[base], " FARY "\n" /* the pusher's far child is the new top entry */                             \
-				 SLAB("0", NX, FX, NY, FY, NZ, FZ) SNAIL_TAIL_POS("0", "s0")                                                                 \
-				 SNAIL_PF2_NEARFAR(SUB, AUX, FARX, OTHERSET)                                                                                 \
-				 SLAB("1", NX, FX, NY, FY, NZ, FZ) SNAIL_TAIL_POS("1", "s1")                                                                 \
+				 CNTVISIT PRE(NX, FX, NY, FY, NZ, FZ)                                                                                        \
+				 SLAB("0", NX, FX, NY, FY, NZ, FZ) TAIL("0", "s0")                                                                           \
+				 SNAIL_PF2_NEARFAR(SUB, AUX, FARX, OTHERSET, LEAFREQ)                                                                        \
+				 SLAB("1", NX, FX, NY, FY, NZ, FZ) TAIL("1", "s1")                                                                           \
 				 SNAIL_PF2_FIRSTLAST /* of the pusher: EXEC is still its survivor set */                                                     \
 				 " s_lshl_b32 %[off], %[last], 6\n s_or_b32 %[off], %[off], %[first]\n s_lshl_b32 %[off], %[off], 20\n"                    \
 				 SNAIL_PF2_ALIVE                                                                                                            \
-				 SLAB("2", NX, FX, NY, FY, NZ, FZ) SNAIL_TAIL_POS("2", "s2")                                                                 \
+				 SLAB("2", NX, FX, NY, FY, NZ, FZ) TAIL("2", "s2")                                                                           \
 				 " s_lshr_b32 %[topw], " FARY ", 5\n s_or_b32 %[topw], %[topw], %[off]\n"                                                    \
 				 " v_writelane_b32 %[stkN], %[topw], m0\n s_add_u32 m0, m0, 1\n" SNAIL_PF2_ISLEAF(SUB)                                       \
-				 SLAB("3", NX, FX, NY, FY, NZ, FZ) SNAIL_TAIL_POS("3", "s3")                                                                 \
+				 SLAB("3", NX, FX, NY, FY, NZ, FZ) TAIL("3", "s3")                                                                           \
 				 SNAIL_PF2_TAIL(X, SUB)
 #define SNAIL_PF2_LEAF(X, SUB, AUX)                                                                                                         \
 				 "L_leaf" X "_%=:\n" SNAIL_PF2_FIRSTLAST                                                                                    \
 				 " s_bfe_u32 %[leafSub], " SUB ", 0x190006\n s_sub_u32 %[leafSub], %[leafSub], 0x80000\n s_bitset1_b32 %[leafSub], 31\n"   \
 				 " s_mov_b32 %[leafAux], " AUX "\n s_waitcnt lgkmcnt(0)\n s_branch L_end_%=\n"
-#define SNAIL_DESCEND_PF2(SLAB, NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)                                                  \
+#define SNAIL_DESCEND_PF2(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)                                                  \
 	asm volatile(" s_mov_b32 m0, %[sp]\n"                                                                                                 \
 				 "L_entry_%=:\n"                                                                                                           \
 				 " s_cmp_eq_u32 m0, 0\n s_cbranch_scc1 L_done_%=\n"                                                                     \
@@ -1337,25 +1337,26 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 " s_load_dwordx8 s[68:75], %[base], %[off]\n"                                                                             \
 				 " s_bfe_u32 %[first], %[topw], 0x60014\n s_lshr_b32 %[last], %[topw], 26\n" SNAIL_PF2_ALIVE                               \
 				 "L_pop_%=:\n" /* sp > 0, topw = the top entry, alive = its lanes, T = its record (requested) */                            \
-				 " s_sub_u32 m0, m0, 1\n" SNAIL_COUNT                                                                                     \
+				 " s_sub_u32 m0, m0, 1\n" CNTPOP                                                                                     \
 				 " s_mov_b64 exec, %[alive]\n"                                                                                             \
 				 " s_waitcnt lgkmcnt(0)\n" SNAIL_A_FROM_T                                                                                  \
 				 /* the popped node's visit (record set A); the NEW top entry's word and record are fetched inside it */                  \
 				 " s_sub_u32 %[off], m0, 1\n s_max_i32 %[off], %[off], 0\n" /* (an empty stack re-reads entry 0: harmless, never used) */  \
 				 " v_readlane_b32 %[topw], %[stkN], %[off]\n"                                                                              \
-				 SLAB("0", NXA, FXA, NYA, FYA, NZA, FZA) SNAIL_TAIL_POS("0", "s0")                                                          \
+				 CNTVISIT PRE(NXA, FXA, NYA, FYA, NZA, FZA)                                                                                 \
+				 SLAB("0", NXA, FXA, NYA, FYA, NZA, FZA) TAIL("0", "s0")                                                          \
 				 " s_and_b32 %[cur], %[topw], 0xfffff\n s_lshl_b32 %[off], %[cur], 5\n"                                                    \
 				 " s_load_dwordx8 s[68:75], %[base], %[off]\n"                                                                             \
-				 SLAB("1", NXA, FXA, NYA, FYA, NZA, FZA) SNAIL_TAIL_POS("1", "s1")                                                          \
-				 SNAIL_PF2_NEARFAR("s90", "s91", "%[fl]", "s[76:83]")                                                                       \
-				 SLAB("2", NXA, FXA, NYA, FYA, NZA, FZA) SNAIL_TAIL_POS("2", "s2")                                                          \
+				 SLAB("1", NXA, FXA, NYA, FYA, NZA, FZA) TAIL("1", "s1")                                                          \
+				 SNAIL_PF2_NEARFAR("s90", "s91", "%[fl]", "s[76:83]", LEAFREQ)                                                                       \
+				 SLAB("2", NXA, FXA, NYA, FYA, NZA, FZA) TAIL("2", "s2")                                                          \
 				 " s_bfe_u32 %[first], %[topw], 0x60014\n s_lshr_b32 %[last], %[topw], 26\n" SNAIL_PF2_ALIVE SNAIL_PF2_ISLEAF("s90")        \
-				 SLAB("3", NXA, FXA, NYA, FYA, NZA, FZA) SNAIL_TAIL_POS("3", "s3")                                                          \
+				 SLAB("3", NXA, FXA, NYA, FYA, NZA, FZA) TAIL("3", "s3")                                                          \
 				 SNAIL_PF2_TAIL("A", "s90")                                                                                                 \
 				 /* falls through: A descends into B, its push pending */                                                                   \
-				 SNAIL_PF2_PENDING("B", "s[84:91]", "s82", "s83", "%[width]", "%[fl]", SLAB, NXB, FXB, NYB, FYB, NZB, FZB)                   \
+				 SNAIL_PF2_PENDING("B", "s[84:91]", "s82", "s83", "%[width]", "%[fl]", PRE, SLAB, TAIL, CNTVISIT, LEAFREQ, NXB, FXB, NYB, FYB, NZB, FZB)                   \
 				 /* falls through: B descends into A, its push pending */                                                                   \
-				 SNAIL_PF2_PENDING("A", "s[76:83]", "s90", "s91", "%[fl]", "%[width]", SLAB, NXA, FXA, NYA, FYA, NZA, FZA)                   \
+				 SNAIL_PF2_PENDING("A", "s[76:83]", "s90", "s91", "%[fl]", "%[width]", PRE, SLAB, TAIL, CNTVISIT, LEAFREQ, NXA, FXA, NYA, FYA, NZA, FZA)                   \
 				 " s_branch L_visitBp_%=\n"                                                                                                \
 				 SNAIL_PF2_LEAF("A", "s90", "s91") SNAIL_PF2_LEAF("B", "s82", "s83")                                                       \
 				 "L_fail_%=:\n"                                                                                                            \
@@ -1368,7 +1369,7 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				   [pnz] "=&v"(vt[2]), [pfx] "=&v"(vt[3]), [pfy] "=&v"(vt[4]), [pfz] "=&v"(vt[5]), [t0] "=&v"(vt[6]), [t1] "=&v"(vt[7]),   \
 				   [t2] "=&v"(vt[8]), [t3] "=&v"(vt[9]), [t4] "=&v"(vt[10]), [t5] "=&v"(vt[11]), [s0] "=&v"(vt[12]), [s1] "=&v"(vt[13]),   \
 				   [s2] "=&v"(vt[14]), [s3] "=&v"(vt[15]), [u0] "=&v"(vt[16])                                                              \
-				 : [base] "s"(nodeBase), [sign16] "s"(sign16), [lane] "v"(lane), SNAIL_ORG_SHARED(), [ix0] "v"(Q.id[0][0]), [ix1] "v"(Q.id[0][1]), [ix2] "v"(Q.id[0][2]), [ix3] "v"(Q.id[0][3]),        \
+				 : [base] "s"(nodeBase), [sign16] "s"(sign16), [lane] "v"(lane), ORGOPS(), [ix0] "v"(Q.id[0][0]), [ix1] "v"(Q.id[0][1]), [ix2] "v"(Q.id[0][2]), [ix3] "v"(Q.id[0][3]),        \
 				   [iy0] "v"(Q.id[1][0]), [iy1] "v"(Q.id[1][1]), [iy2] "v"(Q.id[1][2]), [iy3] "v"(Q.id[1][3]), [iz0] "v"(Q.id[2][0]),      \
 				   [iz1] "v"(Q.id[2][1]), [iz2] "v"(Q.id[2][2]), [iz3] "v"(Q.id[2][3]), [d0] "v"(Q.dist[0]), [d1] "v"(Q.dist[1]),          \
 				   [d2] "v"(Q.dist[2]), [d3] "v"(Q.dist[3])                                                                                \
@@ -1377,17 +1378,17 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 	asm volatile("" ::"s"(sp), "s"(first), "s"(last), "s"(cnt), "v"(stkN), "v"(stkF), "s"(leafSub), "s"(leafAux), "s"(sCur), "s"(sFl), "s"(sOff),    \
 				 "s"(sWidth), "s"(sTopw), "s"(sAlive), "v"(vt[0]), "v"(vt[1]), "v"(vt[2]), "v"(vt[3]), "v"(vt[4]), "v"(vt[5]), "v"(vt[6]), "v"(vt[7]), \
 				 "v"(vt[8]), "v"(vt[9]), "v"(vt[10]), "v"(vt[11]), "v"(vt[12]), "v"(vt[13]), "v"(vt[14]), "v"(vt[15]), "v"(vt[16]))
-#define SNAIL_DESCEND_PF2_PLAIN(SLAB) SNAIL_DESCEND_PF2(SLAB, "s84", "s87", "s85", "s88", "s86", "s89", "s76", "s79", "s77", "s80", "s78", "s81")
-#define SNAIL_DESCEND_PF2_OCT(SLAB, OCT)                                                                                                    \
+#define SNAIL_DESCEND_PF2_PLAIN(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ) SNAIL_DESCEND_PF2(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s84", "s87", "s85", "s88", "s86", "s89", "s76", "s79", "s77", "s80", "s78", "s81")
+#define SNAIL_DESCEND_PF2_OCT(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, OCT)                                                                                                    \
 	switch(OCT) {                                                                                                                          \
-	case 0: SNAIL_DESCEND_PF2(SLAB, "s84", "s87", "s85", "s88", "s86", "s89", "s76", "s79", "s77", "s80", "s78", "s81"); break;            \
-	case 1: SNAIL_DESCEND_PF2(SLAB, "s87", "s84", "s85", "s88", "s86", "s89", "s79", "s76", "s77", "s80", "s78", "s81"); break;            \
-	case 2: SNAIL_DESCEND_PF2(SLAB, "s84", "s87", "s88", "s85", "s86", "s89", "s76", "s79", "s80", "s77", "s78", "s81"); break;            \
-	case 3: SNAIL_DESCEND_PF2(SLAB, "s87", "s84", "s88", "s85", "s86", "s89", "s79", "s76", "s80", "s77", "s78", "s81"); break;            \
-	case 4: SNAIL_DESCEND_PF2(SLAB, "s84", "s87", "s85", "s88", "s89", "s86", "s76", "s79", "s77", "s80", "s81", "s78"); break;            \
-	case 5: SNAIL_DESCEND_PF2(SLAB, "s87", "s84", "s85", "s88", "s89", "s86", "s79", "s76", "s77", "s80", "s81", "s78"); break;            \
-	case 6: SNAIL_DESCEND_PF2(SLAB, "s84", "s87", "s88", "s85", "s89", "s86", "s76", "s79", "s80", "s77", "s81", "s78"); break;            \
-	default: SNAIL_DESCEND_PF2(SLAB, "s87", "s84", "s88", "s85", "s89", "s86", "s79", "s76", "s80", "s77", "s81", "s78"); break;           \
+	case 0: SNAIL_DESCEND_PF2(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s84", "s87", "s85", "s88", "s86", "s89", "s76", "s79", "s77", "s80", "s78", "s81"); break;            \
+	case 1: SNAIL_DESCEND_PF2(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s87", "s84", "s85", "s88", "s86", "s89", "s79", "s76", "s77", "s80", "s78", "s81"); break;            \
+	case 2: SNAIL_DESCEND_PF2(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s84", "s87", "s88", "s85", "s86", "s89", "s76", "s79", "s80", "s77", "s78", "s81"); break;            \
+	case 3: SNAIL_DESCEND_PF2(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s87", "s84", "s88", "s85", "s86", "s89", "s79", "s76", "s80", "s77", "s78", "s81"); break;            \
+	case 4: SNAIL_DESCEND_PF2(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s84", "s87", "s85", "s88", "s89", "s86", "s76", "s79", "s77", "s80", "s81", "s78"); break;            \
+	case 5: SNAIL_DESCEND_PF2(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s87", "s84", "s85", "s88", "s89", "s86", "s79", "s76", "s77", "s80", "s81", "s78"); break;            \
+	case 6: SNAIL_DESCEND_PF2(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s84", "s87", "s88", "s85", "s89", "s86", "s76", "s79", "s80", "s77", "s81", "s78"); break;            \
+	default: SNAIL_DESCEND_PF2(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s87", "s84", "s88", "s85", "s89", "s86", "s79", "s76", "s80", "s77", "s81", "s78"); break;           \
 	}
 
 // near/far plane registers by sign octant (bit k set = idir negative on axis k: near plane = bmax[k]); s[84:86] = bmin, s[87:89] = bmax
@@ -1431,10 +1432,20 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 #define SNAIL_NODE_PREFETCH 1 // 0 = the loop without record prefetch for one-word stacks too (A/B measurements)
 #endif
 #ifndef SNAIL_DEFER_PUSH
-#define SNAIL_DEFER_PUSH 1 // primary packets over camera-relative records: the push of a descent is done inside the next visit (SNAIL_DESCEND_PF2)
+#define SNAIL_DEFER_PUSH 1 // the prefetching loop with the push of a descent done inside the next visit (SNAIL_DESCEND_PF2); 0 = SNAIL_DESCEND_PF (A/B measurements)
+#endif
+#if SNAIL_DEFER_PUSH
+#define SNAIL_WALK_PF_OCT SNAIL_DESCEND_PF2_OCT
+#define SNAIL_WALK_PF_PLAIN SNAIL_DESCEND_PF2_PLAIN
+#else
+#define SNAIL_WALK_PF_OCT SNAIL_DESCEND_PF_OCT
+#define SNAIL_WALK_PF_PLAIN SNAIL_DESCEND_PF_PLAIN
 #endif
 #ifndef SNAIL_REL_NODES
 #define SNAIL_REL_NODES 1 // primary packets walk camera-relative node records (no plane offsets to compute per visit); 0 = the loop's plain copy
+#endif
+#ifndef SNAIL_REL_SHADOW
+#define SNAIL_REL_SHADOW 1 // shadow packets of k_light walk records relative to their light's position (ShadeArgs::relLight), as primary packets do for the camera
 #endif
 // the node array a PACK instantiation of the hand-written walks is given: the prefetching loop's own copy of the tree
 #define SNAIL_PACK_NODES(A) (SNAIL_NODE_PREFETCH ? (A).pf : (A).nodes)
@@ -1477,38 +1488,31 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /*
 		}
 		if(PF) {
 			int sTopw;
+			// primary packets (POSDIST) read camera-relative records: no plane offsets to form, a leaf's request is slot 0
 			if(COH) {
-				if(SHADOW) { SNAIL_DESCEND_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_ANY, "", SNAIL_COUNT, oct) }
+#if SNAIL_REL_SHADOW
+				if(SHADOW) { SNAIL_WALK_PF_OCT(SNAIL_PRE_NONE, SNAIL_ORG_SHARED, SNAIL_SLAB_COH_R, SNAIL_TAIL_ANY, "", SNAIL_COUNT, SNAIL_PF_LEAFREQ_SLOT0, oct) }
+#else
+				if(SHADOW) { SNAIL_WALK_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_ANY, "", SNAIL_COUNT, SNAIL_PF_LEAFREQ_TRI, oct) }
+#endif
 #if SNAIL_REL_NODES
-#undef SNAIL_PF_LEAFREQ
-#define SNAIL_PF_LEAFREQ SNAIL_PF_LEAFREQ_SLOT0
-#if SNAIL_DEFER_PUSH
-				else if(POSDIST) { SNAIL_DESCEND_PF2_OCT(SNAIL_SLAB_COH_R, oct) }
+				else if(POSDIST) { SNAIL_WALK_PF_OCT(SNAIL_PRE_NONE, SNAIL_ORG_SHARED, SNAIL_SLAB_COH_R, SNAIL_TAIL_POS, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_SLOT0, oct) }
 #else
-				else if(POSDIST) { SNAIL_DESCEND_PF_OCT(SNAIL_PRE_NONE, SNAIL_ORG_SHARED, SNAIL_SLAB_COH_R, SNAIL_TAIL_POS, SNAIL_COUNT, "", oct) }
+				else if(POSDIST) { SNAIL_WALK_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_POS, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_TRI, oct) }
 #endif
-#undef SNAIL_PF_LEAFREQ
-#define SNAIL_PF_LEAFREQ SNAIL_PF_LEAFREQ_TRI
-#else
-				else if(POSDIST) { SNAIL_DESCEND_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_POS, SNAIL_COUNT, "", oct) }
-#endif
-				else { SNAIL_DESCEND_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_ANY, SNAIL_COUNT, "", oct) }
+				else { SNAIL_WALK_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_ANY, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_TRI, oct) }
 			} else {
-				if(SHADOW) { SNAIL_DESCEND_PF_PLAIN(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, "", SNAIL_COUNT); }
+#if SNAIL_REL_SHADOW
+				if(SHADOW) { SNAIL_WALK_PF_PLAIN(SNAIL_PRE_NONE, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST_R, SNAIL_TAIL_ANY, "", SNAIL_COUNT, SNAIL_PF_LEAFREQ_SLOT0); }
+#else
+				if(SHADOW) { SNAIL_WALK_PF_PLAIN(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, "", SNAIL_COUNT, SNAIL_PF_LEAFREQ_TRI); }
+#endif
 #if SNAIL_REL_NODES
-#undef SNAIL_PF_LEAFREQ
-#define SNAIL_PF_LEAFREQ SNAIL_PF_LEAFREQ_SLOT0
-#if SNAIL_DEFER_PUSH
-				else if(POSDIST) { SNAIL_DESCEND_PF2_PLAIN(SNAIL_SLAB_FAST_R); }
+				else if(POSDIST) { SNAIL_WALK_PF_PLAIN(SNAIL_PRE_NONE, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST_R, SNAIL_TAIL_POS, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_SLOT0); }
 #else
-				else if(POSDIST) { SNAIL_DESCEND_PF_PLAIN(SNAIL_PRE_NONE, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST_R, SNAIL_TAIL_POS, SNAIL_COUNT, ""); }
+				else if(POSDIST) { SNAIL_WALK_PF_PLAIN(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_POS, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_TRI); }
 #endif
-#undef SNAIL_PF_LEAFREQ
-#define SNAIL_PF_LEAFREQ SNAIL_PF_LEAFREQ_TRI
-#else
-				else if(POSDIST) { SNAIL_DESCEND_PF_PLAIN(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_POS, SNAIL_COUNT, ""); }
-#endif
-				else { SNAIL_DESCEND_PF_PLAIN(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, ""); }
+				else { SNAIL_WALK_PF_PLAIN(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_TRI); }
 			}
 		} else if(PACK) { SNAIL_SHARED_VARIANTS(SNAIL_POP_1W, SNAIL_PUSH_1W) }
 		else { SNAIL_SHARED_VARIANTS(SNAIL_POP_2W, SNAIL_PUSH_2W) }
@@ -1543,7 +1547,7 @@ __device__ __forceinline__ void walkPerRayAsm(const uint4 *__restrict__ nodes /*
 			// copies of it beside the per-ray leaf code ("illegal VGPR to SGPR copy": the scalar-register pressure of the 16-SGPR triangle
 			// record plus three node record sets); coherent packets keep the plain loop.
 			int sTopw;
-			SNAIL_DESCEND_PF_PLAIN(SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, "");
+			SNAIL_WALK_PF_PLAIN(SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_TRI);
 		} else if(COH) { SNAIL_DESCEND_OCT(SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_COH, SNAIL_TAIL_ANY, SNAIL_COUNT, "", oct) }
 		else { SNAIL_DESCEND_ASM(SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, "", "s84", "s87", "s85", "s88", "s86", "s89"); }
 		if(leafSub == 0) break;
@@ -1959,6 +1963,7 @@ struct ShadeArgs {
 	int pack;            // at most 2^20 node slots: one-word stack entries in the hand-written walks
 	int nLights;
 	float lights[SNAIL_MAX_LIGHTS][7];
+	const uint4 *relLight[SNAIL_MAX_LIGHTS]; // per light: the node records relative to its position (SnailScene::relFor; set by launchLights when `pack` is set)
 	float ambient[3], color[3];
 	const float *hitT;   // primary hits, packet-major
 	const int *hitId;
@@ -2150,8 +2155,9 @@ __device__ __forceinline__ void lightPacket(const ShadeArgs &A, const int li, co
 			if(mode == M_COH) walk<true, false, true, M_COH, false, DEEP, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st, oct);
 			else walk<true, false, true, M_FAST, false, DEEP, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st);
 		} else if(A.pack) {
-			if(mode == M_COH) walkSharedAsm<true, true, true, false, false, false>(SNAIL_PACK_NODES(A), A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st, oct);
-			else walkSharedAsm<true, false, true, false, false, false>(SNAIL_PACK_NODES(A), A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st, 0);
+			const uint4 *pn = (SNAIL_NODE_PREFETCH && SNAIL_REL_SHADOW) ? A.relLight[n] : SNAIL_PACK_NODES(A);   // this light's relative records
+			if(mode == M_COH) walkSharedAsm<true, true, true, false, false, false>(pn, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st, oct);
+			else walkSharedAsm<true, false, true, false, false, false>(pn, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st, 0);
 		} else if(mode == M_COH) walkSharedAsm<true, true, false, false, false, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st, oct);
 		else walkSharedAsm<true, false, false, false, false, false>(A.nodes, A.tris, 64, lane, lorg, Q, 15u, stid, bu, bv, lds, st, 0);
 	}
@@ -3195,8 +3201,13 @@ int launchRays(SnailScene *s, bool shadow, int nPackets, int size, int sharedOri
 }
 
 template <int SRC>
-void launchLights(const SnailScene *s, const dev::ShadeArgs &A, hipStream_t stream) {
-	if(A.nLights <= 0) return;
+int launchLights(SnailScene *s, dev::ShadeArgs A /* a copy: relLight is filled in here */, hipStream_t stream) {
+	if(A.nLights <= 0) return 0;
+	int relWhich[SNAIL_MAX_LIGHTS];
+	for(int n = 0; n < SNAIL_MAX_LIGHTS; n++) { relWhich[n] = -1; A.relLight[n] = nullptr; }
+	if(SNAIL_NODE_PREFETCH && SNAIL_REL_SHADOW && A.pack && !useDeep(s))
+		for(int n = 0; n < A.nLights; n++)
+			if(int rc = relFor(s, A.lights[n], stream, &A.relLight[n], &relWhich[n])) return rc;   // lights[n][0..2] = the light's position
 	const dim3 grid(A.nBlocks, A.nLights);
 	const int total = A.nBlocks * A.nLights;
 	const int exactBlocks = A.fastOK ? (total < 8 ? total : 8) : (total < 2048 ? total : 2048);
@@ -3207,6 +3218,10 @@ void launchLights(const SnailScene *s, const dev::ShadeArgs &A, hipStream_t stre
 		hipLaunchKernelGGL((dev::k_light<false, SRC>), grid, dim3(64), 0, stream, A);
 		hipLaunchKernelGGL((dev::k_light_exact<false, SRC>), dim3(exactBlocks), dim3(64), 0, stream, A);
 	}
+	HIP_TRY(hipGetLastError());
+	for(int n = 0; n < A.nLights; n++)
+		if(relWhich[n] >= 0) { if(int rc = relUsed(s, relWhich[n], stream)) return rc; }
+	return 0;
 }
 
 } // namespace
@@ -3683,11 +3698,11 @@ static int renderWhitted(const char *fn, SnailScene *s, const float cam[13], int
 		hipLaunchKernelGGL((dev::k_final<dev::SRC_PRIMARY, dev::DST_MIRROR>), grid, wave, 0, st, A);
 		HIP_TRY(hipGetLastError());
 		if(int rc = launchRays(s, false, packets, 64, 0, W.rOrg, W.rDir, W.rIDir, W.rMask, W.rDist, W.rObj, nullptr, dStats, st)) return rc;
-		launchLights<dev::SRC_MIRROR>(s, A, st);
+		if(int rc = launchLights<dev::SRC_MIRROR>(s, A, st)) return rc;
 		hipLaunchKernelGGL((dev::k_final<dev::SRC_MIRROR, dev::DST_COLOR>), grid, wave, 0, st, A);
 		HIP_TRY(hipGetLastError());
 	}
-	launchLights<dev::SRC_PRIMARY>(s, A, st);
+	if(int rc = launchLights<dev::SRC_PRIMARY>(s, A, st)) return rc;
 	hipLaunchKernelGGL((dev::k_final<dev::SRC_PRIMARY, dev::DST_FRAME>), grid, wave, 0, st, A);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(W.done, st));
@@ -3745,7 +3760,7 @@ int snail_trace_transparency_dev(SnailScene *s, const float cam[13], int resx, i
 	hipLaunchKernelGGL((dev::k_final<dev::SRC_PRIMARY, dev::DST_CONTINUE>), dim3(blocks), dim3(64), 0, st, A);
 	HIP_TRY(hipGetLastError());
 	if(int rc = launchRays(s, false, nPackets, 64, 0, W.rOrg, W.rDir, W.rIDir, W.rMask, W.rDist, W.rObj, nullptr, dStats, st)) return rc;
-	launchLights<dev::SRC_MIRROR>(s, A, st);
+	if(int rc = launchLights<dev::SRC_MIRROR>(s, A, st)) return rc;
 	hipLaunchKernelGGL((dev::k_final<dev::SRC_MIRROR, dev::DST_COLOR>), dim3(blocks), dim3(64), 0, st, A);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(W.done, st));
