@@ -74,6 +74,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 VALU_PEAK_GINST = 1024 * 2.4 / 2.0   # wave64 VALU instructions per ns: 1024 SIMDs x 2.4 GHz / 2 cycles each (MI355X_MICROARCH.md, cycle constants)
+VALU_CYCLES_MEASURED = 2.5   # cycles per wave64 VALU instruction a SIMD sustains at 6 waves (tools/micro/visit_rate.hip, valu_banks.hip)
 CPU_THREADS_CAP = 16
 
 CONFIGS = {
@@ -401,6 +402,10 @@ def main():
         roof = {"bound": "valu_issue", "achieved": round(valu / step_s / 1e9, 1) if valu else None, "peak": round(peak_ginst, 1), "unit": "Gwaveinst/s",
                 "frac": round(valu / step_s / 1e9 / peak_ginst, 4) if valu else None,
                 "counters_stale": bool(tr.get("_stale")) if tr else None,
+                # what a SIMD of this part sustains on the visit's own instruction mix at 6 waves (tools/micro/visit_rate.hip: 118-121 cycles per
+                # 47-instruction visit; pure v_fma_f32 / v_mul_f32 streams 2.45-2.65 cycles per instruction, tools/micro/valu_banks.hip)
+                "frac_of_measured_issue_rate": round(valu / step_s / 1e9 / (peak_ginst * 2.0 / VALU_CYCLES_MEASURED), 4) if valu else None,
+                "measured_issue_rate_note": "peak above = one wave64 VALU instruction per 2 cycles per SIMD (MI355X_MICROARCH.md); measured on this part: one per %.1f cycles (profiles/r3_valu_microbench.txt)" % VALU_CYCLES_MEASURED,
                 "traffic": traffic * rnd.batch if traffic else None,
                 "traffic_unit": "HBM bytes per launch of %d frame(s) (rocprofv3 PMC of a one-frame launch: 2 x FETCH_SIZE + WRITE_SIZE, x frames per launch)" % rnd.batch,
                 "frames_per_launch": rnd.batch, "traffic_bytes_per_frame": traffic,

@@ -1113,10 +1113,17 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 	" s_lshl_b32 %[off], %[last], 6\n s_or_b32 %[off], %[off], %[first]\n s_lshl_b32 %[off], %[off], 20\n s_or_b32 %[off], %[off], %[fl]\n" \
 	" s_mov_b32 m0, %[sp]\n v_writelane_b32 %[stkN], %[off], m0\n"
 #define SNAIL_COUNT " s_add_u32 %[cnt], %[cnt], 1\n"
+// Every statement of the loop starts by waiting for the scalar loads the COMPILER may still have in flight: it does not wait for a load whose
+// result turned out dead (the per-ray-origin leaf fetches a triangle record with s_load_dwordx16 and may leave the loop before using it), such a
+// load may target the very registers the statement pins (s68..s91 are free between two statements), and scalar loads return out of order --
+// a record requested here could be overwritten by the stale one.  (Found by the soak runs of round 3: mirrored / masked per-ray packets, on
+// some boxes only, ~4 % of the batches; shared-origin leaves fetch their triangles with vector loads and were never affected.)
+#define SNAIL_DRAIN_SMEM " s_waitcnt lgkmcnt(0)\n"
 #define SNAIL_DESCEND_ASM(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, NX, FX, NY, FY, NZ, FZ)                                                 \
 	SNAIL_DESCEND_ASM_S(SNAIL_POP_2W, SNAIL_PUSH_2W, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, NX, FX, NY, FY, NZ, FZ)
 #define SNAIL_DESCEND_ASM_S(POP, PUSH, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, NX, FX, NY, FY, NZ, FZ)                                                            \
-	asm volatile("L_pop_%=:\n"                                                                                                             \
+	asm volatile(SNAIL_DRAIN_SMEM                                                                                                          \
+				 "L_pop_%=:\n"                                                                                                             \
 				 " s_cmp_eq_u32 %[sp], 0\n s_cbranch_scc1 L_done_%=\n"                                                                     \
 				 " s_sub_u32 %[sp], %[sp], 1\n" CNTPOP                                                                                     \
 				 POP                                                                                                                       \
@@ -1224,7 +1231,7 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 " s_mov_b32 %[leafAux], " AUX "\n s_waitcnt lgkmcnt(0)\n s_branch L_end_%=\n"
 // set A = s[84:91] (planes NXA.., sub s90, aux s91), set B = s[76:83] (planes NXB.., sub s82, aux s83)
 #define SNAIL_DESCEND_PF(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)                 \
-	asm volatile(" s_mov_b32 m0, %[sp]\n"                                                                                                 \
+	asm volatile(SNAIL_DRAIN_SMEM " s_mov_b32 m0, %[sp]\n"                                                                                \
 				 "L_entry_%=:\n"                                                                                                           \
 				 " s_cmp_eq_u32 m0, 0\n s_cbranch_scc1 L_done_%=\n"                                                                     \
 				 " s_sub_u32 %[off], m0, 1\n"                                                                                           \
@@ -1327,8 +1334,8 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 "L_leaf" X "_%=:\n" SNAIL_PF2_FIRSTLAST                                                                                    \
 				 " s_bfe_u32 %[leafSub], " SUB ", 0x190006\n s_sub_u32 %[leafSub], %[leafSub], 0x80000\n s_bitset1_b32 %[leafSub], 31\n"   \
 				 " s_mov_b32 %[leafAux], " AUX "\n s_waitcnt lgkmcnt(0)\n s_branch L_end_%=\n"
-#define SNAIL_DESCEND_PF2(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)                                                  \
-	asm volatile(" s_mov_b32 m0, %[sp]\n"                                                                                                 \
+#define SNAIL_DESCEND_PF2X(EXTRACLOB, PREVARS, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)                                                  \
+	asm volatile(SNAIL_DRAIN_SMEM " s_mov_b32 m0, %[sp]\n"                                                                                \
 				 "L_entry_%=:\n"                                                                                                           \
 				 " s_cmp_eq_u32 m0, 0\n s_cbranch_scc1 L_done_%=\n"                                                                     \
 				 " s_sub_u32 %[off], m0, 1\n"                                                                                           \
@@ -1365,8 +1372,7 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 "L_end_%=:\n s_mov_b64 exec, -1\n s_mov_b32 %[sp], m0\n"                                                                                        \
 				 : [sp] "+s"(sp), [first] "+s"(first), [last] "+s"(last), [cnt] "+s"(cnt), [stkN] "+v"(stkN), [stkF] "+v"(stkF),           \
 				   [leafSub] "=&s"(leafSub), [leafAux] "=&s"(leafAux), [cur] "=&s"(sCur), [fl] "=&s"(sFl), [off] "=&s"(sOff),              \
-				   [width] "=&s"(sWidth), [topw] "=&s"(sTopw), [alive] "=&s"(sAlive), [pnx] "=&v"(vt[0]), [pny] "=&v"(vt[1]),              \
-				   [pnz] "=&v"(vt[2]), [pfx] "=&v"(vt[3]), [pfy] "=&v"(vt[4]), [pfz] "=&v"(vt[5]), [t0] "=&v"(vt[6]), [t1] "=&v"(vt[7]),   \
+				   [width] "=&s"(sWidth), [topw] "=&s"(sTopw), [alive] "=&s"(sAlive), PREVARS() [t0] "=&v"(vt[6]), [t1] "=&v"(vt[7]),   \
 				   [t2] "=&v"(vt[8]), [t3] "=&v"(vt[9]), [t4] "=&v"(vt[10]), [t5] "=&v"(vt[11]), [s0] "=&v"(vt[12]), [s1] "=&v"(vt[13]),   \
 				   [s2] "=&v"(vt[14]), [s3] "=&v"(vt[15]), [u0] "=&v"(vt[16])                                                              \
 				 : [base] "s"(nodeBase), [sign16] "s"(sign16), [lane] "v"(lane), ORGOPS(), [ix0] "v"(Q.id[0][0]), [ix1] "v"(Q.id[0][1]), [ix2] "v"(Q.id[0][2]), [ix3] "v"(Q.id[0][3]),        \
@@ -1374,10 +1380,30 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				   [iz1] "v"(Q.id[2][1]), [iz2] "v"(Q.id[2][2]), [iz3] "v"(Q.id[2][3]), [d0] "v"(Q.dist[0]), [d1] "v"(Q.dist[1]),          \
 				   [d2] "v"(Q.dist[2]), [d3] "v"(Q.dist[3])                                                                                \
 				 : "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", \
-				   "s88", "s89", "s90", "s91", "vcc", "scc", "m0");                                                                        \
+				   "s88", "s89", "s90", "s91", "vcc", "scc", "m0" EXTRACLOB);                                                                        \
 	asm volatile("" ::"s"(sp), "s"(first), "s"(last), "s"(cnt), "v"(stkN), "v"(stkF), "s"(leafSub), "s"(leafAux), "s"(sCur), "s"(sFl), "s"(sOff),    \
-				 "s"(sWidth), "s"(sTopw), "s"(sAlive), "v"(vt[0]), "v"(vt[1]), "v"(vt[2]), "v"(vt[3]), "v"(vt[4]), "v"(vt[5]), "v"(vt[6]), "v"(vt[7]), \
+				 "s"(sWidth), "s"(sTopw), "s"(sAlive), "v"(vt[6]), "v"(vt[7]), \
 				 "v"(vt[8]), "v"(vt[9]), "v"(vt[10]), "v"(vt[11]), "v"(vt[12]), "v"(vt[13]), "v"(vt[14]), "v"(vt[15]), "v"(vt[16]))
+// the six plane-offset registers of SNAIL_PRE_SHARED are operands only where a visit forms them (PREVARS = SNAIL_PREVARS_of(PRE))
+#define SNAIL_PREVARS_SHARED() [pnx] "=&v"(vt[0]), [pny] "=&v"(vt[1]), [pnz] "=&v"(vt[2]), [pfx] "=&v"(vt[3]), [pfy] "=&v"(vt[4]), [pfz] "=&v"(vt[5]),
+#define SNAIL_PREVARS_NONE() [pnx] "=&v"(vt[0]), [pny] "=&v"(vt[1]), [pnz] "=&v"(vt[2]), [pfx] "=&v"(vt[3]), [pfy] "=&v"(vt[4]), [pfz] "=&v"(vt[5]),   /* (unused, but without them this compiler ends in "illegal VGPR to SGPR copy") */
+#define SNAIL_PREVARS_SNAIL_PRE_SHARED SNAIL_PREVARS_SHARED
+#define SNAIL_PREVARS_SNAIL_PRE_NONE SNAIL_PREVARS_NONE
+#define SNAIL_PREVARS_SNAIL_PRE_SEL SNAIL_PREVARS_NONE
+#define SNAIL_PREVARS_of(PRE) SNAIL_PREVARS_##PRE
+#define SNAIL_DESCEND_PF2(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)                 \
+	SNAIL_DESCEND_PF2X(, SNAIL_PREVARS_of(PRE), PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)
+// coherent packets WITHOUT one statement per sign octant: the near / far plane of each axis is picked on the scalar side, per visit, into
+// s62..s67 (nine scalar instructions that issue beside the visit's vector ones) -- for walks whose leaf code leaves the compiler no room
+// for eight copies of this loop (per-ray origins)
+#define SNAIL_PRE_SEL(NX, FX, NY, FY, NZ, FZ)                                                                                               \
+				 " s_bitcmp1_b32 %[sign16], 8\n s_cselect_b32 s62, " FX ", " NX "\n s_cselect_b32 s65, " NX ", " FX "\n"                       \
+				 " s_bitcmp1_b32 %[sign16], 9\n s_cselect_b32 s63, " FY ", " NY "\n s_cselect_b32 s66, " NY ", " FY "\n"                       \
+				 " s_bitcmp1_b32 %[sign16], 10\n s_cselect_b32 s64, " FZ ", " NZ "\n s_cselect_b32 s67, " NZ ", " FZ "\n"
+#define SNAIL_SLABO_SEL(L, NX, FX, NY, FY, NZ, FZ) SNAIL_SLABO_COH(L, "s62", "s65", "s63", "s66", "s64", "s67")
+#define SNAIL_SEL_CLOB , "s62", "s63", "s64", "s65", "s66", "s67"
+#define SNAIL_DESCEND_PF2_SEL(ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ)                                                                \
+	SNAIL_DESCEND_PF2X(SNAIL_SEL_CLOB, SNAIL_PREVARS_NONE, SNAIL_PRE_SEL, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s84", "s87", "s85", "s88", "s86", "s89", "s76", "s79", "s77", "s80", "s78", "s81")
 #define SNAIL_DESCEND_PF2_PLAIN(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ) SNAIL_DESCEND_PF2(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s84", "s87", "s85", "s88", "s86", "s89", "s76", "s79", "s77", "s80", "s78", "s81")
 #define SNAIL_DESCEND_PF2_OCT(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, OCT)                                                                                                    \
 	switch(OCT) {                                                                                                                          \
@@ -1528,12 +1554,16 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /*
 
 // closest hit of a packet with per-ray origins (TraversePrimaryN<0,mask>), node loop in assembly as in walkSharedAsm; any
 // distance on entry (masked lanes -inf), `size` quads
+#ifndef SNAIL_PERRAY_COH_PF
+#define SNAIL_PERRAY_COH_PF SNAIL_DEFER_PUSH // coherent per-ray-origin packets (most mirrored packets) through the prefetching loop as well (SNAIL_DESCEND_PF2_SEL)
+#endif
 template <bool MASK, bool COH, bool BARY, bool PACK>
 __device__ __forceinline__ void walkPerRayAsm(const uint4 *__restrict__ nodes /* PACK and not COH: the prefetching loop's copy */, const uint4 *__restrict__ tris, int size, int lane, const float (&org)[3][4],
 											  Quad &Q, unsigned mask4, int (&tid)[4], float (&bu)[4], float (&bv)[4], Counters &st, const int oct) {
 	const int signBits = __builtin_amdgcn_readfirstlane((Q.d[0][0] < 0.0f ? 1 : 0) | (Q.d[1][0] < 0.0f ? 2 : 0) | (Q.d[2][0] < 0.0f ? 4 : 0));
-	constexpr bool PF = PACK && SNAIL_NODE_PREFETCH && !COH;   // (coherent packets keep the plain two-word loop over the caller's records)
-	const int sign16 = PF ? signBits : signBits << 16;
+	constexpr bool PF = PACK && SNAIL_NODE_PREFETCH && (SNAIL_PERRAY_COH_PF || !COH);   // (SNAIL_PERRAY_COH_PF 0: coherent packets keep the plain two-word loop over the caller's records)
+	// PF: bits 0..2 = the signs of lane 0's first ray (child order, as the reference takes it); bits 8..10 = the packet's sign octant (plane selection of SNAIL_PRE_SEL)
+	const int sign16 = PF ? (COH ? signBits | __builtin_amdgcn_readfirstlane(oct) << 8 : signBits) : signBits << 16;
 	const u64 nodeBase = (u64)nodes;
 	int stkN = PF ? (int)((unsigned)(size - 1) << 26) | 1 : 0, stkF = (size - 1) << 8; // stack slot 0 = the root (PF: record slot 1) with the full quad range
 	int sp = 1, first = 0, last = size - 1, cnt = 0;
@@ -1547,7 +1577,8 @@ __device__ __forceinline__ void walkPerRayAsm(const uint4 *__restrict__ nodes /*
 			// copies of it beside the per-ray leaf code ("illegal VGPR to SGPR copy": the scalar-register pressure of the 16-SGPR triangle
 			// record plus three node record sets); coherent packets keep the plain loop.
 			int sTopw;
-			SNAIL_WALK_PF_PLAIN(SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_TRI);
+			if(COH) { SNAIL_DESCEND_PF2_SEL(SNAIL_ORG_PERRAY, SNAIL_SLABO_SEL, SNAIL_TAIL_ANY, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_TRI); }
+			else { SNAIL_WALK_PF_PLAIN(SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_TRI); }
 		} else if(COH) { SNAIL_DESCEND_OCT(SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_COH, SNAIL_TAIL_ANY, SNAIL_COUNT, "", oct) }
 		else { SNAIL_DESCEND_ASM(SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, "", "s84", "s87", "s85", "s88", "s86", "s89"); }
 		if(leafSub == 0) break;
@@ -2466,7 +2497,7 @@ __device__ __forceinline__ void raysPacket(const RaysArgs &A, const int p, float
 		}
 		if(!SHARED && !DEEP) { // per-ray origins: the hand-written node loop
 			if(A.pack) {
-				if(mode == M_COH) walkPerRayAsm<MASK, true, BARY, true>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, st, oct);
+				if(mode == M_COH) walkPerRayAsm<MASK, true, BARY, true>(SNAIL_PERRAY_COH_PF ? SNAIL_PACK_NODES(A) : A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, st, oct);
 				else walkPerRayAsm<MASK, false, BARY, true>(SNAIL_PACK_NODES(A), A.tris, size, lane, org, Q, mask4, tid, bu, bv, st, 0);
 			} else if(mode == M_COH) walkPerRayAsm<MASK, true, BARY, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, st, oct);
 			else walkPerRayAsm<MASK, false, BARY, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, st, 0);
@@ -2488,10 +2519,16 @@ __device__ __forceinline__ void raysPacket(const RaysArgs &A, const int p, float
 	}
 }
 #ifndef SNAIL_RAYS_WAVES
-#define SNAIL_RAYS_WAVES 6 // occupancy target of the generic-packet kernels (the per-ray-origin walk compiles to 85 VGPRs = 5 waves by itself)
+#define SNAIL_RAYS_WAVES 0 // occupancy target of the generic-packet kernels; 0 = the compiler's own allocation (no spills: these kernels keep lane-indexed state
+						   // in VGPRs and the soak runs are made on spill-free code; a forced six-wave budget -- 80 VGPRs, up to 88 spilled -- measured no gain)
+#endif
+#if SNAIL_RAYS_WAVES > 0
+#define SNAIL_RAYS_OCCUPANCY __attribute__((amdgpu_waves_per_eu(SNAIL_RAYS_WAVES)))
+#else
+#define SNAIL_RAYS_OCCUPANCY
 #endif
 template <bool SHARED, bool MASK, bool DEEP, bool BARY>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SNAIL_RAYS_WAVES))) void k_rays(RaysArgs A) {
+__global__ __launch_bounds__(64) SNAIL_RAYS_OCCUPANCY void k_rays(RaysArgs A) {
 	__shared__ float lds[LDS_FLOATS_PER_WAVE];
 	raysPacket<SHARED, MASK, DEEP, BARY, false>(A, interleave16((int)blockIdx.x), lds);
 }

@@ -1,6 +1,6 @@
 """Long seeded fuzz run (not collected by pytest; uses the oracle, hence lives under tests/): random cameras, frame sizes, lights,
 scenes and tree builders, GPU hit records / staged config-3 frames / counters against the oracle, bit for bit.
-Usage: python tests/soak_fuzz.py [cases] [seed]"""
+Usage: python tests/soak_fuzz.py [cases] [seed] [focus]   (focus = "refl": the stress scene with the mirrored bounce only, differences printed)"""
 import math, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -10,6 +10,7 @@ from tests import oracle_lib as O, util
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+focus = sys.argv[3] if len(sys.argv) > 3 else ""
 rng = np.random.RandomState(seed)
 names = ["atrium:0.05", "stress:0.05", "box", "chain", "atrium:0.02"]
 scn = {}
@@ -19,6 +20,7 @@ for n in names:
 bad = 0; t0 = time.time()
 for case in range(cases):
     name = names[rng.randint(len(names))]
+    if focus == "refl": name = "stress:0.05"
     tv, sc, osc = scn[name]
     bmin, bmax = osc.nodes[0]["bmin"], osc.nodes[0]["bmax"]
     c, e = (bmin + bmax) * 0.5, (bmax - bmin)
@@ -32,6 +34,7 @@ for case in range(cases):
     ok = all(np.array_equal(g.cpu().numpy().view(np.uint32), w.view(np.uint32)) for g, w in zip((fr.t, fr.u, fr.v, fr.tri_id), want[:4]))
     ok = ok and np.array_equal(st.cpu().numpy().astype(np.uint64), want[4])
     nl = int(rng.randint(0, 4)); refl = bool(rng.rand() < 0.5)
+    if focus == "refl": refl = True
     lights = np.zeros((nl, 7), dtype=np.float32)
     for k in range(nl):
         lights[k, :3] = c + (rng.rand(3) - 0.5) * e * 1.2
@@ -41,6 +44,12 @@ for case in range(cases):
     ok2 = np.array_equal(img.cpu().numpy(), wimg) and np.array_equal(st.cpu().numpy().astype(np.uint64), wst)
     if not (ok and ok2):
         bad += 1
+        if focus:
+            g = img.cpu().numpy(); w = np.flatnonzero((g != wimg).any(axis=-1).ravel()) if g.shape == wimg.shape else []
+            print("  pixels differing: %d of %d, first %s; stats gpu %s oracle %s" % (len(w), g.shape[0] * g.shape[1], w[:6], st.cpu().numpy().astype(np.uint64), wst), flush=True)
+            # a second run of the same frame: does the device agree with itself?
+            st2 = sc.new_stats(); img2 = sc.render_whitted(cam, resx, resy, lights, stats=st2, reflections=refl); torch.cuda.synchronize()
+            print("  rerun equals first run: %s, equals oracle: %s" % (bool(torch.equal(img, img2)), np.array_equal(img2.cpu().numpy(), wimg)), flush=True)
         print("MISMATCH case %d: %s %dx%d primary_ok=%s whitted_ok=%s nl=%d refl=%s pos=%s yaw=%.4f pitch=%.4f" % (case, name, resx, resy, ok, ok2, nl, refl, pos, yaw, pitch), flush=True)
     if case % 100 == 99:
         print("%d cases, %d mismatches, %.0f s" % (case + 1, bad, time.time() - t0), flush=True)

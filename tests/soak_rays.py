@@ -1,6 +1,6 @@
 """Seeded soak of the generic entry points (not collected by pytest): random batches of secondary packets (shared / per-ray origins,
 lane masks, packet sizes 1..64, optional non-finite poison -> M_EXACT deferral) and shadow packets, GPU against the oracle bit for bit.
-Usage: python tests/soak_rays.py [batches] [seed]"""
+Usage: python tests/soak_rays.py [batches] [seed] [focus]   (focus = "perray": per-ray-origin masked packet batches only, "perray1": those with 1..3 quads per packet; differences are printed)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,6 +9,7 @@ from tests import oracle_lib as O, util
 
 batches = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+focus = sys.argv[3] if len(sys.argv) > 3 else ""
 rng = np.random.RandomState(seed)
 names = ["atrium:0.05", "stress:0.05", "chain"]
 scn = {}
@@ -22,8 +23,10 @@ for b in range(batches):
     tv, sc, osc, cam = scn[name]
     size = int([64, 64, 64, 16, 1, rng.randint(1, 65)][rng.randint(6)])
     npk = int(rng.randint(1, 40))
-    if rng.rand() < 0.7:
+    if rng.rand() < 0.7 or focus.startswith("perray"):
         shared, masked, poison = bool(rng.rand() < 0.5), bool(rng.rand() < 0.5), bool(rng.rand() < 0.15)
+        if focus.startswith("perray"): shared, masked, poison = False, True, False
+        if focus == "perray1": size = int(rng.randint(1, 4))   # tiny packets: where the round-3 soak saw its mismatches
         if poison and size < 3: poison = False
         origin, dirs, idir, mask, dist, obj, bary = util.secondary_packets(osc, cam, 640, 368, npk, seed=int(rng.randint(1 << 30)), shared=shared, masked=masked,
                                                                            size=size, poison=poison)
@@ -36,6 +39,15 @@ for b in range(batches):
         ok = (np.array_equal(ctx.object.cpu().numpy(), o2) and np.array_equal(ctx.distance.cpu().numpy().view(np.uint32), d2.view(np.uint32)) and
               np.array_equal(ctx.barycentric.cpu().numpy().view(np.uint32), b2.view(np.uint32)) and s[0] == ost[0] and s[1] == ost[1])
         what = "rays shared=%s masked=%s size=%d poison=%s npk=%d" % (shared, masked, size, poison, npk)
+        if not ok:
+            go, gd, gb = ctx.object.cpu().numpy(), ctx.distance.cpu().numpy(), ctx.barycentric.cpu().numpy()
+            wo, wd, wb = np.flatnonzero(go.ravel() != o2.ravel()), np.flatnonzero(gd.ravel().view(np.uint32) != d2.ravel().view(np.uint32)), np.flatnonzero(gb.ravel().view(np.uint32) != b2.ravel().view(np.uint32))
+            what += " | object differs at %d %s dist at %d %s bary at %d %s stats gpu %s oracle %s" % (len(wo), wo[:4], len(wd), wd[:4], len(wb), wb[:4], s[:4], [int(x) for x in ost[:4]])
+            ctx2 = Context(tt(origin).cuda(), tt(dirs).cuda(), tt(idir).cuda(), tt(dist.copy()).cuda(), tt(obj.copy()).cuda(), tt(bary.copy()).cuda(),
+                           size=size, shared_origin=shared, mask=None if mask is None else tt(mask).cuda())
+            st2 = sc.new_stats(); sc.traverse_primary(ctx2, stats=st2); torch.cuda.synchronize()
+            what += " | rerun: object equal to first run %s, to oracle %s; stats %s" % (bool(torch.equal(ctx2.object, ctx.object)), np.array_equal(ctx2.object.cpu().numpy(), o2), st2.cpu().numpy()[:2])
+            if len(wd): what += " | dist gpu %s oracle %s obj gpu %s oracle %s" % (gd.ravel()[wd[:3]], d2.ravel()[wd[:3]], go.ravel()[wd[:3]], o2.ravel()[wd[:3]])
     else:
         origin, dirs, idir, dist = util.shadow_packets(osc, npk, seed=int(rng.randint(1 << 30)), size=size)
         d2 = dist.copy()
