@@ -1572,10 +1572,10 @@ __device__ __forceinline__ void walkPerRayAsm(const uint4 *__restrict__ nodes /*
 		u64 sRng, sAlive;
 		float vt[17];
 		if(PF) {
-			// non-coherent packets (the heavy ones among the mirrored packets): one-word stack entries + node records fetched ahead.  The
-			// coherent form would need the prefetching loop once per sign octant, and this compiler cannot place eight (or even two)
-			// copies of it beside the per-ray leaf code ("illegal VGPR to SGPR copy": the scalar-register pressure of the 16-SGPR triangle
-			// record plus three node record sets); coherent packets keep the plain loop.
+			// one-word stack entries + node records fetched ahead.  Non-coherent packets: the plain form of the loop.  Coherent packets would need the
+			// loop once per sign octant, and this compiler cannot place eight (or even two) copies of it beside the per-ray leaf code ("illegal VGPR
+			// to SGPR copy": the scalar-register pressure of the 16-SGPR triangle record plus three node record sets): they take ONE statement in
+			// which the near / far planes are picked per visit on the scalar side (SNAIL_DESCEND_PF2_SEL).
 			int sTopw;
 			if(COH) { SNAIL_DESCEND_PF2_SEL(SNAIL_ORG_PERRAY, SNAIL_SLABO_SEL, SNAIL_TAIL_ANY, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_TRI); }
 			else { SNAIL_WALK_PF_PLAIN(SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_TRI); }
