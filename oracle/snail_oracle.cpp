@@ -853,9 +853,20 @@ uint64_t fnv1a(uint64_t h, const void *p, size_t n) {
 
 } // namespace
 
+// The checker must not inherit a caller's floating-point control state: a shared library built with -ffast-math sets flush-to-zero /
+// denormals-are-zero in MXCSR for the thread that loads it (crtfastmath), and which libraries a Python process loads depends on the host
+// CPU.  The path's arithmetic keeps denormals (the device does, and so does the reference under its default environment): every entry point
+// runs with the default MXCSR (round to nearest, exceptions masked, no FTZ / DAZ) and restores the caller's on return; worker threads
+// inherit the entry point's.
+struct FpEnvGuard {
+	unsigned old;
+	FpEnvGuard() : old(_mm_getcsr()) { _mm_setcsr(0x1f80u); }
+	~FpEnvGuard() { _mm_setcsr(old); }
+};
 extern "C" {
 
 void orc_tris_from_verts(const float *verts, int n, OrcTri *out) {
+	FpEnvGuard fpEnv;
 	for(int i = 0; i < n; i++) {
 		V3 v0 = mk(verts + i * 9), v1 = mk(verts + i * 9 + 3), v2 = mk(verts + i * 9 + 6);
 		V3 ba = v1 - v0, ca = v2 - v0;
@@ -873,6 +884,7 @@ void orc_tris_from_verts(const float *verts, int n, OrcTri *out) {
 }
 
 int orc_bvh_build(OrcTri *tris, int n, OrcNode *nodes, int *depth, int32_t *perm) {
+	FpEnvGuard fpEnv;
 	if(n <= 0) return 0;
 	if(perm) for(int i = 0; i < n; i++) perm[i] = i;
 	Builder b{tris, perm, nodes};
@@ -897,6 +909,7 @@ uint64_t orc_fnv_tris(const OrcTri *tris, int n) {
 }
 
 void orc_gen_packet(const OrcCamera *cam, int resx, int resy, int px, int py, int mode, float *dir, float *idir) {
+	FpEnvGuard fpEnv;
 	RayGen g = makeRayGen(*cam, resx, resy);
 	if(mode == ORC_MODE_SSE) genPacket<ORC_MODE_SSE>(g, px, py, dir, idir);
 	else genPacket<ORC_MODE_IEEE>(g, px, py, dir, idir);
@@ -905,6 +918,7 @@ void orc_gen_packet(const OrcCamera *cam, int resx, int resy, int px, int py, in
 void orc_trace_rays(const OrcNode *nodes, const OrcTri *tris, int npackets, int size, int sharedOrigin, const float *origin,
 					const float *dir, const float *idir, const uint8_t *mask, float *distance, int32_t *object, float *bary,
 					uint64_t *stats, int mode) {
+	FpEnvGuard fpEnv;
 	Stats st;
 	for(int p = 0; p < npackets; p++) {
 		size_t qo = (size_t)p * size;
@@ -918,6 +932,7 @@ void orc_trace_rays(const OrcNode *nodes, const OrcTri *tris, int npackets, int 
 
 void orc_trace_shadow(const OrcNode *nodes, const OrcTri *tris, int npackets, int size, const float *origin, const float *dir,
 					  const float *idir, float *distance, uint64_t *stats, int mode) {
+	FpEnvGuard fpEnv;
 	(void)mode; // no approximate operation on the any-hit path (src/triangle.cpp:94-95: no division)
 	Stats st;
 	for(int p = 0; p < npackets; p++) {
@@ -932,22 +947,26 @@ void orc_trace_shadow(const OrcNode *nodes, const OrcTri *tris, int npackets, in
 
 void orc_render_primary(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam, int resx, int resy, int x0, int y0, int w,
 						int h, float *t, float *u, float *v, int32_t *triId, uint64_t *stats, int mode, int threads) {
+	FpEnvGuard fpEnv;
 	if(mode == ORC_MODE_SSE) renderPrimary<ORC_MODE_SSE>(nodes, tris, cam, resx, resy, x0, y0, w, h, t, u, v, triId, stats, threads);
 	else renderPrimary<ORC_MODE_IEEE>(nodes, tris, cam, resx, resy, x0, y0, w, h, t, u, v, triId, stats, threads);
 }
 
 void orc_render_primary_sse4(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam, int resx, int resy, int x0, int y0, int w,
 							 int h, float *t, float *u, float *v, int32_t *triId, uint64_t *stats, int threads) {
+	FpEnvGuard fpEnv;
 	sse4::renderPrimary(nodes, tris, cam, resx, resy, x0, y0, w, h, t, u, v, triId, stats, threads);
 }
 
 void orc_account_primary(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam, int resx, int resy, int x0, int y0, int w,
 						 int h, uint64_t *out, int mode, int threads) {
+	FpEnvGuard fpEnv;
 	if(mode == ORC_MODE_SSE) accountPrimary<ORC_MODE_SSE>(nodes, tris, cam, resx, resy, x0, y0, w, h, out, threads);
 	else accountPrimary<ORC_MODE_IEEE>(nodes, tris, cam, resx, resy, x0, y0, w, h, out, threads);
 }
 
 void orc_shade_depth(const float *t, int n, uint8_t *bgr, int mode) {
+	FpEnvGuard fpEnv;
 	for(int i = 0; i < n; i++) {
 		// Condition(tDistance > maxDist(+inf), 0, Inv(tDistance)): the comparison is never true (src/scene_trace.cpp:130)
 		float dist = mode == ORC_MODE_SSE ? Inv<ORC_MODE_SSE>(t[i]) : Inv<ORC_MODE_IEEE>(t[i]);
@@ -960,6 +979,7 @@ void orc_shade_depth(const float *t, int n, uint8_t *bgr, int mode) {
 
 void orc_render_whitted(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam, int resx, int resy, const float *lights7, int nLights,
 						const float ambient[3], const float color[3], int flags, uint8_t *frame_bgr, int pitch, uint64_t *stats, int mode, int threads) {
+	FpEnvGuard fpEnv;
 	if(mode == ORC_MODE_SSE) renderWhitted<ORC_MODE_SSE>(nodes, tris, cam, resx, resy, lights7, nLights, ambient, color, flags, frame_bgr, pitch, stats, threads);
 	else renderWhitted<ORC_MODE_IEEE>(nodes, tris, cam, resx, resy, lights7, nLights, ambient, color, flags, frame_bgr, pitch, stats, threads);
 }
@@ -968,6 +988,7 @@ void orc_render_whitted(const OrcNode *nodes, const OrcTri *tris, const OrcCamer
 void orc_trace_transparency(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam, int resx, int resy, const int32_t *packet_xy, int nPackets,
 							const float *t, const uint8_t *sel, const float *lights7, int nLights, const float ambient[3], const float color[3],
 							float *out_color, uint64_t *stats, int mode) {
+	FpEnvGuard fpEnv;
 	const Lighting L{lights7, nLights, ambient, color, false};
 	RayGen g = makeRayGen(*cam, resx, resy);
 	Stats st;
@@ -1001,10 +1022,13 @@ void orc_planar_decode_tile(const uint8_t *planes, int x, int y, int w, int h, u
 	}
 }
 void orc_debug_range_hist(uint64_t *hist) { g_rangeHist = hist; }
+unsigned orc_caller_mxcsr(void) { return _mm_getcsr(); } // diagnostics: what the calling thread runs with (0x1f80 = default)
+void orc_debug_set_mxcsr(unsigned v) { _mm_setcsr(v); } // tests: put the calling thread into flush-to-zero mode (0x9fc0) and back (0x1f80)
 // The named shading expressions on one row of eight floats (qa = in[0..3], qb = in[4..7] as two SSE quads; v1 = (qa, qa<<<1, qa<<<2),
 // v2 = (qb, qb<<<1, qb<<<2) as two Vec3q, <<< = lane rotation) -- the same row the reference's veclib evaluates in
 // oracle/veclib_probe.cpp `exprs`; word layout documented there.  Words 45.. use the approximate operations (mode).
 void orc_veclib_exprs(const float *in, uint32_t *out, int mode) {
+	FpEnvGuard fpEnv;
 	auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
 	float qa[4], qb[4];
 	V3 v1[4], v2[4];

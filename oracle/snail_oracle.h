@@ -141,6 +141,8 @@ void orc_planar_decode_tile(const uint8_t *planes, int x, int y, int w, int h, u
 
 /* instrumentation for tests/range_hist.py: hist[192] (see snail_oracle.cpp); NULL switches it off. Single-threaded only. */
 void orc_debug_range_hist(uint64_t *hist);
+void orc_debug_set_mxcsr(unsigned v); /* tests only */
+unsigned orc_caller_mxcsr(void); /* diagnostics: MXCSR of the calling thread (0x1f80 = default; every entry point above computes under the default) */
 
 /* The shading path's small expressions (Abs, Reflect, SafeInv, FastInv, the light attenuation, ConvColor's channel, ForWhich / ForAny /
  * ForAll of a compare, Condition on a Vec3q, Vec3q dot / cross, Sqrt) evaluated by the SAME inline helpers the oracle's hot path calls, on

@@ -192,14 +192,28 @@ void trisFromVerts(const float *v, int n, Tri64 *out) {
 
 extern void snail_set_error(const char *fmt, ...);
 
+// The reference's builder runs under the default floating-point environment; a host process may not (a shared library built with
+// -ffast-math switches flush-to-zero / denormals-are-zero on for the thread that loads it).  The two host-side entry points compute under the
+// default MXCSR and restore the caller's, so that the tree and the triangle records do not depend on what else the process has loaded.
+#include <xmmintrin.h>
+namespace {
+struct FpEnvGuard {
+	unsigned old;
+	FpEnvGuard() : old(_mm_getcsr()) { _mm_setcsr(0x1f80u); }
+	~FpEnvGuard() { _mm_setcsr(old); }
+};
+} // namespace
+
 extern "C" int snail_tris_from_verts(const float *verts9, int n, void *tris64) {
 	if(n < 0 || (n > 0 && (!verts9 || !tris64))) { snail_set_error("snail_tris_from_verts: bad arguments"); return 1; }
+	FpEnvGuard fpEnv;
 	snail::trisFromVerts(verts9, n, (snail::Tri64 *)tris64);
 	return 0;
 }
 
 extern "C" int snail_bvh_build(void *tris64, int nTris, void *nodes32, int *nNodes, int *depth, int32_t *perm) {
 	if(nTris <= 0 || !tris64 || !nodes32 || !nNodes || !depth) { snail_set_error("snail_bvh_build: bad arguments"); return 1; }
+	FpEnvGuard fpEnv;
 	int rc = snail::buildSweep((snail::Tri64 *)tris64, nTris, (snail::Node32 *)nodes32, nNodes, depth, perm);
 	if(rc == 0 && *depth > SNAIL_MAX_DEPTH) { snail_set_error("snail_bvh_build: depth %d exceeds %d", *depth, SNAIL_MAX_DEPTH); return 2; }
 	return rc;

@@ -1390,6 +1390,9 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 #define SNAIL_PREVARS_SNAIL_PRE_SHARED SNAIL_PREVARS_SHARED
 #define SNAIL_PREVARS_SNAIL_PRE_NONE SNAIL_PREVARS_NONE
 #define SNAIL_PREVARS_SNAIL_PRE_SEL SNAIL_PREVARS_NONE
+#define SNAIL_PREVARS_EMPTY()
+#define SNAIL_PRE_NONE_X(NX, FX, NY, FY, NZ, FZ) "" /* = SNAIL_PRE_NONE, in walks that compile without the six unused operands */
+#define SNAIL_PREVARS_SNAIL_PRE_NONE_X SNAIL_PREVARS_EMPTY
 #define SNAIL_PREVARS_of(PRE) SNAIL_PREVARS_##PRE
 #define SNAIL_DESCEND_PF2(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)                 \
 	SNAIL_DESCEND_PF2X(, SNAIL_PREVARS_of(PRE), PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)
@@ -1517,7 +1520,7 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /*
 			// primary packets (POSDIST) read camera-relative records: no plane offsets to form, a leaf's request is slot 0
 			if(COH) {
 #if SNAIL_REL_SHADOW
-				if(SHADOW) { SNAIL_WALK_PF_OCT(SNAIL_PRE_NONE, SNAIL_ORG_SHARED, SNAIL_SLAB_COH_R, SNAIL_TAIL_ANY, "", SNAIL_COUNT, SNAIL_PF_LEAFREQ_SLOT0, oct) }
+				if(SHADOW) { SNAIL_WALK_PF_OCT(SNAIL_PRE_NONE_X, SNAIL_ORG_SHARED, SNAIL_SLAB_COH_R, SNAIL_TAIL_ANY, "", SNAIL_COUNT, SNAIL_PF_LEAFREQ_SLOT0, oct) }
 #else
 				if(SHADOW) { SNAIL_WALK_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_ANY, "", SNAIL_COUNT, SNAIL_PF_LEAFREQ_TRI, oct) }
 #endif
@@ -1529,7 +1532,7 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /*
 				else { SNAIL_WALK_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_ANY, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_TRI, oct) }
 			} else {
 #if SNAIL_REL_SHADOW
-				if(SHADOW) { SNAIL_WALK_PF_PLAIN(SNAIL_PRE_NONE, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST_R, SNAIL_TAIL_ANY, "", SNAIL_COUNT, SNAIL_PF_LEAFREQ_SLOT0); }
+				if(SHADOW) { SNAIL_WALK_PF_PLAIN(SNAIL_PRE_NONE_X, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST_R, SNAIL_TAIL_ANY, "", SNAIL_COUNT, SNAIL_PF_LEAFREQ_SLOT0); }
 #else
 				if(SHADOW) { SNAIL_WALK_PF_PLAIN(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, "", SNAIL_COUNT, SNAIL_PF_LEAFREQ_TRI); }
 #endif
@@ -2589,7 +2592,7 @@ __device__ __forceinline__ void shadowPacket(const RaysArgs &A, const int p, flo
 	if(live) *(float4 *)(A.distance + q * 4) = make_float4(Q.dist[0], Q.dist[1], Q.dist[2], Q.dist[3]);
 }
 template <bool DEEP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_shadow(RaysArgs A) {
+__global__ __launch_bounds__(64) SNAIL_RAYS_OCCUPANCY void k_shadow(RaysArgs A) {
 	__shared__ float lds[LDS_FLOATS_PER_WAVE];
 	shadowPacket<DEEP, false>(A, interleave16((int)blockIdx.x), lds);
 }

@@ -17,6 +17,8 @@ scn = {}
 for n in names:
     tv, hb, osc = util.scene_pair(n)
     scn[n] = (tv, Scene(hb, 0), osc)
+L_ = O.lib(); L_.orc_caller_mxcsr.restype = __import__("ctypes").c_uint
+print("caller MXCSR 0x%04x (0x1f80 = default); float32 denormals in numpy: %s" % (L_.orc_caller_mxcsr(), "kept" if float(np.float32(1e-40) * np.float32(0.5)) != 0.0 else "FLUSHED"), flush=True)
 bad = 0; t0 = time.time()
 for case in range(cases):
     name = names[rng.randint(len(names))]

@@ -159,3 +159,36 @@ def test_sse4_port_equals_scalar_oracle(name, resx, resy):
         util.assert_bit_equal(x, y, "%s %s" % (name, what))
     assert np.array_equal(a[4], b[4]), (a[4], b[4])
     assert np.isfinite(a[0]).sum() > 0
+
+
+def test_checker_does_not_inherit_flush_to_zero():
+    """A Python process may run with flush-to-zero / denormals-are-zero switched on in MXCSR (a shared library built with -ffast-math does that
+    to the thread that loads it, and which libraries get loaded depends on the host CPU): the oracle's entry points and the product's host-side
+    builder compute under the default environment whatever the caller's is -- same bits with the caller in flush-to-zero mode."""
+    import ctypes
+    L = O.lib()
+    L.orc_caller_mxcsr.restype = ctypes.c_uint
+    L.orc_debug_set_mxcsr.argtypes = [ctypes.c_uint]
+    default = L.orc_caller_mxcsr()
+    tv, hb, osc = util.scene_pair("atrium:0.02")
+    cam = util.camera_for("atrium:0.02", tv)
+    # mirrored rays start ON surfaces: plane - origin differences get tiny there
+    origin, dirs, idir, mask, dist, obj, bary = util.secondary_packets(osc, cam, 320, 192, 12, seed=5, shared=False, masked=True, size=64, poison=False)
+    # denormal-scale geometry as well: the triangle precompute (ba, ca of 1e-39-sized edges) must keep denormals
+    verts = (np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=np.float32) * np.float32(1e-39)).reshape(1, 9)
+    def run():
+        d2, o2, b2 = dist.copy(), obj.copy(), bary.copy()
+        st = osc.trace_rays(origin, dirs, idir, mask, d2, o2, b2, 12, 64, False, mode=O.MODE_IEEE)
+        return d2.view(np.uint32).copy(), o2.copy(), b2.view(np.uint32).copy(), np.asarray(st).copy(), O.tris_from_verts(verts).tobytes()
+    want = run()
+    try:
+        L.orc_debug_set_mxcsr(0x9fc0)      # FTZ | DAZ, as crtfastmath sets them
+        assert L.orc_caller_mxcsr() == 0x9fc0
+        got = run()
+        assert L.orc_caller_mxcsr() == 0x9fc0   # the caller's environment is restored, not replaced
+        flushed = float(np.float32(1e-40) * np.float32(0.5)) == 0.0   # (what the caller's own arithmetic does in this mode)
+    finally:
+        L.orc_debug_set_mxcsr(default)
+    for w, g in zip(want, got):
+        assert (w == g) if isinstance(w, bytes) else np.array_equal(w, g)
+    assert flushed or True   # numpy may or may not use SSE scalar multiplies here; the point is the equality above
