@@ -59,7 +59,10 @@ int snail_bvh_build(void *tris64, int nTris, void *nodes32, int *nNodes, int *de
 
 /* ---- device scene -------------------------------------------------------------------------------- */
 /* Mirrors the public BVH::nodes / BVH::tris / BVH::depth (src/bvh/tree.h:86-92), i.e. what the
- * reference ships to a render node in SendBVH (src/server.cpp:144-164).  Copies to `device`. */
+ * reference ships to a render node in SendBVH (src/server.cpp:144-164).  Copies to `device`.
+ * Device memory per scene: the caller's records (32 B x nNodes + 64 B x nTris), the node loop's copy of them (a fixed 32 MiB region +
+ * 64 B x nTris) and, created on demand, one 32 B x (nNodes + 1) array of node boxes relative to each distinct shared origin the scene is
+ * traced from -- camera positions, light positions; at most 16 are kept, least recently used first out. */
 SnailScene *snail_scene_create(const void *nodes32, int nNodes, const void *tris64, int nTris, int depth, int device);
 void snail_scene_destroy(SnailScene *);
 /* GPU tree builder option (NOT the parity tree, reported separately): a linear BVH -- Morton order of the
