@@ -1434,3 +1434,64 @@ def test_big_leaf_under_a_narrow_range(torch_mod, resx, resy):
     assert hit_clump > 0
     sc.close()
 
+
+
+@pytest.mark.gpu
+def test_origin_relative_record_cache_over_many_origins(torch_mod):
+    """Shared-origin packets walk node records relative to their origin (camera / light position), kept per scene in an LRU cache of 16
+    arrays: 14 cameras x 3 lights each -- more distinct origins than the cache holds, entries recycled while earlier frames are still in
+    flight on the stream -- and the first views again at the end; every frame and its counters equal the oracle's."""
+    from snail_amd import FPSCamera
+    name = "atrium:0.02"
+    tv, sc, osc = gpu_scene(name)
+    bmin, bmax = osc.nodes[0]["bmin"], osc.nodes[0]["bmax"]
+    c, e = (bmin + bmax) * 0.5, (bmax - bmin)
+    rng = np.random.RandomState(11)
+    views = []
+    for k in range(14):
+        pos = (c + (rng.rand(3) - 0.5) * e * 0.8).astype(np.float32)
+        cam = FPSCamera(pos, float(rng.rand() * 6.28), float((rng.rand() - 0.5) * 0.8)).camera()
+        lights = np.zeros((3, 7), dtype=np.float32)
+        for n in range(3):
+            lights[n, :3] = c + (rng.rand(3) - 0.5) * e * 1.1
+            lights[n, 3:6] = rng.rand(3); lights[n, 6] = float(e.max()) * float(np.exp(rng.uniform(-1.5, 0.8)))
+        views.append((cam, lights))
+    views += views[:2]
+    frames = []
+    for cam, lights in views:                      # enqueue everything first: cache entries are recycled under frames in flight
+        st = sc.new_stats()
+        frames.append((sc.render_whitted(cam, 200, 120, lights, stats=st, reflections=False), st))
+    torch_mod.cuda.synchronize()
+    for (cam, lights), (img, st) in zip(views, frames):
+        want, wst = osc.render_whitted(cam.as_array13(), 200, 120, lights, mode=O.MODE_IEEE, reflections=False)
+        assert np.array_equal(img.cpu().numpy(), want)
+        assert np.array_equal(st.cpu().numpy().astype(np.uint64), wst)
+    sc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["stress:0.05", "atrium:0.05"])
+def test_tiny_masked_per_ray_origin_packets(torch_mod, name):
+    """Packets of one to three quads with lane masks and per-ray origins (what a mirrored bounce leaves of a packet that mostly missed):
+    400 seeded batches through the generic entry point, hit records, barycentrics and counters equal the oracle's -- the case a round-3
+    soak saw differ on one box (profiles/r3_final_soak.txt)."""
+    from snail_amd.scene import Context
+    tv, sc, osc = gpu_scene(name)
+    cam = util.camera_for(name, tv)
+    rng = np.random.RandomState(5)
+    tt = torch_mod.from_numpy
+    for b in range(400):
+        size, npk = int(rng.randint(1, 4)), int(rng.randint(1, 40))
+        origin, dirs, idir, mask, dist, obj, bary = util.secondary_packets(osc, cam, 640, 368, npk, seed=int(rng.randint(1 << 30)), shared=False, masked=True,
+                                                                           size=size, poison=False)
+        d2, o2, b2 = dist.copy(), obj.copy(), bary.copy()
+        ost = osc.trace_rays(origin, dirs, idir, mask, d2, o2, b2, npk, size, False, mode=O.MODE_IEEE)
+        ctx = Context(tt(origin).cuda(), tt(dirs).cuda(), tt(idir).cuda(), tt(dist.copy()).cuda(), tt(obj.copy()).cuda(), tt(bary.copy()).cuda(),
+                      size=size, shared_origin=False, mask=tt(mask).cuda())
+        st = sc.new_stats(); sc.traverse_primary(ctx, stats=st); torch_mod.cuda.synchronize()
+        s = st.cpu().numpy().astype(np.uint64)
+        assert np.array_equal(ctx.object.cpu().numpy(), o2), (b, size, npk)
+        assert np.array_equal(ctx.distance.cpu().numpy().view(np.uint32), d2.view(np.uint32)), (b, size, npk)
+        assert np.array_equal(ctx.barycentric.cpu().numpy().view(np.uint32), b2.view(np.uint32)), (b, size, npk)
+        assert s[0] == ost[0] and s[1] == ost[1], (b, size, npk, s, ost)
+    sc.close()
