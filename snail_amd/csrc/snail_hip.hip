@@ -762,48 +762,59 @@ __device__ __forceinline__ bool leafShared(const uint4 *__restrict__ tris, int c
 // -- mirrored bounce 1.005 vs 0.940 ms per frame: too few leaf triangles are rejected by every ray, and the kernel goes from 79 to 95 VGPRs.
 // the narrow-range form of the per-ray-origin leaf (one ray per lane): here EVERY triangle of the leaf is intersected by every ray of the
 // range (no packet-level cull), ~47 VALU instructions per ray and triangle -- 4 x 47 per lane in the wide form whatever the range's width
-template <bool MASK, int M>
+template <int R, bool MASK, int M>
 __device__ __forceinline__ void leafPerRayNarrow(const uint4 *__restrict__ tris, int count, int firstTri, int lane, int first, int last,
 												 const float (&org)[3][4], Quad &Q, unsigned mask4, int (&tid)[4], Counters &st) {
+	constexpr int LPQ = 4 / R;                       // lanes per quad: R = 1: lane j <- quad first + j / 4, ray j % 4;  R = 2: quad first + j / 2, rays 2 (j % 2), + 1
 	const int width = last - first + 1;
 	const bool inRange = lane >= first && lane <= last;
-	const int srcAddr = (first + (lane >> 2)) * 4;   // lanes past the range read some quad's rays and never accept
+	const int srcAddr = (first + lane / LPQ) * 4;    // lanes past the range read some quad's rays and never accept
 	// (the crossbar read first, by EVERY lane: behind `live &&` it would run with the other lanes switched off, and a switched-off source
 	// lane reads as 0)
 	const unsigned quadMask = MASK ? (unsigned)__builtin_amdgcn_ds_bpermute(srcAddr, (int)mask4) : 15u;
-	const bool live = (lane < width * 4) & (((quadMask >> (lane & 3)) & 1u) != 0);
-	float g[1], no[3], nd[3], ndist;
-	int ntid = -1;
+	bool live[R];
 #pragma unroll
-	for(int c = 0; c < 3; c++) { narrowGather<1>(org[c], srcAddr, g); no[c] = g[0]; narrowGather<1>(Q.d[c], srcAddr, g); nd[c] = g[0]; }
-	narrowGather<1>(Q.dist, srcAddr, g); ndist = g[0];
+	for(int i = 0; i < R; i++) live[i] = (lane < width * LPQ) & (((quadMask >> ((lane % LPQ) * R + i)) & 1u) != 0);
+	float no[3][R], nd[3][R], ndist[R];
+	int ntid[R];
+#pragma unroll
+	for(int c = 0; c < 3; c++) { narrowGather<R>(org[c], srcAddr, no[c]); narrowGather<R>(Q.d[c], srcAddr, nd[c]); }
+	narrowGather<R>(Q.dist, srcAddr, ndist);
+#pragma unroll
+	for(int i = 0; i < R; i++) ntid[i] = -1;
 	st.leaves++; st.fetched += (unsigned)count;
 	for(int k = 0; k < count; k++) {
 		const Tri t = loadTriScalar(tris, firstTri + k);
-		const float det = nd[0] * t.n[0] + nd[1] * t.n[1] + nd[2] * t.n[2];
-		float tv[3] = {no[0] - t.a[0], no[1] - t.a[1], no[2] - t.a[2]};
-		float c0[3] = {t.ba[1] * tv[2] - t.ba[2] * tv[1], t.ba[2] * tv[0] - t.ba[0] * tv[2], t.ba[0] * tv[1] - t.ba[1] * tv[0]};
-		float c1[3] = {tv[1] * t.ca[2] - tv[2] * t.ca[1], tv[2] * t.ca[0] - tv[0] * t.ca[2], tv[0] * t.ca[1] - tv[1] * t.ca[0]};
-		const float tmul = -(tv[0] * t.n[0] + tv[1] * t.n[1] + tv[2] * t.n[2]);
-		const float v = (nd[0] * c0[0] + nd[1] * c0[1] + nd[2] * c0[2]) * t.it0;
-		const float u = (nd[0] * c1[0] + nd[1] * c1[1] + nd[2] * c1[2]) * t.it0;
-		const float duv = det - u - v;
-		const float uvmin = Min3<M>(u, v, duv), uvmax = Max3<M>(u, v, duv);
-		if(((uvmax <= 0.0f) | (uvmin >= 0.0f)) & live) {
-			const float dd = recipExact(det) * tmul;
-			if(dd < ndist && dd > 0.0f) { ndist = dd; ntid = firstTri + k; }
+#pragma unroll
+		for(int i = 0; i < R; i++) {
+			const float det = nd[0][i] * t.n[0] + nd[1][i] * t.n[1] + nd[2][i] * t.n[2];
+			float tv[3] = {no[0][i] - t.a[0], no[1][i] - t.a[1], no[2][i] - t.a[2]};
+			float c0[3] = {t.ba[1] * tv[2] - t.ba[2] * tv[1], t.ba[2] * tv[0] - t.ba[0] * tv[2], t.ba[0] * tv[1] - t.ba[1] * tv[0]};
+			float c1[3] = {tv[1] * t.ca[2] - tv[2] * t.ca[1], tv[2] * t.ca[0] - tv[0] * t.ca[2], tv[0] * t.ca[1] - tv[1] * t.ca[0]};
+			const float tmul = -(tv[0] * t.n[0] + tv[1] * t.n[1] + tv[2] * t.n[2]);
+			const float v = (nd[0][i] * c0[0] + nd[1][i] * c0[1] + nd[2][i] * c0[2]) * t.it0;
+			const float u = (nd[0][i] * c1[0] + nd[1][i] * c1[1] + nd[2][i] * c1[2]) * t.it0;
+			const float duv = det - u - v;
+			const float uvmin = Min3<M>(u, v, duv), uvmax = Max3<M>(u, v, duv);
+			if(((uvmax <= 0.0f) | (uvmin >= 0.0f)) & live[i]) {
+				const float dd = recipExact(det) * tmul;
+				if(dd < ndist[i] && dd > 0.0f) { ndist[i] = dd; ntid[i] = firstTri + k; }
+			}
 		}
 		st.intersects += width;
 	}
 	const int q = lane - first;
 #pragma unroll
 	for(int l = 0; l < 4; l++) {
-		const int src = (q * 4 + l) * 4;
-		const float d = xbar(src, ndist);
-		const int nt = __builtin_amdgcn_ds_bpermute(src, ntid);
+		const int src = (q * LPQ + l / R) * 4;
+		const float d = xbar(src, ndist[l % R]);
+		const int nt = __builtin_amdgcn_ds_bpermute(src, ntid[l % R]);
 		if(inRange && nt >= 0) { Q.dist[l] = d; tid[l] = nt; }
 	}
 }
+#ifndef SNAIL_PERRAY_NARROW2
+#define SNAIL_PERRAY_NARROW2 1 // per-ray-origin leaves of ranges of 17..32 quads with two rays per lane (94 instead of 188 vector instructions per triangle)
+#endif
 template <bool MASK, int M, bool BARY>
 __device__ __forceinline__ void leafPerRay(const uint4 *__restrict__ tris, int count, int firstTri, int lane, int first, int last, const float (&org)[3][4],
 										   Quad &Q, unsigned mask4, int (&tid)[4], float (&bu)[4], float (&bv)[4], Counters &st) {
@@ -811,9 +822,10 @@ __device__ __forceinline__ void leafPerRay(const uint4 *__restrict__ tris, int c
 	const int width = last - first + 1;
 	if(SNAIL_LEAF_COMPACT_PERRAY && !BARY) {
 		const int widthU = __builtin_amdgcn_readfirstlane(width);
-		if(widthU <= 16) {
+		if(widthU <= (SNAIL_PERRAY_NARROW2 ? 32 : 16)) {
 			const int firstU = __builtin_amdgcn_readfirstlane(first);
-			leafPerRayNarrow<MASK, M>(tris, __builtin_amdgcn_readfirstlane(count), firstTri, lane, firstU, firstU + widthU - 1, org, Q, mask4, tid, st);
+			if(widthU <= 16) leafPerRayNarrow<1, MASK, M>(tris, __builtin_amdgcn_readfirstlane(count), firstTri, lane, firstU, firstU + widthU - 1, org, Q, mask4, tid, st);
+			else leafPerRayNarrow<2, MASK, M>(tris, __builtin_amdgcn_readfirstlane(count), firstTri, lane, firstU, firstU + widthU - 1, org, Q, mask4, tid, st);
 			return;
 		}
 	}

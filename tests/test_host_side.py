@@ -308,7 +308,7 @@ def json_budget():
         "k_shadowILb0E": {"vgprs": 88, "waves": 5},                # the compiler's own allocation: nothing spilled
         "k_lightILb0ELi0E": {"vgprs": 80, "waves": 6, "vgpr_spill": 2},   # (six-wave budget: two registers of the sample set-up spilled, none in the walk)
         "k_lightILb0ELi1E": {"vgprs": 80, "waves": 6},
-        "k_raysILb0ELb1ELb0ELb0E": {"vgprs": 88, "waves": 5},      # mirrored packets (per-ray origins, masks): the compiler's own allocation, nothing spilled
+        "k_raysILb0ELb1ELb0ELb0E": {"vgprs": 96, "waves": 5},      # mirrored packets (per-ray origins, masks): the compiler's own allocation, nothing spilled
         "k_raysILb0E": {"vgprs": 112, "waves": 4},                 # every generic-packet kernel of ordinary trees: no scratch
     }
 
