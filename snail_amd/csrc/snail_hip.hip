@@ -1398,7 +1398,7 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 "v"(vt[8]), "v"(vt[9]), "v"(vt[10]), "v"(vt[11]), "v"(vt[12]), "v"(vt[13]), "v"(vt[14]), "v"(vt[15]), "v"(vt[16]))
 // the six plane-offset registers of SNAIL_PRE_SHARED are operands only where a visit forms them (PREVARS = SNAIL_PREVARS_of(PRE))
 #define SNAIL_PREVARS_SHARED() [pnx] "=&v"(vt[0]), [pny] "=&v"(vt[1]), [pnz] "=&v"(vt[2]), [pfx] "=&v"(vt[3]), [pfy] "=&v"(vt[4]), [pfz] "=&v"(vt[5]),
-#define SNAIL_PREVARS_NONE() [pnx] "=&v"(vt[0]), [pny] "=&v"(vt[1]), [pnz] "=&v"(vt[2]), [pfx] "=&v"(vt[3]), [pfy] "=&v"(vt[4]), [pfz] "=&v"(vt[5]),   /* (unused, but without them this compiler ends in "illegal VGPR to SGPR copy") */
+#define SNAIL_PREVARS_NONE() [pnx] "=&v"(vt[0]), [pny] "=&v"(vt[1]), [pnz] "=&v"(vt[2]), [pfx] "=&v"(vt[3]), [pfy] "=&v"(vt[4]), [pfz] "=&v"(vt[5]),   /* (SNAIL_PRE_NONE keeps the operands; SNAIL_PRE_NONE_X drops them) */
 #define SNAIL_PREVARS_SNAIL_PRE_SHARED SNAIL_PREVARS_SHARED
 #define SNAIL_PREVARS_SNAIL_PRE_NONE SNAIL_PREVARS_NONE
 #define SNAIL_PREVARS_SNAIL_PRE_SEL SNAIL_PREVARS_NONE
@@ -1511,7 +1511,10 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /*
 	constexpr bool PF = PACK && SNAIL_NODE_PREFETCH;   // the record-prefetching loop over its own copy of the tree
 	const int sign16 = PF ? signBits : signBits << 16; // (PF: sign bit k against an inner record's 1 << axis)
 	const u64 nodeBase = (u64)nodes;
-	int stkN = PACK ? (int)((unsigned)(size - 1) << 26) | (PF ? 1 : 0) : 0, stkF = (size - 1) << 8; // stack slot 0 = the root (PF: record slot 1) with the full quad range
+	// stack slot 0 = the root (PF: record slot 1) with the full quad range.  (float-typed: the only 32-bit INTEGER values that go in and out of the loop
+	// statements are then scalar ones -- the instruction selector shares one undefined register among all undefined values of a type on a path, and an
+	// undefined VGPR feeding a scalar operand's PHI is this compiler's "illegal VGPR to SGPR copy")
+	float stkN = __int_as_float(PACK ? (int)((unsigned)(size - 1) << 26) | (PF ? 1 : 0) : 0), stkF = __int_as_float((size - 1) << 8);
 	int sp = 1, first = 0, last = size - 1, cnt = 0;
 	for(;;) {
 		int leafSub, leafAux, sCur, sFl, sOff, sWidth;
@@ -1537,7 +1540,7 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /*
 				if(SHADOW) { SNAIL_WALK_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_ANY, "", SNAIL_COUNT, SNAIL_PF_LEAFREQ_TRI, oct) }
 #endif
 #if SNAIL_REL_NODES
-				else if(POSDIST) { SNAIL_WALK_PF_OCT(SNAIL_PRE_NONE, SNAIL_ORG_SHARED, SNAIL_SLAB_COH_R, SNAIL_TAIL_POS, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_SLOT0, oct) }
+				else if(POSDIST) { SNAIL_WALK_PF_OCT(SNAIL_PRE_NONE_X, SNAIL_ORG_SHARED, SNAIL_SLAB_COH_R, SNAIL_TAIL_POS, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_SLOT0, oct) }
 #else
 				else if(POSDIST) { SNAIL_WALK_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_POS, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_TRI, oct) }
 #endif
@@ -1549,7 +1552,7 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /*
 				if(SHADOW) { SNAIL_WALK_PF_PLAIN(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, "", SNAIL_COUNT, SNAIL_PF_LEAFREQ_TRI); }
 #endif
 #if SNAIL_REL_NODES
-				else if(POSDIST) { SNAIL_WALK_PF_PLAIN(SNAIL_PRE_NONE, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST_R, SNAIL_TAIL_POS, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_SLOT0); }
+				else if(POSDIST) { SNAIL_WALK_PF_PLAIN(SNAIL_PRE_NONE_X, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST_R, SNAIL_TAIL_POS, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_SLOT0); }
 #else
 				else if(POSDIST) { SNAIL_WALK_PF_PLAIN(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_POS, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_TRI); }
 #endif
@@ -1580,7 +1583,7 @@ __device__ __forceinline__ void walkPerRayAsm(const uint4 *__restrict__ nodes /*
 	// PF: bits 0..2 = the signs of lane 0's first ray (child order, as the reference takes it); bits 8..10 = the packet's sign octant (plane selection of SNAIL_PRE_SEL)
 	const int sign16 = PF ? (COH ? signBits | __builtin_amdgcn_readfirstlane(oct) << 8 : signBits) : signBits << 16;
 	const u64 nodeBase = (u64)nodes;
-	int stkN = PF ? (int)((unsigned)(size - 1) << 26) | 1 : 0, stkF = (size - 1) << 8; // stack slot 0 = the root (PF: record slot 1) with the full quad range
+	float stkN = __int_as_float(PF ? (int)((unsigned)(size - 1) << 26) | 1 : 0), stkF = __int_as_float((size - 1) << 8); // stack slot 0 = the root (PF: record slot 1) with the full quad range; float-typed as in walkSharedAsm
 	int sp = 1, first = 0, last = size - 1, cnt = 0;
 	for(;;) {
 		int leafSub, leafAux, sCur, sFl, sOff, sWidth;
