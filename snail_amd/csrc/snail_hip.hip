@@ -458,11 +458,6 @@ __device__ __forceinline__ u64 cullQuad(const uint4 *__restrict__ tris, int coun
 #ifndef SNAIL_LEAF_COMPACT
 #define SNAIL_LEAF_COMPACT 1 // 0 = every leaf in the wide form (A/B measurements)
 #endif
-// a hit's triangle index, stored into the caller's per-lane record: an int, or -- inside the hand-written walks -- the same bits in a float: a
-// 32-bit INTEGER VGPR value that lives across the loop statements would share its undefined register (one per type and path) with the
-// statements' scalar in / out operands, which this compiler reports as "illegal VGPR to SGPR copy"
-__device__ __forceinline__ void setId(int &d, int v) { d = v; }
-__device__ __forceinline__ void setId(float &d, int v) { d = __int_as_float(v); }
 template <int R> struct NarrowRays {
 	float d[3][R], dist[R];
 	int tid[R];
@@ -473,9 +468,9 @@ template <int R> __device__ __forceinline__ void narrowGather(const float (&q)[4
 	if(R == 1) out[0] = selLanes(selLanes(a0, a1, 0xaaaaaaaaaaaaaaaaull), selLanes(a2, a3, 0xaaaaaaaaaaaaaaaaull), 0xccccccccccccccccull);
 	else { out[0] = selLanes(a0, a2, 0xaaaaaaaaaaaaaaaaull); out[R - 1] = selLanes(a1, a3, 0xaaaaaaaaaaaaaaaaull); }
 }
-template <int R, int M, class TID>
+template <int R, int M>
 __device__ __forceinline__ void leafSharedNarrow(const uint4 *__restrict__ tris, int count, int firstTri, int lane, int first, int last,
-												 const float (&org)[3][4], Quad &Q, TID (&tid)[4], const Interval &iv, Counters &st) {
+												 const float (&org)[3][4], Quad &Q, int (&tid)[4], const Interval &iv, Counters &st) {
 	constexpr int LPQ = 4 / R;                      // lanes per quad
 	const int width = last - first + 1;             // count <= 64: one chunk
 	const bool inRange = lane >= first && lane <= last;
@@ -546,7 +541,7 @@ __device__ __forceinline__ void leafSharedNarrow(const uint4 *__restrict__ tris,
 		const int src = (q * LPQ + l / R) * 4;
 		const float nd = xbar(src, N.dist[l % R]);
 		const int nt = __builtin_amdgcn_ds_bpermute(src, N.tid[l % R]);
-		if(inRange && nt >= 0) { Q.dist[l] = nd; setId(tid[l], nt); }
+		if(inRange && nt >= 0) { Q.dist[l] = nd; tid[l] = nt; }
 	}
 }
 
@@ -615,53 +610,15 @@ __device__ __forceinline__ void leafSharedNarrowShadow(const uint4 *__restrict__
 	}
 }
 
-// leaf inside a narrow subtree walk (walkSharedAsm, SNAIL_NARROW_SUBTREE): the rays already sit one per lane (gd, gdist, ntid live across the whole
-// subtree: no gather, no write-back here), lanes [first, last] = the leaf's quads x 4; cull and terms as everywhere (four lanes per triangle,
-// 16 triangles at a time), the surviving triangles in order.  src/triangle.cpp:44-60 per ray.
-template <int M>
-__device__ __forceinline__ void leafNarrowInPlace(const uint4 *__restrict__ tris, int count, int firstTri, int lane, int first, int last,
-												  const float (&org)[3][4], const float (&gd)[3], float &gdist, float &ntidBits /* the hit triangle's index as float bits (-1 = none):
-												  a 32-bit INTEGER carried through the caller's loop would share its undefined register with the loop's scalar operands */,
-												  const Interval &iv, Counters &st) {
-	const bool live = lane >= first && lane <= last;
-	const int widthQ = (last - first + 1) >> 2;
-	st.leaves++;
-	st.fetched += (unsigned)count;
-	for(int base = 0; base < count; base += 16) {
-		QuadTerms qt;
-		u64 keep = cullQuad<M>(tris, count - base < 16 ? count - base : 16, firstTri + base, lane, org, iv, qt);
-		while(keep) {
-			const int kb = __builtin_ctzll(keep);
-			keep &= keep - 1;
-			const float nx = xbar(kb * 4, qt.n), ny = xbar(kb * 4 + 4, qt.n), nz = xbar(kb * 4 + 8, qt.n);
-			const float ax = xbar(kb * 4, qt.t0v), ay = xbar(kb * 4 + 4, qt.t0v), az = xbar(kb * 4 + 8, qt.t0v);
-			const float bx = xbar(kb * 4, qt.t1v), by = xbar(kb * 4 + 4, qt.t1v), bz = xbar(kb * 4 + 8, qt.t1v);
-			const float tmul = xbar(kb * 4, qt.tmul);
-			if(live) {
-				const float det = gd[0] * nx + gd[1] * ny + gd[2] * nz;
-				const float v = gd[0] * ax + gd[1] * ay + gd[2] * az;
-				const float u = gd[0] * bx + gd[1] * by + gd[2] * bz;
-				const float duv = det - u - v;
-				const float uvmin = Min3<M>(u, v, duv), uvmax = Max3<M>(u, v, duv);
-				if((uvmax <= 0.0f) | (uvmin >= 0.0f)) {
-					const float dd = recipExact(det) * tmul;
-					if(dd < gdist && dd > 0.0f) { gdist = dd; ntidBits = __int_as_float(firstTri + base + (kb >> 2)); }
-				}
-			}
-			st.intersects += widthQ;
-		}
-	}
-}
-
 // ---- leaf, shared origin (src/bvh/traverse.cpp:34-56 / :98-124): lanes 0..chunk-1 each take one triangle (packet-level
 // cull + shared-origin terms in parallel), survivors are broadcast one by one to the whole packet.  Returns true when a
 // shadow packet is fully occluded (the walk ends, src/bvh/traverse.cpp:117-121).
 #ifndef SNAIL_LEAF_MASK
 #define SNAIL_LEAF_MASK 1 // 0 = every lane computes everything in the leaf (A/B measurements)
 #endif
-template <bool MASK, bool SHADOW, int M, bool BARY, class TID>
+template <bool MASK, bool SHADOW, int M, bool BARY>
 __device__ __forceinline__ bool leafShared(const uint4 *__restrict__ tris, int count, int firstTri, int size, int lane, int first, int last,
-										   const float (&org)[3][4], Quad &Q, unsigned mask4, TID (&tid)[4], float (&bu)[4], float (&bv)[4],
+										   const float (&org)[3][4], Quad &Q, unsigned mask4, int (&tid)[4], float (&bu)[4], float (&bv)[4],
 										   const Interval &iv, Counters &st) {
 	const float inf = __builtin_inff();
 	const bool inRange = lane >= first && lane <= last;
@@ -718,7 +675,7 @@ __device__ __forceinline__ bool leafShared(const uint4 *__restrict__ tris, int c
 					const float idet = recipExact(det);
 					const float dd = idet * tmul;
 					if(dd < Q.dist[l] && dd > 0.0f) {
-						Q.dist[l] = dd; setId(tid[l], idx);
+						Q.dist[l] = dd; tid[l] = idx;
 						if(BARY) { bu[l] = u * idet; bv[l] = v * idet; }
 					}
 				}
@@ -1369,7 +1326,7 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 #define SNAIL_PF2_ALIVE " s_sub_u32 %[cur], %[last], %[first]\n s_bfm_b64 %[alive], %[cur], %[first]\n s_bitset1_b64 %[alive], %[last]\n"
 #define SNAIL_PF2_FIRSTLAST " s_ff1_i32_b64 %[first], exec\n s_flbit_i32_b64 %[last], exec\n s_xor_b32 %[last], %[last], 63\n"
 // a visit entered from a descent: the push of (FARY, survivors' first / last) happens here, between the slab products
-#define SNAIL_PF2_PENDING(X, OTHERSET, SUB, AUX, FARX, FARY, PRE, SLAB, TAIL, CNTVISIT, LEAFREQ, NCHK, NX, FX, NY, FY, NZ, FZ)                                                   \
+#define SNAIL_PF2_PENDING(X, OTHERSET, SUB, AUX, FARX, FARY, PRE, SLAB, TAIL, CNTVISIT, LEAFREQ, NX, FX, NY, FY, NZ, FZ)                                                   \
 				 "L_visit" X "p_%=:\n"                                                                                                      \
 				 " s_waitcnt lgkmcnt(0)\n" /* this record has arrived; T's last request too */                                                \
 				 " s_load_dwordx8 s[68:75], %[base], " FARY "\n" /* the pusher's far child is the new top entry */                             \
@@ -1379,7 +1336,7 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 SLAB("1", NX, FX, NY, FY, NZ, FZ) TAIL("1", "s1")                                                                           \
 				 SNAIL_PF2_FIRSTLAST /* of the pusher: EXEC is still its survivor set */                                                     \
 				 " s_lshl_b32 %[off], %[last], 6\n s_or_b32 %[off], %[off], %[first]\n s_lshl_b32 %[off], %[off], 20\n"                    \
-				 SNAIL_PF2_ALIVE NCHK                                                                                                       \
+				 SNAIL_PF2_ALIVE                                                                                                            \
 				 SLAB("2", NX, FX, NY, FY, NZ, FZ) TAIL("2", "s2")                                                                           \
 				 " s_lshr_b32 %[topw], " FARY ", 5\n s_or_b32 %[topw], %[topw], %[off]\n"                                                    \
 				 " v_writelane_b32 %[stkN], %[topw], m0\n s_add_u32 m0, m0, 1\n" SNAIL_PF2_ISLEAF(SUB)                                       \
@@ -1389,7 +1346,7 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 "L_leaf" X "_%=:\n" SNAIL_PF2_FIRSTLAST                                                                                    \
 				 " s_bfe_u32 %[leafSub], " SUB ", 0x190006\n s_sub_u32 %[leafSub], %[leafSub], 0x80000\n s_bitset1_b32 %[leafSub], 31\n"   \
 				 " s_mov_b32 %[leafAux], " AUX "\n s_waitcnt lgkmcnt(0)\n s_branch L_end_%=\n"
-#define SNAIL_DESCEND_PF2X(NCHK, NPOP, EXTRACLOB, PREVARS, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)                                                  \
+#define SNAIL_DESCEND_PF2X(EXTRACLOB, PREVARS, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)                                                  \
 	asm volatile(SNAIL_DRAIN_SMEM " s_mov_b32 m0, %[sp]\n"                                                                                \
 				 "L_entry_%=:\n"                                                                                                           \
 				 " s_cmp_eq_u32 m0, 0\n s_cbranch_scc1 L_done_%=\n"                                                                     \
@@ -1397,9 +1354,8 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 " v_readlane_b32 %[topw], %[stkN], %[off]\n"                                                                              \
 				 " s_and_b32 %[cur], %[topw], 0xfffff\n s_lshl_b32 %[off], %[cur], 5\n"                                                    \
 				 " s_load_dwordx8 s[68:75], %[base], %[off]\n"                                                                             \
-				 " s_bfe_u32 %[first], %[topw], 0x60014\n s_lshr_b32 %[last], %[topw], 26\n" SNAIL_PF2_ALIVE NCHK                          \
+				 " s_bfe_u32 %[first], %[topw], 0x60014\n s_lshr_b32 %[last], %[topw], 26\n" SNAIL_PF2_ALIVE                               \
 				 "L_pop_%=:\n" /* sp > 0, topw = the top entry, alive = its lanes, T = its record (requested) */                            \
-				 NPOP                                                                                                                      \
 				 " s_sub_u32 m0, m0, 1\n" CNTPOP                                                                                     \
 				 " s_mov_b64 exec, %[alive]\n"                                                                                             \
 				 " s_waitcnt lgkmcnt(0)\n" SNAIL_A_FROM_T                                                                                  \
@@ -1413,23 +1369,22 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 SLAB("1", NXA, FXA, NYA, FYA, NZA, FZA) TAIL("1", "s1")                                                          \
 				 SNAIL_PF2_NEARFAR("s90", "s91", "%[fl]", "s[76:83]", LEAFREQ)                                                                       \
 				 SLAB("2", NXA, FXA, NYA, FYA, NZA, FZA) TAIL("2", "s2")                                                          \
-				 " s_bfe_u32 %[first], %[topw], 0x60014\n s_lshr_b32 %[last], %[topw], 26\n" SNAIL_PF2_ALIVE NCHK SNAIL_PF2_ISLEAF("s90")        \
+				 " s_bfe_u32 %[first], %[topw], 0x60014\n s_lshr_b32 %[last], %[topw], 26\n" SNAIL_PF2_ALIVE SNAIL_PF2_ISLEAF("s90")        \
 				 SLAB("3", NXA, FXA, NYA, FYA, NZA, FZA) TAIL("3", "s3")                                                          \
 				 SNAIL_PF2_TAIL("A", "s90")                                                                                                 \
 				 /* falls through: A descends into B, its push pending */                                                                   \
-				 SNAIL_PF2_PENDING("B", "s[84:91]", "s82", "s83", "%[width]", "%[fl]", PRE, SLAB, TAIL, CNTVISIT, LEAFREQ, NCHK, NXB, FXB, NYB, FYB, NZB, FZB)             \
+				 SNAIL_PF2_PENDING("B", "s[84:91]", "s82", "s83", "%[width]", "%[fl]", PRE, SLAB, TAIL, CNTVISIT, LEAFREQ, NXB, FXB, NYB, FYB, NZB, FZB)                   \
 				 /* falls through: B descends into A, its push pending */                                                                   \
-				 SNAIL_PF2_PENDING("A", "s[76:83]", "s90", "s91", "%[fl]", "%[width]", PRE, SLAB, TAIL, CNTVISIT, LEAFREQ, NCHK, NXA, FXA, NYA, FYA, NZA, FZA)             \
+				 SNAIL_PF2_PENDING("A", "s[76:83]", "s90", "s91", "%[fl]", "%[width]", PRE, SLAB, TAIL, CNTVISIT, LEAFREQ, NXA, FXA, NYA, FYA, NZA, FZA)                   \
 				 " s_branch L_visitBp_%=\n"                                                                                                \
 				 SNAIL_PF2_LEAF("A", "s90", "s91") SNAIL_PF2_LEAF("B", "s82", "s83")                                                       \
-				 "L_narrow_%=:\n s_mov_b32 %[leafSub], 1\n s_mov_b32 %[leafAux], 0\n s_waitcnt lgkmcnt(0)\n s_branch L_end_%=\n" /* the top entry's range is narrow: left on the stack for the caller */ \
 				 "L_fail_%=:\n"                                                                                                            \
 				 " s_cmp_eq_u32 m0, 0\n s_cbranch_scc0 L_pop_%=\n"                                                                      \
 				 "L_done_%=:\n s_mov_b32 %[leafSub], 0\n s_mov_b32 %[leafAux], 0\n s_waitcnt lgkmcnt(0)\n"                                  \
 				 "L_end_%=:\n s_mov_b64 exec, -1\n s_mov_b32 %[sp], m0\n"                                                                                        \
 				 : [sp] "+s"(sp), [first] "+s"(first), [last] "+s"(last), [cnt] "+s"(cnt), [stkN] "+v"(stkN), [stkF] "+v"(stkF),           \
 				   [leafSub] "=&s"(leafSub), [leafAux] "=&s"(leafAux), [cur] "=&s"(sCur), [fl] "=&s"(sFl), [off] "=&s"(sOff),              \
-				   [width] "=&s"(sWidth), [topw] "=&s"(sTopw), [alive] "=&s"(sAlive), [nfl] "=&s"(sNfl), PREVARS() [t0] "=&v"(vt[6]), [t1] "=&v"(vt[7]),   \
+				   [width] "=&s"(sWidth), [topw] "=&s"(sTopw), [alive] "=&s"(sAlive), PREVARS() [t0] "=&v"(vt[6]), [t1] "=&v"(vt[7]),   \
 				   [t2] "=&v"(vt[8]), [t3] "=&v"(vt[9]), [t4] "=&v"(vt[10]), [t5] "=&v"(vt[11]), [s0] "=&v"(vt[12]), [s1] "=&v"(vt[13]),   \
 				   [s2] "=&v"(vt[14]), [s3] "=&v"(vt[15]), [u0] "=&v"(vt[16])                                                              \
 				 : [base] "s"(nodeBase), [sign16] "s"(sign16), [lane] "v"(lane), ORGOPS(), [ix0] "v"(Q.id[0][0]), [ix1] "v"(Q.id[0][1]), [ix2] "v"(Q.id[0][2]), [ix3] "v"(Q.id[0][3]),        \
@@ -1439,7 +1394,7 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 : "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", \
 				   "s88", "s89", "s90", "s91", "vcc", "scc", "m0" EXTRACLOB);                                                                        \
 	asm volatile("" ::"s"(sp), "s"(first), "s"(last), "s"(cnt), "v"(stkN), "v"(stkF), "s"(leafSub), "s"(leafAux), "s"(sCur), "s"(sFl), "s"(sOff),    \
-				 "s"(sWidth), "s"(sTopw), "s"(sAlive), "s"(sNfl), "v"(vt[6]), "v"(vt[7]), \
+				 "s"(sWidth), "s"(sTopw), "s"(sAlive), "v"(vt[6]), "v"(vt[7]), \
 				 "v"(vt[8]), "v"(vt[9]), "v"(vt[10]), "v"(vt[11]), "v"(vt[12]), "v"(vt[13]), "v"(vt[14]), "v"(vt[15]), "v"(vt[16]))
 // the six plane-offset registers of SNAIL_PRE_SHARED are operands only where a visit forms them (PREVARS = SNAIL_PREVARS_of(PRE))
 #define SNAIL_PREVARS_SHARED() [pnx] "=&v"(vt[0]), [pny] "=&v"(vt[1]), [pnz] "=&v"(vt[2]), [pfx] "=&v"(vt[3]), [pfy] "=&v"(vt[4]), [pfz] "=&v"(vt[5]),
@@ -1451,12 +1406,8 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 #define SNAIL_PRE_NONE_X(NX, FX, NY, FY, NZ, FZ) "" /* = SNAIL_PRE_NONE, in walks that compile without the six unused operands */
 #define SNAIL_PREVARS_SNAIL_PRE_NONE_X SNAIL_PREVARS_EMPTY
 #define SNAIL_PREVARS_of(PRE) SNAIL_PREVARS_##PRE
-// SNAIL_NCHK / SNAIL_NPOP (primary packets with SNAIL_NARROW_SUBTREE): the statement keeps a flag "the top entry's range holds <= 16 quads" beside the
-// entry's lane mask and, instead of popping such an entry, leaves with leafSub = 1: the caller walks the subtree below it one ray per lane
-#define SNAIL_NCHK_ON " s_cmp_lt_u32 %[cur], 16\n s_cselect_b32 %[nfl], 1, 0\n" /* after SNAIL_PF2_ALIVE: cur = last - first of the top entry */
-#define SNAIL_NPOP_ON " s_cmp_lg_u32 %[nfl], 0\n s_cbranch_scc1 L_narrow_%=\n"
 #define SNAIL_DESCEND_PF2(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)                 \
-	SNAIL_DESCEND_PF2X("", "", , SNAIL_PREVARS_of(PRE), PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)
+	SNAIL_DESCEND_PF2X(, SNAIL_PREVARS_of(PRE), PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)
 // coherent packets WITHOUT one statement per sign octant: the near / far plane of each axis is picked on the scalar side, per visit, into
 // s62..s67 (nine scalar instructions that issue beside the visit's vector ones) -- for walks whose leaf code leaves the compiler no room
 // for eight copies of this loop (per-ray origins)
@@ -1467,91 +1418,19 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 #define SNAIL_SLABO_SEL(L, NX, FX, NY, FY, NZ, FZ) SNAIL_SLABO_COH(L, "s62", "s65", "s63", "s66", "s64", "s67")
 #define SNAIL_SEL_CLOB , "s62", "s63", "s64", "s65", "s66", "s67"
 #define SNAIL_DESCEND_PF2_SEL(ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ)                                                                \
-	SNAIL_DESCEND_PF2X("", "", SNAIL_SEL_CLOB, SNAIL_PREVARS_NONE, SNAIL_PRE_SEL, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s84", "s87", "s85", "s88", "s86", "s89", "s76", "s79", "s77", "s80", "s78", "s81")
-// (D = the statement to instantiate: SNAIL_DESCEND_PF2, or SNAIL_DESCEND_PF2_NARROWTOP for walks that hand narrow subtrees to their caller)
-#define SNAIL_DESCEND_PF2_NARROWTOP(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)       \
-	SNAIL_DESCEND_PF2X(SNAIL_NCHK_ON, SNAIL_NPOP_ON, , SNAIL_PREVARS_of(PRE), PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)
-#define SNAIL_PF2_PLAIN_WITH(D, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ) D(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s84", "s87", "s85", "s88", "s86", "s89", "s76", "s79", "s77", "s80", "s78", "s81")
-#define SNAIL_PF2_OCT_WITH(D, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, OCT)                                                       \
+	SNAIL_DESCEND_PF2X(SNAIL_SEL_CLOB, SNAIL_PREVARS_NONE, SNAIL_PRE_SEL, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s84", "s87", "s85", "s88", "s86", "s89", "s76", "s79", "s77", "s80", "s78", "s81")
+#define SNAIL_DESCEND_PF2_PLAIN(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ) SNAIL_DESCEND_PF2(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s84", "s87", "s85", "s88", "s86", "s89", "s76", "s79", "s77", "s80", "s78", "s81")
+#define SNAIL_DESCEND_PF2_OCT(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, OCT)                                                                                                    \
 	switch(OCT) {                                                                                                                          \
-	case 0: D(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s84", "s87", "s85", "s88", "s86", "s89", "s76", "s79", "s77", "s80", "s78", "s81"); break;            \
-	case 1: D(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s87", "s84", "s85", "s88", "s86", "s89", "s79", "s76", "s77", "s80", "s78", "s81"); break;            \
-	case 2: D(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s84", "s87", "s88", "s85", "s86", "s89", "s76", "s79", "s80", "s77", "s78", "s81"); break;            \
-	case 3: D(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s87", "s84", "s88", "s85", "s86", "s89", "s79", "s76", "s80", "s77", "s78", "s81"); break;            \
-	case 4: D(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s84", "s87", "s85", "s88", "s89", "s86", "s76", "s79", "s77", "s80", "s81", "s78"); break;            \
-	case 5: D(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s87", "s84", "s85", "s88", "s89", "s86", "s79", "s76", "s77", "s80", "s81", "s78"); break;            \
-	case 6: D(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s84", "s87", "s88", "s85", "s89", "s86", "s76", "s79", "s80", "s77", "s81", "s78"); break;            \
-	default: D(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s87", "s84", "s88", "s85", "s89", "s86", "s79", "s76", "s80", "s77", "s81", "s78"); break;           \
+	case 0: SNAIL_DESCEND_PF2(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s84", "s87", "s85", "s88", "s86", "s89", "s76", "s79", "s77", "s80", "s78", "s81"); break;            \
+	case 1: SNAIL_DESCEND_PF2(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s87", "s84", "s85", "s88", "s86", "s89", "s79", "s76", "s77", "s80", "s78", "s81"); break;            \
+	case 2: SNAIL_DESCEND_PF2(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s84", "s87", "s88", "s85", "s86", "s89", "s76", "s79", "s80", "s77", "s78", "s81"); break;            \
+	case 3: SNAIL_DESCEND_PF2(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s87", "s84", "s88", "s85", "s86", "s89", "s79", "s76", "s80", "s77", "s78", "s81"); break;            \
+	case 4: SNAIL_DESCEND_PF2(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s84", "s87", "s85", "s88", "s89", "s86", "s76", "s79", "s77", "s80", "s81", "s78"); break;            \
+	case 5: SNAIL_DESCEND_PF2(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s87", "s84", "s85", "s88", "s89", "s86", "s79", "s76", "s77", "s80", "s81", "s78"); break;            \
+	case 6: SNAIL_DESCEND_PF2(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s84", "s87", "s88", "s85", "s89", "s86", "s76", "s79", "s80", "s77", "s81", "s78"); break;            \
+	default: SNAIL_DESCEND_PF2(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, "s87", "s84", "s88", "s85", "s89", "s86", "s79", "s76", "s80", "s77", "s81", "s78"); break;           \
 	}
-#define SNAIL_DESCEND_PF2_PLAIN(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ) SNAIL_PF2_PLAIN_WITH(SNAIL_DESCEND_PF2, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ)
-#define SNAIL_DESCEND_PF2_OCT(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, OCT) SNAIL_PF2_OCT_WITH(SNAIL_DESCEND_PF2, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, OCT)
-
-// ---- the same loop for a NARROW subtree: ONE ray per lane ------------------------------------------------------------------------------
-// A lane holds an SSE quad, so a node visit costs 47 vector instructions whatever the width of the active range; under an entry whose range
-// holds <= 16 quads the caller spreads those quads' rays over the wave (lane j <- ray j % 4 of quad first + j / 4; gathered once) and this
-// statement walks the whole subtree below the entry with 18 vector instructions per visit: the slab test of ONE ray (min / max form: any sign
-// octant), EXEC = the surviving RAYS (a ray that fails a box fails every box inside it), ranges in LANE units rounded to whole quads -- first &= ~3,
-// last |= 3: a quad survives with any of its rays, exactly the reference's first / last scan -- in the same one-word stack entries, above the
-// caller's.  The statement ends at a leaf (first / last = its range in lanes) or when the stack is back at %[spb] (leafSub = 0).
-// Camera-relative records only (primary packets); record sets, prefetching and the deferred push as in SNAIL_DESCEND_PF2X.
-#define SNAIL_PFN_FIRSTLAST SNAIL_PF2_FIRSTLAST " s_andn2_b32 %[first], %[first], 3\n s_or_b32 %[last], %[last], 3\n"
-#define SNAIL_PFN_TAIL(X) " v_cmpx_le_f32 vcc, 0, %[s0]\n s_cbranch_execz L_fail_%=\n s_cbranch_scc1 L_leaf" X "_%=\n"
-#define SNAIL_PFN_PENDING(X, OTHERSET, SUB, AUX, FARX, FARY, NX, FX, NY, FY, NZ, FZ)                                                         \
-				 "L_visit" X "p_%=:\n"                                                                                                      \
-				 " s_waitcnt lgkmcnt(0)\n"                                                                                                  \
-				 " s_load_dwordx8 s[68:75], %[base], " FARY "\n"                                                                             \
-				 SNAIL_SLAB_FAST_R("0", NX, FX, NY, FY, NZ, FZ)                                                                              \
-				 SNAIL_PF2_NEARFAR(SUB, AUX, FARX, OTHERSET, SNAIL_PF_LEAFREQ_SLOT0)                                                         \
-				 SNAIL_TAIL_POS("0", "s0")                                                                                                  \
-				 SNAIL_PFN_FIRSTLAST /* of the pusher: EXEC is still its survivor set */                                                     \
-				 " s_lshl_b32 %[off], %[last], 6\n s_or_b32 %[off], %[off], %[first]\n s_lshl_b32 %[off], %[off], 20\n"                    \
-				 SNAIL_PF2_ALIVE                                                                                                            \
-				 " s_lshr_b32 %[topw], " FARY ", 5\n s_or_b32 %[topw], %[topw], %[off]\n"                                                    \
-				 " v_writelane_b32 %[stkN], %[topw], m0\n s_add_u32 m0, m0, 1\n" SNAIL_PF2_ISLEAF(SUB)                                       \
-				 SNAIL_PFN_TAIL(X)
-#define SNAIL_PFN_LEAF(X, SUB, AUX)                                                                                                         \
-				 "L_leaf" X "_%=:\n" SNAIL_PFN_FIRSTLAST                                                                                    \
-				 " s_bfe_u32 %[leafSub], " SUB ", 0x190006\n s_sub_u32 %[leafSub], %[leafSub], 0x80000\n s_bitset1_b32 %[leafSub], 31\n"   \
-				 " s_mov_b32 %[leafAux], " AUX "\n s_waitcnt lgkmcnt(0)\n s_branch L_end_%=\n"
-#define SNAIL_DESCEND_NARROW()                                                                                                             \
-	asm volatile(SNAIL_DRAIN_SMEM " s_mov_b32 m0, %[sp]\n"                                                                                \
-				 "L_entry_%=:\n"                                                                                                           \
-				 " s_cmp_eq_u32 m0, %[spb]\n s_cbranch_scc1 L_done_%=\n"                                                                \
-				 " s_sub_u32 %[off], m0, 1\n"                                                                                           \
-				 " v_readlane_b32 %[topw], %[stkN], %[off]\n"                                                                              \
-				 " s_and_b32 %[cur], %[topw], 0xfffff\n s_lshl_b32 %[off], %[cur], 5\n"                                                    \
-				 " s_load_dwordx8 s[68:75], %[base], %[off]\n"                                                                             \
-				 " s_bfe_u32 %[first], %[topw], 0x60014\n s_lshr_b32 %[last], %[topw], 26\n" SNAIL_PF2_ALIVE                               \
-				 "L_pop_%=:\n"                                                                                                             \
-				 " s_sub_u32 m0, m0, 1\n" SNAIL_COUNT                                                                                     \
-				 " s_mov_b64 exec, %[alive]\n"                                                                                             \
-				 " s_waitcnt lgkmcnt(0)\n" SNAIL_A_FROM_T                                                                                  \
-				 " s_sub_u32 %[off], m0, 1\n s_max_i32 %[off], %[off], 0\n"                                                               \
-				 " v_readlane_b32 %[topw], %[stkN], %[off]\n"                                                                              \
-				 SNAIL_SLAB_FAST_R("0", "s84", "s87", "s85", "s88", "s86", "s89")                                                          \
-				 " s_and_b32 %[cur], %[topw], 0xfffff\n s_lshl_b32 %[off], %[cur], 5\n"                                                    \
-				 " s_load_dwordx8 s[68:75], %[base], %[off]\n"                                                                             \
-				 SNAIL_PF2_NEARFAR("s90", "s91", "%[fl]", "s[76:83]", SNAIL_PF_LEAFREQ_SLOT0)                                                \
-				 SNAIL_TAIL_POS("0", "s0")                                                                                                  \
-				 " s_bfe_u32 %[first], %[topw], 0x60014\n s_lshr_b32 %[last], %[topw], 26\n" SNAIL_PF2_ALIVE SNAIL_PF2_ISLEAF("s90")        \
-				 SNAIL_PFN_TAIL("A")                                                                                                        \
-				 SNAIL_PFN_PENDING("B", "s[84:91]", "s82", "s83", "%[width]", "%[fl]", "s76", "s79", "s77", "s80", "s78", "s81")             \
-				 SNAIL_PFN_PENDING("A", "s[76:83]", "s90", "s91", "%[fl]", "%[width]", "s84", "s87", "s85", "s88", "s86", "s89")             \
-				 " s_branch L_visitBp_%=\n"                                                                                                \
-				 SNAIL_PFN_LEAF("A", "s90", "s91") SNAIL_PFN_LEAF("B", "s82", "s83")                                                       \
-				 "L_fail_%=:\n"                                                                                                            \
-				 " s_cmp_eq_u32 m0, %[spb]\n s_cbranch_scc0 L_pop_%=\n"                                                                 \
-				 "L_done_%=:\n s_mov_b32 %[leafSub], 0\n s_mov_b32 %[leafAux], 0\n s_waitcnt lgkmcnt(0)\n"                                  \
-				 "L_end_%=:\n s_mov_b64 exec, -1\n s_mov_b32 %[sp], m0\n"                                                                  \
-				 : [sp] "+s"(sp), [first] "+s"(first), [last] "+s"(last), [cnt] "+s"(cnt), [stkN] "+v"(stkN),                              \
-				   [leafSub] "=&s"(leafSub), [leafAux] "=&s"(leafAux), [cur] "=&s"(sCur), [fl] "=&s"(sFl), [off] "=&s"(sOff),              \
-				   [width] "=&s"(sWidth), [topw] "=&s"(sTopw), [alive] "=&s"(sAlive), [t0] "=&v"(vt[6]), [t1] "=&v"(vt[7]),                \
-				   [t2] "=&v"(vt[8]), [t3] "=&v"(vt[9]), [t4] "=&v"(vt[10]), [t5] "=&v"(vt[11]), [s0] "=&v"(vt[12]), [u0] "=&v"(vt[16])    \
-				 : [base] "s"(nodeBase), [sign16] "s"(sign16), [spb] "s"(spBase), [ix0] "v"(gi[0]), [iy0] "v"(gi[1]), [iz0] "v"(gi[2]), [d0] "v"(gdist) \
-				 : "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", \
-				   "s88", "s89", "s90", "s91", "vcc", "scc", "m0");                                                                        \
-	asm volatile("" ::"s"(sp), "s"(first), "s"(last), "s"(cnt), "v"(stkN), "s"(leafSub), "s"(leafAux), "s"(sCur), "s"(sFl), "s"(sOff),    \
-				 "s"(sWidth), "s"(sTopw), "s"(sAlive), "v"(vt[6]), "v"(vt[7]), "v"(vt[8]), "v"(vt[9]), "v"(vt[10]), "v"(vt[11]), "v"(vt[12]), "v"(vt[16]))
 
 // near/far plane registers by sign octant (bit k set = idir negative on axis k: near plane = bmax[k]); s[84:86] = bmin, s[87:89] = bmax
 #define SNAIL_DESCEND_OCT(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, OCT) SNAIL_DESCEND_OCT_S(SNAIL_POP_2W, SNAIL_PUSH_2W, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, OCT)
@@ -1606,9 +1485,6 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 #ifndef SNAIL_REL_NODES
 #define SNAIL_REL_NODES 1 // primary packets walk camera-relative node records (no plane offsets to compute per visit); 0 = the loop's plain copy
 #endif
-#ifndef SNAIL_NARROW_SUBTREE
-#define SNAIL_NARROW_SUBTREE 0 // primary packets: the subtree under a stack entry whose range holds <= 16 quads is walked one ray per lane (SNAIL_DESCEND_NARROW)
-#endif
 #ifndef SNAIL_REL_SHADOW
 #define SNAIL_REL_SHADOW 1 // shadow packets of k_light walk records relative to their light's position (ShadeArgs::relLight), as primary packets do for the camera
 #endif
@@ -1632,11 +1508,7 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /*
 #pragma unroll
 	for(int k = 0; k < 3; k++) { iv.minIDir[k] = iv.maxIDir[k] = 0.0f; iv.minOrg[k] = iv.maxOrg[k] = org[k][0]; }
 	const int signBits = __builtin_amdgcn_readfirstlane((Q.d[0][0] < 0.0f ? 1 : 0) | (Q.d[1][0] < 0.0f ? 2 : 0) | (Q.d[2][0] < 0.0f ? 4 : 0));
-	float tidBits[4];   // the caller's tid[] as float bits while the loop statements are around (setId)
-#pragma unroll
-	for(int l = 0; l < 4; l++) tidBits[l] = __int_as_float(tid[l]);
 	constexpr bool PF = PACK && SNAIL_NODE_PREFETCH;   // the record-prefetching loop over its own copy of the tree
-	constexpr bool NARROW = SNAIL_NARROW_SUBTREE && SNAIL_DEFER_PUSH && SNAIL_REL_NODES && PF && !SHADOW && POSDIST && !MASK && !BARY; // narrow subtrees one ray per lane
 	const int sign16 = PF ? signBits : signBits << 16; // (PF: sign bit k against an inner record's 1 << axis)
 	const u64 nodeBase = (u64)nodes;
 	// stack slot 0 = the root (PF: record slot 1) with the full quad range.  (float-typed: the only 32-bit INTEGER values that go in and out of the loop
@@ -1659,7 +1531,7 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /*
 			else { SNAIL_DESCEND_ASM_S(POP, PUSH, SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, "", "s84", "s87", "s85", "s88", "s86", "s89"); } \
 		}
 		if(PF) {
-			int sTopw, sNfl;
+			int sTopw;
 			// primary packets (POSDIST) read camera-relative records: no plane offsets to form, a leaf's request is slot 0
 			if(COH) {
 #if SNAIL_REL_SHADOW
@@ -1668,9 +1540,6 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /*
 				if(SHADOW) { SNAIL_WALK_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_ANY, "", SNAIL_COUNT, SNAIL_PF_LEAFREQ_TRI, oct) }
 #endif
 #if SNAIL_REL_NODES
-#if SNAIL_NARROW_SUBTREE && SNAIL_DEFER_PUSH
-				else if(POSDIST && NARROW) { SNAIL_PF2_OCT_WITH(SNAIL_DESCEND_PF2_NARROWTOP, SNAIL_PRE_NONE_X, SNAIL_ORG_SHARED, SNAIL_SLAB_COH_R, SNAIL_TAIL_POS, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_SLOT0, oct) }
-#endif
 				else if(POSDIST) { SNAIL_WALK_PF_OCT(SNAIL_PRE_NONE_X, SNAIL_ORG_SHARED, SNAIL_SLAB_COH_R, SNAIL_TAIL_POS, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_SLOT0, oct) }
 #else
 				else if(POSDIST) { SNAIL_WALK_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_POS, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_TRI, oct) }
@@ -1683,9 +1552,6 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /*
 				if(SHADOW) { SNAIL_WALK_PF_PLAIN(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, "", SNAIL_COUNT, SNAIL_PF_LEAFREQ_TRI); }
 #endif
 #if SNAIL_REL_NODES
-#if SNAIL_NARROW_SUBTREE && SNAIL_DEFER_PUSH
-				else if(POSDIST && NARROW) { SNAIL_PF2_PLAIN_WITH(SNAIL_DESCEND_PF2_NARROWTOP, SNAIL_PRE_NONE_X, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST_R, SNAIL_TAIL_POS, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_SLOT0); }
-#endif
 				else if(POSDIST) { SNAIL_WALK_PF_PLAIN(SNAIL_PRE_NONE_X, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST_R, SNAIL_TAIL_POS, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_SLOT0); }
 #else
 				else if(POSDIST) { SNAIL_WALK_PF_PLAIN(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_POS, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_TRI); }
@@ -1696,45 +1562,11 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /*
 		else { SNAIL_SHARED_VARIANTS(SNAIL_POP_2W, SNAIL_PUSH_2W) }
 #undef SNAIL_SHARED_VARIANTS
 		if(leafSub == 0) break;
-#if SNAIL_NARROW_SUBTREE && SNAIL_DEFER_PUSH
-		if(NARROW && leafSub == 1) {
-			// the top entry's range holds <= 16 quads: its rays one per lane (lane j <- ray j % 4 of quad first0 + j / 4), the entry rewritten in
-			// lane units, the subtree below it walked by SNAIL_DESCEND_NARROW, the leaves intersected in place, one write-back at the end
-			const int spBase = sp - 1;
-			const int top = __builtin_amdgcn_readlane(__float_as_int(stkN), spBase);
-			const int first0 = (top >> 20) & 63, last0 = (int)((unsigned)top >> 26), w = last0 - first0 + 1;
-			asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(stkN) : "s"((top & 0xfffff) | (int)((unsigned)(4 * w - 1) << 26)), "s"(spBase) : "m0");
-			const int srcAddr = (first0 + (lane >> 2)) * 4;
-			float gi[3], gd[3], gdist, g1[1];
-#pragma unroll
-			for(int c = 0; c < 3; c++) { narrowGather<1>(Q.id[c], srcAddr, g1); gi[c] = g1[0]; narrowGather<1>(Q.d[c], srcAddr, g1); gd[c] = g1[0]; }
-			narrowGather<1>(Q.dist, srcAddr, g1); gdist = g1[0];
-			float ntid = __int_as_float(-1);
-			for(;;) {
-				int sTopw;
-				SNAIL_DESCEND_NARROW();
-				if(leafSub == 0) break;
-				leafNarrowInPlace<COH ? M_COH : M_FAST>(tris, leafAux, (int)((unsigned)leafSub & 0x7fffffffu), lane, first, last, org, gd, gdist, ntid, iv, st);
-			}
-			const int q = lane - first0;
-			const bool inRange0 = lane >= first0 && lane <= last0;
-#pragma unroll
-			for(int l = 0; l < 4; l++) {
-				const int src = (q * 4 + l) * 4;
-				const float nd = xbar(src, gdist);
-				const int nt = __builtin_amdgcn_ds_bpermute(src, __float_as_int(ntid));
-				if(inRange0 && nt >= 0) { Q.dist[l] = nd; setId(tidBits[l], nt); }
-			}
-			continue;
-		}
-#endif
 		SNAIL_PRIO_BY_WORK(cnt);
 		if(leafShared<MASK, SHADOW, COH ? M_COH : M_FAST, BARY>(tris, leafAux, (int)((unsigned)leafSub & 0x7fffffffu), size, lane, first, last, org, Q, mask4,
-																 tidBits, bu, bv, iv, st))
+																 tid, bu, bv, iv, st))
 			break;
 	}
-#pragma unroll
-	for(int l = 0; l < 4; l++) tid[l] = __float_as_int(tidBits[l]);
 	st.iters += SHADOW ? (unsigned)cnt : 2u * (unsigned)cnt - 1u;
 }
 
@@ -1762,7 +1594,7 @@ __device__ __forceinline__ void walkPerRayAsm(const uint4 *__restrict__ nodes /*
 			// loop once per sign octant, and this compiler cannot place eight (or even two) copies of it beside the per-ray leaf code ("illegal VGPR
 			// to SGPR copy": the scalar-register pressure of the 16-SGPR triangle record plus three node record sets): they take ONE statement in
 			// which the near / far planes are picked per visit on the scalar side (SNAIL_DESCEND_PF2_SEL).
-			int sTopw, sNfl;
+			int sTopw;
 			if(COH) { SNAIL_DESCEND_PF2_SEL(SNAIL_ORG_PERRAY, SNAIL_SLABO_SEL, SNAIL_TAIL_ANY, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_TRI); }
 			else { SNAIL_WALK_PF_PLAIN(SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_TRI); }
 		} else if(COH) { SNAIL_DESCEND_OCT(SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_COH, SNAIL_TAIL_ANY, SNAIL_COUNT, "", oct) }
