@@ -458,6 +458,11 @@ __device__ __forceinline__ u64 cullQuad(const uint4 *__restrict__ tris, int coun
 #ifndef SNAIL_LEAF_COMPACT
 #define SNAIL_LEAF_COMPACT 1 // 0 = every leaf in the wide form (A/B measurements)
 #endif
+// a hit's triangle index, stored into the caller's per-lane record: an int, or -- inside the hand-written walks -- the same bits in a float: a
+// 32-bit INTEGER VGPR value that lives across the loop statements can end up sharing its undefined register (the instruction selector keeps one
+// per type and path) with the statements' scalar in / out operands, which this compiler reports as "illegal VGPR to SGPR copy"
+__device__ __forceinline__ void setId(int &d, int v) { d = v; }
+__device__ __forceinline__ void setId(float &d, int v) { d = __int_as_float(v); }
 template <int R> struct NarrowRays {
 	float d[3][R], dist[R];
 	int tid[R];
@@ -468,9 +473,9 @@ template <int R> __device__ __forceinline__ void narrowGather(const float (&q)[4
 	if(R == 1) out[0] = selLanes(selLanes(a0, a1, 0xaaaaaaaaaaaaaaaaull), selLanes(a2, a3, 0xaaaaaaaaaaaaaaaaull), 0xccccccccccccccccull);
 	else { out[0] = selLanes(a0, a2, 0xaaaaaaaaaaaaaaaaull); out[R - 1] = selLanes(a1, a3, 0xaaaaaaaaaaaaaaaaull); }
 }
-template <int R, int M>
+template <int R, int M, class TID>
 __device__ __forceinline__ void leafSharedNarrow(const uint4 *__restrict__ tris, int count, int firstTri, int lane, int first, int last,
-												 const float (&org)[3][4], Quad &Q, int (&tid)[4], const Interval &iv, Counters &st) {
+												 const float (&org)[3][4], Quad &Q, TID (&tid)[4], const Interval &iv, Counters &st) {
 	constexpr int LPQ = 4 / R;                      // lanes per quad
 	const int width = last - first + 1;             // count <= 64: one chunk
 	const bool inRange = lane >= first && lane <= last;
@@ -541,7 +546,7 @@ __device__ __forceinline__ void leafSharedNarrow(const uint4 *__restrict__ tris,
 		const int src = (q * LPQ + l / R) * 4;
 		const float nd = xbar(src, N.dist[l % R]);
 		const int nt = __builtin_amdgcn_ds_bpermute(src, N.tid[l % R]);
-		if(inRange && nt >= 0) { Q.dist[l] = nd; tid[l] = nt; }
+		if(inRange && nt >= 0) { Q.dist[l] = nd; setId(tid[l], nt); }
 	}
 }
 
@@ -616,9 +621,9 @@ __device__ __forceinline__ void leafSharedNarrowShadow(const uint4 *__restrict__
 #ifndef SNAIL_LEAF_MASK
 #define SNAIL_LEAF_MASK 1 // 0 = every lane computes everything in the leaf (A/B measurements)
 #endif
-template <bool MASK, bool SHADOW, int M, bool BARY>
+template <bool MASK, bool SHADOW, int M, bool BARY, class TID>
 __device__ __forceinline__ bool leafShared(const uint4 *__restrict__ tris, int count, int firstTri, int size, int lane, int first, int last,
-										   const float (&org)[3][4], Quad &Q, unsigned mask4, int (&tid)[4], float (&bu)[4], float (&bv)[4],
+										   const float (&org)[3][4], Quad &Q, unsigned mask4, TID (&tid)[4], float (&bu)[4], float (&bv)[4],
 										   const Interval &iv, Counters &st) {
 	const float inf = __builtin_inff();
 	const bool inRange = lane >= first && lane <= last;
@@ -675,7 +680,7 @@ __device__ __forceinline__ bool leafShared(const uint4 *__restrict__ tris, int c
 					const float idet = recipExact(det);
 					const float dd = idet * tmul;
 					if(dd < Q.dist[l] && dd > 0.0f) {
-						Q.dist[l] = dd; tid[l] = idx;
+						Q.dist[l] = dd; setId(tid[l], idx);
 						if(BARY) { bu[l] = u * idet; bv[l] = v * idet; }
 					}
 				}
@@ -1508,6 +1513,9 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /*
 #pragma unroll
 	for(int k = 0; k < 3; k++) { iv.minIDir[k] = iv.maxIDir[k] = 0.0f; iv.minOrg[k] = iv.maxOrg[k] = org[k][0]; }
 	const int signBits = __builtin_amdgcn_readfirstlane((Q.d[0][0] < 0.0f ? 1 : 0) | (Q.d[1][0] < 0.0f ? 2 : 0) | (Q.d[2][0] < 0.0f ? 4 : 0));
+	float tidBits[4];   // the caller's tid[] as float bits while the loop statements are around (setId)
+#pragma unroll
+	for(int l = 0; l < 4; l++) tidBits[l] = __int_as_float(tid[l]);
 	constexpr bool PF = PACK && SNAIL_NODE_PREFETCH;   // the record-prefetching loop over its own copy of the tree
 	const int sign16 = PF ? signBits : signBits << 16; // (PF: sign bit k against an inner record's 1 << axis)
 	const u64 nodeBase = (u64)nodes;
@@ -1564,9 +1572,11 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /*
 		if(leafSub == 0) break;
 		SNAIL_PRIO_BY_WORK(cnt);
 		if(leafShared<MASK, SHADOW, COH ? M_COH : M_FAST, BARY>(tris, leafAux, (int)((unsigned)leafSub & 0x7fffffffu), size, lane, first, last, org, Q, mask4,
-																 tid, bu, bv, iv, st))
+																 tidBits, bu, bv, iv, st))
 			break;
 	}
+#pragma unroll
+	for(int l = 0; l < 4; l++) tid[l] = __float_as_int(tidBits[l]);
 	st.iters += SHADOW ? (unsigned)cnt : 2u * (unsigned)cnt - 1u;
 }
 
