@@ -54,7 +54,9 @@ int snail_device_count(void);
 int snail_tris_from_verts(const float *verts9, int n, void *tris64);
 /* BVH::Construct(scene, BVH::useSah) -> FindSplitSweep (src/bvh/tree.cpp:293-328, 51-159).
  * Permutes tris64 in place (this ordering DEFINES triId).  nodes32 must hold 2*nTris records.
- * perm (optional) receives, per final slot, the index the triangle had on input. */
+ * perm (optional) receives, per final slot, the index the triangle had on input.
+ * Both host-side functions compute under the default floating-point environment (round to nearest, denormals kept) whatever the
+ * calling thread's MXCSR says, and restore it: the tree does not depend on what else the process has loaded. */
 int snail_bvh_build(void *tris64, int nTris, void *nodes32, int *nNodes, int *depth, int32_t *perm);
 
 /* ---- device scene -------------------------------------------------------------------------------- */
