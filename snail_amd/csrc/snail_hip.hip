@@ -1350,13 +1350,16 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 #define SNAIL_PF2_LEAF(X, SUB, AUX)                                                                                                         \
 				 "L_leaf" X "_%=:\n" SNAIL_PF2_FIRSTLAST                                                                                    \
 				 " s_bfe_u32 %[leafSub], " SUB ", 0x190006\n s_sub_u32 %[leafSub], %[leafSub], 0x80000\n s_bitset1_b32 %[leafSub], 31\n"   \
-				 " s_mov_b32 %[leafAux], " AUX "\n s_waitcnt lgkmcnt(0)\n" /* T = the top entry's record has arrived: it leaves with topw and alive */ \
-				 " s_mov_b64 %[tr0], s[68:69]\n s_mov_b64 %[tr1], s[70:71]\n s_mov_b64 %[tr2], s[72:73]\n s_mov_b64 %[tr3], s[74:75]\n s_branch L_end_%=\n"
+				 " s_mov_b32 %[leafAux], " AUX "\n s_waitcnt lgkmcnt(0)\n s_branch L_end_%=\n"
 #define SNAIL_DESCEND_PF2X(EXTRACLOB, PREVARS, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, LEAFREQ, NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)                                                  \
 	asm volatile(SNAIL_DRAIN_SMEM " s_mov_b32 m0, %[sp]\n"                                                                                \
-				 "L_entry_%=:\n" /* topw, alive and T come in as the previous statement left them (the caller sets them up for the root) */      \
+				 "L_entry_%=:\n"                                                                                                           \
 				 " s_cmp_eq_u32 m0, 0\n s_cbranch_scc1 L_done_%=\n"                                                                     \
-				 " s_mov_b64 s[68:69], %[tr0]\n s_mov_b64 s[70:71], %[tr1]\n s_mov_b64 s[72:73], %[tr2]\n s_mov_b64 s[74:75], %[tr3]\n"     \
+				 " s_sub_u32 %[off], m0, 1\n"                                                                                           \
+				 " v_readlane_b32 %[topw], %[stkN], %[off]\n"                                                                              \
+				 " s_and_b32 %[cur], %[topw], 0xfffff\n s_lshl_b32 %[off], %[cur], 5\n"                                                    \
+				 " s_load_dwordx8 s[68:75], %[base], %[off]\n"                                                                             \
+				 " s_bfe_u32 %[first], %[topw], 0x60014\n s_lshr_b32 %[last], %[topw], 26\n" SNAIL_PF2_ALIVE                               \
 				 "L_pop_%=:\n" /* sp > 0, topw = the top entry, alive = its lanes, T = its record (requested) */                            \
 				 " s_sub_u32 m0, m0, 1\n" CNTPOP                                                                                     \
 				 " s_mov_b64 exec, %[alive]\n"                                                                                             \
@@ -1385,9 +1388,8 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 "L_done_%=:\n s_mov_b32 %[leafSub], 0\n s_mov_b32 %[leafAux], 0\n s_waitcnt lgkmcnt(0)\n"                                  \
 				 "L_end_%=:\n s_mov_b64 exec, -1\n s_mov_b32 %[sp], m0\n"                                                                                        \
 				 : [sp] "+s"(sp), [first] "+s"(first), [last] "+s"(last), [cnt] "+s"(cnt), [stkN] "+v"(stkN), [stkF] "+v"(stkF),           \
-				   [topw] "+s"(sTopw), [alive] "+s"(sAlive), [tr0] "+s"(tRec[0]), [tr1] "+s"(tRec[1]), [tr2] "+s"(tRec[2]), [tr3] "+s"(tRec[3]), \
 				   [leafSub] "=&s"(leafSub), [leafAux] "=&s"(leafAux), [cur] "=&s"(sCur), [fl] "=&s"(sFl), [off] "=&s"(sOff),              \
-				   [width] "=&s"(sWidth), PREVARS() [t0] "=&v"(vt[6]), [t1] "=&v"(vt[7]),   \
+				   [width] "=&s"(sWidth), [topw] "=&s"(sTopw), [alive] "=&s"(sAlive), PREVARS() [t0] "=&v"(vt[6]), [t1] "=&v"(vt[7]),   \
 				   [t2] "=&v"(vt[8]), [t3] "=&v"(vt[9]), [t4] "=&v"(vt[10]), [t5] "=&v"(vt[11]), [s0] "=&v"(vt[12]), [s1] "=&v"(vt[13]),   \
 				   [s2] "=&v"(vt[14]), [s3] "=&v"(vt[15]), [u0] "=&v"(vt[16])                                                              \
 				 : [base] "s"(nodeBase), [sign16] "s"(sign16), [lane] "v"(lane), ORGOPS(), [ix0] "v"(Q.id[0][0]), [ix1] "v"(Q.id[0][1]), [ix2] "v"(Q.id[0][2]), [ix3] "v"(Q.id[0][3]),        \
@@ -1397,7 +1399,7 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 				 : "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", \
 				   "s88", "s89", "s90", "s91", "vcc", "scc", "m0" EXTRACLOB);                                                                        \
 	asm volatile("" ::"s"(sp), "s"(first), "s"(last), "s"(cnt), "v"(stkN), "v"(stkF), "s"(leafSub), "s"(leafAux), "s"(sCur), "s"(sFl), "s"(sOff),    \
-				 "s"(sWidth), "s"(sTopw), "s"(sAlive), "s"(tRec[0]), "s"(tRec[1]), "s"(tRec[2]), "s"(tRec[3]), "v"(vt[6]), "v"(vt[7]), \
+				 "s"(sWidth), "s"(sTopw), "s"(sAlive), "v"(vt[6]), "v"(vt[7]), \
 				 "v"(vt[8]), "v"(vt[9]), "v"(vt[10]), "v"(vt[11]), "v"(vt[12]), "v"(vt[13]), "v"(vt[14]), "v"(vt[15]), "v"(vt[16]))
 // the six plane-offset registers of SNAIL_PRE_SHARED are operands only where a visit forms them (PREVARS = SNAIL_PREVARS_of(PRE))
 #define SNAIL_PREVARS_SHARED() [pnx] "=&v"(vt[0]), [pny] "=&v"(vt[1]), [pnz] "=&v"(vt[2]), [pfx] "=&v"(vt[3]), [pfy] "=&v"(vt[4]), [pfz] "=&v"(vt[5]),
@@ -1493,13 +1495,6 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 #endif
 // the node array a PACK instantiation of the hand-written walks is given: the prefetching loop's own copy of the tree
 #define SNAIL_PACK_NODES(A) (SNAIL_NODE_PREFETCH ? (A).pf : (A).nodes)
-// the root's record (slot 1 of the loop's node array) as the four register pairs of the statement's T set
-__device__ __forceinline__ void pfRootRecord(const uint4 *nodes, u64 (&tRec)[4]) {
-	scalar_ptr p = (scalar_ptr)((scalar_bytes)(unsigned long long)nodes + 32);
-	const u32x4 a = p[0], b = p[1];
-	tRec[0] = (u64)a.x | (u64)a.y << 32; tRec[1] = (u64)a.z | (u64)a.w << 32;
-	tRec[2] = (u64)b.x | (u64)b.y << 32; tRec[3] = (u64)b.z | (u64)b.w << 32;
-}
 template <bool SHADOW, bool COH, bool PACK, bool MASK, bool BARY, bool POSDIST>
 __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /* PACK: the prefetching loop's copy, SnailScene::dPF */, const uint4 *__restrict__ tris, int size, int lane,
 											  const float (&org)[3][4], Quad &Q, unsigned mask4, int (&tid)[4], float (&bu)[4], float (&bv)[4], float *lds,
@@ -1529,14 +1524,9 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /*
 	// undefined VGPR feeding a scalar operand's PHI is this compiler's "illegal VGPR to SGPR copy")
 	float stkN = __int_as_float(PACK ? (int)((unsigned)(size - 1) << 26) | (PF ? 1 : 0) : 0), stkF = __int_as_float((size - 1) << 8);
 	int sp = 1, first = 0, last = size - 1, cnt = 0;
-	// SNAIL_DESCEND_PF2X keeps the top entry's stack word, lane mask and record in registers from one statement to the next (the leaf code runs in
-	// between): here those of the root entry
-	int sTopw = __float_as_int(stkN);
-	u64 sAlive = rangeMask(0, size - 1), tRec[4] = {0, 0, 0, 0};
-	if(PF && SNAIL_DEFER_PUSH) pfRootRecord(nodes, tRec);
 	for(;;) {
 		int leafSub, leafAux, sCur, sFl, sOff, sWidth;
-		u64 sRng;
+		u64 sRng, sAlive;
 		float vt[17];
 #define SNAIL_SHARED_VARIANTS(POP, PUSH)                                                                                                   \
 		if(COH) {                                                                                                                          \
@@ -1549,6 +1539,7 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /*
 			else { SNAIL_DESCEND_ASM_S(POP, PUSH, SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, "", "s84", "s87", "s85", "s88", "s86", "s89"); } \
 		}
 		if(PF) {
+			int sTopw;
 			// primary packets (POSDIST) read camera-relative records: no plane offsets to form, a leaf's request is slot 0
 			if(COH) {
 #if SNAIL_REL_SHADOW
@@ -1604,18 +1595,16 @@ __device__ __forceinline__ void walkPerRayAsm(const uint4 *__restrict__ nodes /*
 	const u64 nodeBase = (u64)nodes;
 	float stkN = __int_as_float(PF ? (int)((unsigned)(size - 1) << 26) | 1 : 0), stkF = __int_as_float((size - 1) << 8); // stack slot 0 = the root (PF: record slot 1) with the full quad range; float-typed as in walkSharedAsm
 	int sp = 1, first = 0, last = size - 1, cnt = 0;
-	int sTopw = __float_as_int(stkN);   // (the root entry's word, lane mask and record, as in walkSharedAsm)
-	u64 sAlive = rangeMask(0, size - 1), tRec[4] = {0, 0, 0, 0};
-	if(PF && SNAIL_DEFER_PUSH) pfRootRecord(nodes, tRec);
 	for(;;) {
 		int leafSub, leafAux, sCur, sFl, sOff, sWidth;
-		u64 sRng;
+		u64 sRng, sAlive;
 		float vt[17];
 		if(PF) {
 			// one-word stack entries + node records fetched ahead.  Non-coherent packets: the plain form of the loop.  Coherent packets would need the
 			// loop once per sign octant, and this compiler cannot place eight (or even two) copies of it beside the per-ray leaf code ("illegal VGPR
 			// to SGPR copy": the scalar-register pressure of the 16-SGPR triangle record plus three node record sets): they take ONE statement in
 			// which the near / far planes are picked per visit on the scalar side (SNAIL_DESCEND_PF2_SEL).
+			int sTopw;
 			if(COH) { SNAIL_DESCEND_PF2_SEL(SNAIL_ORG_PERRAY, SNAIL_SLABO_SEL, SNAIL_TAIL_ANY, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_TRI); }
 			else { SNAIL_WALK_PF_PLAIN(SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_FAST, SNAIL_TAIL_ANY, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_TRI); }
 		} else if(COH) { SNAIL_DESCEND_OCT(SNAIL_PRE_NONE, SNAIL_ORG_PERRAY, SNAIL_SLABO_COH, SNAIL_TAIL_ANY, SNAIL_COUNT, "", oct) }
