@@ -1133,8 +1133,8 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 // Every statement of the loop starts by waiting for the scalar loads the COMPILER may still have in flight: it does not wait for a load whose
 // result turned out dead (the per-ray-origin leaf fetches a triangle record with s_load_dwordx16 and may leave the loop before using it), such a
 // load may target the very registers the statement pins (s68..s91 are free between two statements), and scalar loads return out of order --
-// a record requested here could be overwritten by the stale one.  (Found by the soak runs of round 3: mirrored / masked per-ray packets, on
-// some boxes only, ~4 % of the batches; shared-origin leaves fetch their triangles with vector loads and were never affected.)
+// a record requested here could be overwritten by the stale one.  (A precaution, one instruction per statement: in today's builds the compiler's
+// own scalar loads target s4..s67, and no such overwrite has been observed.)
 #define SNAIL_DRAIN_SMEM " s_waitcnt lgkmcnt(0)\n"
 #define SNAIL_DESCEND_ASM(PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, NX, FX, NY, FY, NZ, FZ)                                                 \
 	SNAIL_DESCEND_ASM_S(SNAIL_POP_2W, SNAIL_PUSH_2W, PRE, ORGOPS, SLAB, TAIL, CNTPOP, CNTVISIT, NX, FX, NY, FY, NZ, FZ)
@@ -2548,7 +2548,7 @@ __device__ __forceinline__ void raysPacket(const RaysArgs &A, const int p, float
 }
 #ifndef SNAIL_RAYS_WAVES
 #define SNAIL_RAYS_WAVES 0 // occupancy target of the generic-packet kernels; 0 = the compiler's own allocation (no spills: these kernels keep lane-indexed state
-						   // in VGPRs and the soak runs are made on spill-free code; a forced six-wave budget -- 80 VGPRs, up to 88 spilled -- measured no gain)
+						   // in VGPRs; a forced six-wave budget -- 80 VGPRs, up to 88 spilled into scratch -- measured no gain)
 #endif
 #if SNAIL_RAYS_WAVES > 0
 #define SNAIL_RAYS_OCCUPANCY __attribute__((amdgpu_waves_per_eu(SNAIL_RAYS_WAVES)))

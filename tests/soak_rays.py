@@ -28,7 +28,7 @@ for b in range(batches):
     if rng.rand() < 0.7 or focus.startswith("perray"):
         shared, masked, poison = bool(rng.rand() < 0.5), bool(rng.rand() < 0.5), bool(rng.rand() < 0.15)
         if focus.startswith("perray"): shared, masked, poison = False, True, False
-        if focus == "perray1": size = int(rng.randint(1, 4))   # tiny packets: where the round-3 soak saw its mismatches
+        if focus == "perray1": size = int(rng.randint(1, 4))   # tiny packets (a masked placeholder ray in lane 0 is likely: what tells the packet's octant from lane 0's signs)
         if poison and size < 3: poison = False
         origin, dirs, idir, mask, dist, obj, bary = util.secondary_packets(osc, cam, 640, 368, npk, seed=int(rng.randint(1 << 30)), shared=shared, masked=masked,
                                                                            size=size, poison=poison)

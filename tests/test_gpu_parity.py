@@ -1473,8 +1473,8 @@ def test_origin_relative_record_cache_over_many_origins(torch_mod):
 @pytest.mark.parametrize("name", ["stress:0.05", "atrium:0.05"])
 def test_tiny_masked_per_ray_origin_packets(torch_mod, name):
     """Packets of one to three quads with lane masks and per-ray origins (what a mirrored bounce leaves of a packet that mostly missed):
-    400 seeded batches through the generic entry point, hit records, barycentrics and counters equal the oracle's -- the case a round-3
-    soak saw differ on one box (profiles/r3_final_soak.txt)."""
+    400 seeded batches through the generic entry point, hit records, barycentrics and counters equal the oracle's -- the packets a work-in-progress
+    version of the coherent per-ray loop got wrong in round 3 (planes chosen by lane 0's signs instead of the packet's octant: profiles/r3_final_soak.txt)."""
     from snail_amd.scene import Context
     tv, sc, osc = gpu_scene(name)
     cam = util.camera_for(name, tv)
