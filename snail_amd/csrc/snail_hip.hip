@@ -1495,7 +1495,7 @@ __device__ __forceinline__ void walk(const uint4 *__restrict__ nodes, const uint
 #endif
 // the node array a PACK instantiation of the hand-written walks is given: the prefetching loop's own copy of the tree
 #define SNAIL_PACK_NODES(A) (SNAIL_NODE_PREFETCH ? (A).pf : (A).nodes)
-template <bool SHADOW, bool COH, bool PACK, bool MASK, bool BARY, bool POSDIST>
+template <bool SHADOW, bool COH, bool PACK, bool MASK, bool BARY, bool POSDIST, bool REL = true /* PACK: `nodes` holds records relative to the packet's origin (else the loop's plain copy) */>
 __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /* PACK: the prefetching loop's copy, SnailScene::dPF */, const uint4 *__restrict__ tris, int size, int lane,
 											  const float (&org)[3][4], Quad &Q, unsigned mask4, int (&tid)[4], float (&bu)[4], float (&bv)[4], float *lds,
 											  Counters &st, const int oct) {
@@ -1542,11 +1542,8 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /*
 			int sTopw;
 			// primary packets (POSDIST) read camera-relative records: no plane offsets to form, a leaf's request is slot 0
 			if(COH) {
-#if SNAIL_REL_SHADOW
-				if(SHADOW) { SNAIL_WALK_PF_OCT(SNAIL_PRE_NONE_X, SNAIL_ORG_SHARED, SNAIL_SLAB_COH_R, SNAIL_TAIL_ANY, "", SNAIL_COUNT, SNAIL_PF_LEAFREQ_SLOT0, oct) }
-#else
-				if(SHADOW) { SNAIL_WALK_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_ANY, "", SNAIL_COUNT, SNAIL_PF_LEAFREQ_TRI, oct) }
-#endif
+				if(SHADOW && REL && SNAIL_REL_SHADOW) { SNAIL_WALK_PF_OCT(SNAIL_PRE_NONE_X, SNAIL_ORG_SHARED, SNAIL_SLAB_COH_R, SNAIL_TAIL_ANY, "", SNAIL_COUNT, SNAIL_PF_LEAFREQ_SLOT0, oct) }
+				else if(SHADOW) { SNAIL_WALK_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_ANY, "", SNAIL_COUNT, SNAIL_PF_LEAFREQ_TRI, oct) }
 #if SNAIL_REL_NODES
 				else if(POSDIST) { SNAIL_WALK_PF_OCT(SNAIL_PRE_NONE_X, SNAIL_ORG_SHARED, SNAIL_SLAB_COH_R, SNAIL_TAIL_POS, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_SLOT0, oct) }
 #else
@@ -1554,11 +1551,8 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /*
 #endif
 				else { SNAIL_WALK_PF_OCT(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_COH, SNAIL_TAIL_ANY, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_TRI, oct) }
 			} else {
-#if SNAIL_REL_SHADOW
-				if(SHADOW) { SNAIL_WALK_PF_PLAIN(SNAIL_PRE_NONE_X, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST_R, SNAIL_TAIL_ANY, "", SNAIL_COUNT, SNAIL_PF_LEAFREQ_SLOT0); }
-#else
-				if(SHADOW) { SNAIL_WALK_PF_PLAIN(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, "", SNAIL_COUNT, SNAIL_PF_LEAFREQ_TRI); }
-#endif
+				if(SHADOW && REL && SNAIL_REL_SHADOW) { SNAIL_WALK_PF_PLAIN(SNAIL_PRE_NONE_X, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST_R, SNAIL_TAIL_ANY, "", SNAIL_COUNT, SNAIL_PF_LEAFREQ_SLOT0); }
+				else if(SHADOW) { SNAIL_WALK_PF_PLAIN(SNAIL_PRE_SHARED, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST, SNAIL_TAIL_ANY, "", SNAIL_COUNT, SNAIL_PF_LEAFREQ_TRI); }
 #if SNAIL_REL_NODES
 				else if(POSDIST) { SNAIL_WALK_PF_PLAIN(SNAIL_PRE_NONE_X, SNAIL_ORG_SHARED, SNAIL_SLAB_FAST_R, SNAIL_TAIL_POS, SNAIL_COUNT, "", SNAIL_PF_LEAFREQ_SLOT0); }
 #else
@@ -1582,6 +1576,9 @@ __device__ __forceinline__ void walkSharedAsm(const uint4 *__restrict__ nodes /*
 
 // closest hit of a packet with per-ray origins (TraversePrimaryN<0,mask>), node loop in assembly as in walkSharedAsm; any
 // distance on entry (masked lanes -inf), `size` quads
+#ifndef SNAIL_SHADOW_ENTRY_PF
+#define SNAIL_SHADOW_ENTRY_PF 1 // the packets of snail_trace_shadow and of snail_trace_rays with shared origins through the prefetching loop (0 = the plain two-word loop, as before round 3)
+#endif
 #ifndef SNAIL_PERRAY_COH_PF
 #define SNAIL_PERRAY_COH_PF SNAIL_DEFER_PUSH // coherent per-ray-origin packets (most mirrored packets) through the prefetching loop as well (SNAIL_DESCEND_PF2_SEL)
 #endif
@@ -2529,7 +2526,10 @@ __device__ __forceinline__ void raysPacket(const RaysArgs &A, const int p, float
 				else walkPerRayAsm<MASK, false, BARY, true>(SNAIL_PACK_NODES(A), A.tris, size, lane, org, Q, mask4, tid, bu, bv, st, 0);
 			} else if(mode == M_COH) walkPerRayAsm<MASK, true, BARY, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, st, oct);
 			else walkPerRayAsm<MASK, false, BARY, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, st, 0);
-		} else if(SHARED && !DEEP) { // shared origin, any distances on entry
+		} else if(SHARED && !DEEP && A.pack && SNAIL_SHADOW_ENTRY_PF) { // shared origin, any distances on entry: the prefetching loop over its plain copy of the tree
+			if(mode == M_COH) walkSharedAsm<false, true, true, MASK, BARY, false, false>(SNAIL_PACK_NODES(A), A.tris, size, lane, org, Q, mask4, tid, bu, bv, lds, st, oct);
+			else walkSharedAsm<false, false, true, MASK, BARY, false, false>(SNAIL_PACK_NODES(A), A.tris, size, lane, org, Q, mask4, tid, bu, bv, lds, st, 0);
+		} else if(SHARED && !DEEP) {
 			if(mode == M_COH) walkSharedAsm<false, true, false, MASK, BARY, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, lds, st, oct);
 			else walkSharedAsm<false, false, false, MASK, BARY, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, lds, st, 0);
 		} else if(mode == M_COH) walk<SHARED, MASK, false, M_COH, BARY, DEEP, false>(A.nodes, A.tris, size, lane, org, Q, mask4, tid, bu, bv, lds, st, oct);
@@ -2610,6 +2610,9 @@ __device__ __forceinline__ void shadowPacket(const RaysArgs &A, const int p, flo
 		if(DEEP) {
 			if(mode == M_COH) walk<true, false, true, M_COH, false, DEEP, false>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, lds, st, oct);
 			else walk<true, false, true, M_FAST, false, DEEP, false>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, lds, st);
+		} else if(A.pack && SNAIL_SHADOW_ENTRY_PF) { // the prefetching loop over its plain copy of the tree (origins differ from packet to packet: no relative records)
+			if(mode == M_COH) walkSharedAsm<true, true, true, false, false, false, false>(SNAIL_PACK_NODES(A), A.tris, size, lane, org, Q, 15u, tid, bu, bv, lds, st, oct);
+			else walkSharedAsm<true, false, true, false, false, false, false>(SNAIL_PACK_NODES(A), A.tris, size, lane, org, Q, 15u, tid, bu, bv, lds, st, 0);
 		} else if(mode == M_COH) walkSharedAsm<true, true, false, false, false, false>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, lds, st, oct);
 		else walkSharedAsm<true, false, false, false, false, false>(A.nodes, A.tris, size, lane, org, Q, 15u, tid, bu, bv, lds, st, 0);
 	}
