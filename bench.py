@@ -91,7 +91,7 @@ def kernel_source_sha16() -> str:
     old instruction count."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("snail_hip.hip", "lbvh.inc"):
+    for f in ("snail_hip.hip", "snail_dev.inc", "lbvh.inc", "render_host.inc", "host_sse.h", "Makefile"):
         with open(os.path.join(ROOT, "snail_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -201,6 +201,7 @@ def main():
     ap.add_argument("--camera-path", default="static", choices=["static", "orbit"], help="orbit = the camera turns 0.2 degrees every step (dispatch orders are then predictions from an older view, re-derived every --order-refresh frames of a slot, inside the timed region)")
     ap.add_argument("--settle-ms", type=float, default=30.0, help="untimed frames for this many milliseconds BEFORE the W warm-up steps: the part's clocks ramp for tens of ms after an idle start (2.09 -> 1.91 -> 2.2 GHz over the first 600 frames, profiles/README.md), which a 20-step timed region would otherwise measure instead of the kernel; 0 = off; reported as config.settle_ms")
     ap.add_argument("--dry-run", action="store_true", help="start the ranks, rendezvous, one all-reduce over the chosen backend, print {dry_run, ranks} and exit: checks the launch path without a GPU (with --backend gloo)")
+    ap.add_argument("--arith", default="ieee", choices=["ieee", "host_sse"], help="arithmetic of the path's approximate operations (include/snail_hip.h): ieee = veclib's scalar definitions; host_sse = veclib's SSE definitions as this host's CPU executes them (rcpps / rsqrtps reproduced on the device + Newton), i.e. the reference's x86 results bit for bit")
     ap.add_argument("--order-refresh", type=int, default=16, help="frames of a slot between two derivations of its dispatch order while the camera moves (DistributedRenderer order_refresh)")
     args = ap.parse_args()
 
@@ -262,6 +263,7 @@ def main():
         from snail_amd import survey_camera
         cam = survey_camera(tv)
     scene = Scene(hbvh, local_rank)
+    scene.set_arith(args.arith)
     resx, resy = cfg["res"] if (world == 1 or args.scaling == "strong") else weak_frame_size(world, cfg["res"])
     lights7 = None
     if cfg["lights"]:
@@ -383,6 +385,30 @@ def main():
         fpl1 = {"value": round(primary_rays * args.steps / dt1 / 1e6, 2), "ms_per_step": round(dt1 * 1e3 / args.steps, 5), "frames_per_launch": 1,
                 "frames_in_flight": r1.nslots, "note": "the same %d steps after the timed region with one frame per launch (not the headline)" % args.steps}
 
+    # ---- the same K steps in the OTHER arithmetic (N = 1): both modes' rates in one line ----
+    other = None
+    if rank == 0 and world == 1 and args.lone_frames > 0:
+        other_name = "host_sse" if args.arith == "ieee" else "ieee"
+        try:
+            scene.set_arith(other_name)
+            r2 = DistributedRenderer(scene, resx, resy, 0, 1, slots=args.streams if args.streams > 0 else None, feedback_order=bool(args.feedback_order), lights7=lights7,
+                                     frames_per_launch=rnd.batch, order_refresh=args.order_refresh)
+            for i in range(max(8 * rnd.batch, min(args.warmup, 100) // rnd.batch * rnd.batch)):
+                r2.render(cam_at(i))
+            r2.flush()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for c in cams_timed:
+                r2.render(c)
+            r2.flush()
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            other = {"arith": other_name, "value": round(total_rays * args.steps / dt2 / 1e6, 2), "ms_per_step": round(dt2 * 1e3 / args.steps, 5),
+                     "note": "the same %d steps after the timed region in the other arithmetic (not the headline)" % args.steps}
+        except Exception as e:      # a host whose rcpps / rsqrtps cannot be tabulated: reported, not fatal
+            other = {"arith": other_name, "value": None, "note": str(e)}
+        scene.set_arith(args.arith)
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         step_s = ms_per_step * 1e-3
@@ -414,7 +440,7 @@ def main():
                 "lanes_live_per_valu_inst": tr.get("lanes_live_per_valu_inst") if tr else None, "kernels": tr.get("kernels") if tr else None, "counters_source": (tr.get("source") + shared_note) if tr else "no PMC pass committed for workload key %s" % key,
                 "kernel": tr.get("kernel", "dev::k_primary") if tr else "dev::k_primary", "kernel_ms": round(kern_ms, 5), "kernel_ms_note": "HIP events around one launch (%d frame(s)) on its own stream while %d launches are in flight: overlapped, not a stand-alone duration; every fraction here uses ms_per_step (per frame) and per-frame counters" % (rnd.batch, rnd.nslots),
                 "denominator_ms": round(ms_per_step, 5), "lone_frame_ms": round(lone_ms, 5) if lone_ms is not None else None,
-                "one_frame_per_launch": fpl1}
+                "one_frame_per_launch": fpl1, "other_arith": other}
         if pk is not None:
             visits, fetched = int(pk[:, 0].sum()), int(pk[:, 4].sum())
             pbytes = 32 * visits + 64 * fetched + 16 * 256 * len(pk)
@@ -442,7 +468,7 @@ def main():
             "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: gloo, ranks share one GPU -- not a measurement)",
             "config": {"workload": "BASELINE config %d: %s (%d tris%s) %dx%d %s" % (args.config, scene_name, hbvh.n_tris,
                                                                                      ", sponza.obj stand-in" if scene_name.startswith("atrium") else "", resx, resy, cfg["what"]),
-                       "baseline_config": args.config, "rays_per_step": total_rays, "primary_rays_per_step": primary_rays, "node_visits_per_step": node_visits,
+                       "baseline_config": args.config, "arith": args.arith, "rays_per_step": total_rays, "primary_rays_per_step": primary_rays, "node_visits_per_step": node_visits,
                        "packets": "16x16 px = 1 wavefront", "bvh_nodes": hbvh.n_nodes, "bvh_depth": hbvh.depth,
                        "bvh_build_s": round(build_s, 3), "hit_fraction": round(hit_frac, 5), "frames_in_flight": rnd.nslots * rnd.batch, "frames_per_launch": rnd.batch, "launches_in_flight": rnd.nslots,
                        "lone_launch_ms": round(lone_launch_ms, 5) if lone_launch_ms is not None else None,

@@ -82,6 +82,31 @@ int snail_scene_info(const SnailScene *, int *nNodes, int *nTris, int *depth, in
  * the node loop that rescans the whole inherited quad range at every box, exactly as src/bounding_box.cpp:71-139 does). */
 int snail_scene_flags(const SnailScene *, int *fastOK, int *nestedOK);
 
+/* ---- arithmetic of the path's approximate operations ---------------------------------------------- */
+/* The reference's veclib has two definitions of Inv / RSqrt / FastInv: the scalar one (1 / x, 1 / sqrt(x), correctly rounded:
+ * veclib/vecbase.h:53-57) and the one its x86 build executes -- rcpps / rsqrtps + one Newton step (veclib/sse/base.h:84-92,
+ * veclib/sse/f32.h:98-102), whose low bits depend on the CPU's look-up tables.  They differ by ~1e-7 relative; the operations reach
+ * the hit records through the normalisation and inversion of ray directions (src/ray_generator.cpp:41-44, src/rtbase.h:117-120,
+ * src/scene_trace.cpp:547,:615), through 1 / det of an accepted hit (src/triangle.cpp:55), and the pictures additionally through
+ * the depth shading (src/scene_trace.cpp:128-137) and the light's attenuation (:585-587).
+ *   SNAIL_ARITH_IEEE      (default) the scalar definitions: results do not depend on the host.
+ *   SNAIL_ARITH_HOST_SSE  the SSE definitions AS THE HOST'S CPU EXECUTES THEM: its rcpps / rsqrtps tables (3 x 4096 words, taken from
+ *                         the CPU at first use and verified against the instructions) are reproduced on the device, followed by
+ *                         veclib's Newton steps, each operation rounded separately.  Every entry point that takes the scene then returns
+ *                         what the reference's SSE build computes on this machine, bit for bit (hit records, TreeStats, pictures).
+ * snail_scene_set_arith returns 2 -- nothing changes -- when the host's instructions do not have the table structure (host_sse.h);
+ * rays handed in by the caller (snail_trace_rays / _shadow) are used as they are: only 1 / det depends on the mode there. */
+#define SNAIL_ARITH_IEEE     0
+#define SNAIL_ARITH_HOST_SSE 1
+int snail_scene_set_arith(SnailScene *, int arith);
+int snail_scene_arith(const SnailScene *, int *arith);
+/* The host CPU's tables: T_rcp[4096] (bits of rcpps(1.m), index m >> 11), T_rsqrt[4096] for [1, 2), T_rsqrt[4096] for [2, 4); NULL = only
+ * the status.  No device needed. */
+int snail_host_sse_tables(uint32_t *tables12288);
+/* The table rule against the instruction itself over the float bit patterns [first, first + count) (fn 0 = rcpps, 1 = rsqrtps), on
+ * `threads` host threads: *mismatches = inputs whose result bits differ, *firstBad = the lowest of them.  No device needed. */
+int snail_host_sse_check(int fn, uint64_t first, uint64_t count, int threads, uint64_t *mismatches, uint32_t *firstBad);
+
 /* ---- primary packets: RayGenerator + SafeInv + TraversePrimary<1,0> ----------------------------- */
 /* Replaces the per-packet body of RenderTask::Work (src/render.cpp:58-62,67-68,112-115) plus the
  * hit-array initialisation of Scene::RayTrace (src/scene_trace.cpp:106-120) for every 16x16 packet
@@ -177,6 +202,8 @@ int snail_trace_shadow_dev(SnailScene *, int nPackets, int size, const float *d_
  * d_bgr: packet-major bytes [nPackets][256][3].  This is what a render node returns per tile in the reference
  * (RGB8, src/node.cpp:336-349) and what the multi-GPU path gathers over xGMI. */
 int snail_shade_depth_dev(const float *d_t, int nPackets, uint8_t *d_bgr, void *stream);
+/* (the same with the arithmetic of Inv(t) named: SNAIL_ARITH_*; the call above = SNAIL_ARITH_IEEE) */
+int snail_shade_depth_arith_dev(const float *d_t, int nPackets, uint8_t *d_bgr, int arith, void *stream);
 /* Scatter packet-major BGR bytes into an interleaved rgb8 frame (pitch bytes per row), clipped to the image. */
 int snail_packets_bgr_to_frame_dev(const int32_t *d_packet_xy, int nPackets, int resx, int resy, const uint8_t *d_bgr,
                                    uint8_t *d_frame, int pitch, void *stream);

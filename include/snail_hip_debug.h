@@ -29,6 +29,11 @@ int snail_debug_clock_dev(float microseconds, uint64_t *d_out2, void *stream);
  * (2 * 252 * 2^23).  Blocks the device for a few tens of milliseconds. */
 int snail_debug_recip_check(uint64_t out2[2]);
 
+/* SNAIL_ARITH_HOST_SSE: the DEVICE's reproduction of the host CPU's rcpps (fn 0) / rsqrtps (fn 1) over all 2^32 float bit patterns against
+ * the instructions themselves, by checksums over chunks of 65536 consecutive patterns (the host's sums on `threads` threads):
+ * *badChunks = chunks that differ (must be 0), *firstBadChunk = the lowest of them. */
+int snail_debug_hostsse_device_check(int fn, int threads, uint64_t *badChunks, uint32_t *firstBadChunk);
+
 /* Time per launch of an EMPTY kernel of `blocks` x `threads` (what the workgroup dispatcher alone sustains), averaged
  * over `reps` back-to-back launches on the default stream of the current device.  tools/dispatch_rate.py. */
 int snail_debug_dispatch_rate(int blocks, int threads, int reps, float *ms_per_launch);

@@ -30,6 +30,10 @@ SIGNATURES = {
     "snail_scene_destroy": (None, [_VP]),
     "snail_scene_info": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "snail_scene_flags": (_I, [_VP, _VP, _VP]),
+    "snail_scene_set_arith": (_I, [_VP, _I]),
+    "snail_scene_arith": (_I, [_VP, _VP]),
+    "snail_host_sse_tables": (_I, [_VP]),
+    "snail_host_sse_check": (_I, [_I, C.c_uint64, C.c_uint64, _I, _VP, _VP]),
     "snail_scene_create_lbvh": (_VP, [_VP, _I, _I, _I, _VP, _VP]),
     "snail_scene_download": (_I, [_VP, _VP, _VP]),
     "snail_trace_primary": (_I, [_VP, _F13, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),
@@ -49,6 +53,7 @@ SIGNATURES = {
     "snail_trace_shadow": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "snail_trace_shadow_dev": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "snail_shade_depth_dev": (_I, [_VP, _I, _VP, _VP]),
+    "snail_shade_depth_arith_dev": (_I, [_VP, _I, _VP, _I, _VP]),
     "snail_packets_bgr_to_frame_dev": (_I, [_VP, _I, _I, _I, _VP, _VP, _I, _VP]),
     "snail_packets_bgr_to_frame_chunked_dev": (_I, [_VP, _I, _I, C.c_int64, _I, _I, _VP, _VP, _I, _VP]),
     "snail_packets_bgr_to_planar_dev": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP]),
@@ -70,6 +75,7 @@ DEBUG_SIGNATURES = {
     "snail_debug_clock_dev": (_I, [C.c_float, _VP, _VP]),
     "snail_debug_recip_check": (_I, [_VP]),
     "snail_debug_dispatch_rate": (_I, [_I, _I, _I, _VP]),
+    "snail_debug_hostsse_device_check": (_I, [_I, _I, _VP, _VP]),
     "snail_debug_occupancy": (_I, [_VP]),
     "snail_debug_anyorder": (_I, [_VP, _F13, _I, _I, _I, _I, _VP]),
 }

@@ -274,13 +274,14 @@ class Scene:
 
     # ---- framebuffer: gVals[1] depth shading + RGB8 store (src/scene_trace.cpp:128-137, src/render.cpp:11-17,171-198)
     @staticmethod
-    def shade_depth(t_packets, out=None, stream=None):
+    def shade_depth(t_packets, out=None, stream=None, arith="ieee"):
         """packet-major distances [n,256] -> packet-major bytes [n,256,3] (B,G,R per pixel)."""
         torch = _torch()
         n = int(t_packets.shape[0])
         if out is None:
             out = torch.empty((n, 256, 3), dtype=torch.uint8, device=t_packets.device)
-        _lib.check(_lib.lib().snail_shade_depth_dev(_lib.ptr(t_packets), n, _lib.ptr(out), _stream_ptr(stream)), "snail_shade_depth_dev")
+        code = Scene.ARITH[arith] if isinstance(arith, str) else int(arith)
+        _lib.check(_lib.lib().snail_shade_depth_arith_dev(_lib.ptr(t_packets), n, _lib.ptr(out), code, _stream_ptr(stream)), "snail_shade_depth_arith_dev")
         return out
 
     @staticmethod
@@ -482,6 +483,21 @@ class Scene:
         cam13 = np.ascontiguousarray(cam.as_array13(), dtype=np.float32)
         _lib.check(_lib.lib().snail_account_packets(self._h, _lib.ptr(cam13), resx, resy, _lib.ptr(out)), "snail_account_packets")
         return out
+
+    # ---- arithmetic of Inv / RSqrt / FastInv (include/snail_hip.h, "arithmetic") ------------------------
+    ARITH = {"ieee": 0, "host_sse": 1}
+
+    def set_arith(self, arith) -> None:
+        """"ieee" (default: veclib's scalar definitions) or "host_sse" (veclib's SSE definitions as THIS host's CPU executes them:
+        rcpps / rsqrtps reproduced on the device from the CPU's tables + the Newton steps).  Raises SnailError when the host's
+        instructions cannot be reproduced from tables."""
+        code = self.ARITH[arith] if isinstance(arith, str) else int(arith)
+        _lib.check(_lib.lib().snail_scene_set_arith(self._h, code), "snail_scene_set_arith")
+
+    def arith(self) -> str:
+        a = C.c_int(0)
+        _lib.check(_lib.lib().snail_scene_arith(self._h, C.addressof(a)), "snail_scene_arith")
+        return {v: k for k, v in self.ARITH.items()}[a.value]
 
     def flags(self):
         """(fastOK, nestedOK) as snail_scene_create found them (snail_scene_flags)."""

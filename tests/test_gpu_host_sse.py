@@ -1,0 +1,199 @@
+"""GPU parity tests of SNAIL_ARITH_HOST_SSE (run with -m gpu on an MI355X): the HIP path in the arithmetic the reference's x86 build
+executes -- veclib's SSE Inv / RSqrt / FastInv = rcpps / rsqrtps of the HOST CPU + one Newton step (veclib/sse/base.h:84-92,
+veclib/sse/f32.h:98-102) -- against the oracle in ORC_MODE_SSE, which runs those very instructions on the same CPU.
+
+Bar: BIT-EXACT t, u, v, triId, TreeStats counters and picture bytes.  north_star asks for triId bit-exact and t/u/v within 1e-4 against
+"the reference CPU veclib/SSE path"; in this mode nothing is left to a tolerance: device-generated rays included."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib as O
+from tests import util
+from tests.test_gpu_parity import compare_frames, gpu_scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def sse_scene(name):
+    tv, sc, osc = gpu_scene(name)
+    sc.set_arith("host_sse")
+    assert sc.arith() == "host_sse"
+    return tv, sc, osc
+
+
+def lights_for(osc, cam, n):
+    bmin, bmax = osc.nodes[0]["bmin"], osc.nodes[0]["bmax"]
+    c, e = (bmin + bmax) * 0.5, (bmax - bmin)
+    return np.array([[c[0], c[1] + 0.35 * e[1], c[2], 1.0, 0.9, 0.8, 2.0 * float(e.max())],
+                     [c[0] - 0.3 * e[0], c[1] + 0.1 * e[1], c[2] + 0.2 * e[2], 0.3, 0.5, 1.0, 0.6 * float(e.max())],
+                     [cam.pos[0], cam.pos[1], cam.pos[2], 0.6, 0.6, 0.6, 0.25 * float(e.max())]], dtype=np.float32)[:n]
+
+
+def test_device_reproduces_the_hosts_rcpps_and_rsqrtps_for_every_float(torch_mod):
+    """dev_sse::rcpHost / rsqrtHost over all 2^32 bit patterns against the instructions of this box's CPU (checksums per 65536 inputs)."""
+    import ctypes as C
+    from snail_amd._lib import check, debug_lib
+    L = debug_lib()
+    for fn in (0, 1):
+        bad, first = C.c_uint64(1), C.c_uint32(0)
+        check(L.snail_debug_hostsse_device_check(fn, min(16, os.cpu_count() or 1), C.byref(bad), C.byref(first)), "snail_debug_hostsse_device_check")
+        assert bad.value == 0, (fn, bad.value, hex(first.value << 16))
+
+
+@pytest.mark.parametrize("name,resx,resy", [
+    ("box", 256, 256),            # BASELINE config 0
+    ("box", 250, 130),            # ragged
+    ("atrium:0.05", 640, 368),
+    ("chain", 256, 144),          # depth-63 tree: the DEEP kernels of the second arithmetic
+    ("stress:0.05", 320, 192),
+    ("patches", 200, 120),        # the narrow-range leaf forms at every width
+])
+def test_primary_frame_bit_exact_in_host_sse(torch_mod, name, resx, resy):
+    tv, sc, osc = sse_scene(name)
+    cam = util.camera_for(name, tv)
+    stats = sc.new_stats()
+    frame = sc.trace_primary(cam, resx, resy, stats=stats)
+    torch_mod.cuda.synchronize()
+    ref = osc.render_primary(cam.as_array13(), resx, resy, mode=O.MODE_SSE)
+    compare_frames(frame, ref, "host_sse %s %dx%d" % (name, resx, resy))
+    assert np.array_equal(stats.cpu().numpy().astype(np.uint64), ref[4]), (stats.cpu().numpy(), ref[4])
+    # the two arithmetics are different functions: the IEEE frame of the same scene handle differs in some bits, and switching back restores it
+    sc.set_arith("ieee")
+    f2 = sc.trace_primary(cam, resx, resy)
+    torch_mod.cuda.synchronize()
+    compare_frames(f2, osc.render_primary(cam.as_array13(), resx, resy, mode=O.MODE_IEEE), "back to ieee")
+    if name != "box":
+        assert not np.array_equal(f2.t.cpu().numpy().view(np.uint32), ref[0].view(np.uint32))
+    sc.close()
+
+
+@pytest.mark.parametrize("name", ["atrium", "stress"])
+def test_full_size_frame_bit_exact_in_host_sse(torch_mod, name):
+    """BASELINE configs 1 and 5 at 1920x1080, rays generated on the device: every hit record and the TreeStats equal the oracle's in
+    ORC_MODE_SSE bit for bit -- no hit/miss flip, no triId mismatch, no pixel outside any tolerance."""
+    tv, sc, osc = sse_scene(name)
+    cam = util.camera_for(name, tv)
+    stats = sc.new_stats()
+    frame = sc.trace_primary(cam, 1920, 1080, stats=stats)
+    torch_mod.cuda.synchronize()
+    ref = osc.render_primary(cam.as_array13(), 1920, 1080, mode=O.MODE_SSE, threads=16)
+    compare_frames(frame, ref, "host_sse %s 1920x1080" % name)
+    assert np.array_equal(stats.cpu().numpy().astype(np.uint64), ref[4]), (stats.cpu().numpy(), ref[4])
+    assert np.isfinite(ref[0]).mean() > 0.5
+    sc.close()
+
+
+@pytest.mark.parametrize("shared,masked,size", [(True, False, 64), (False, True, 64), (False, False, 23), (True, True, 16)])
+def test_generic_packets_bit_exact_in_host_sse(torch_mod, shared, masked, size):
+    """TraversePrimary<so,mask> with the caller's rays (dir / idir as the reference's SSE code hands them over): 1 / det of the accepted
+    hits is the only approximate operation left, and it is the host's."""
+    name = "atrium:0.05"
+    tv, sc, osc = sse_scene(name)
+    cam = util.camera_for(name, tv)
+    npk = 24
+    origin, dirs, idir, mask, dist, obj, bary = util.secondary_packets(osc, cam, 640, 368, npk, seed=11 + size, shared=shared, masked=masked, size=size, coherent=size == 64)
+    d2, o2, b2 = dist.copy(), obj.copy(), bary.copy()
+    st2 = osc.trace_rays(origin, dirs, idir, mask, d2, o2, b2, npk, size, shared, mode=O.MODE_SSE)
+    d3, o3, b3 = dist.copy(), obj.copy(), bary.copy()
+    sc.trace_rays_host(origin, dirs, idir, mask, d3, o3, b3, npk, size, shared)
+    util.assert_bit_equal(d3, d2, "t"); util.assert_bit_equal(o3, o2, "triId"); util.assert_bit_equal(b3, b2, "barycentric")
+    assert (o2 != 0).any() and st2[0] > 0
+    # ... and it is not the IEEE result (some accepted hit's 1 / det differs in its last bits)
+    d4, o4, b4 = dist.copy(), obj.copy(), bary.copy()
+    osc.trace_rays(origin, dirs, idir, mask, d4, o4, b4, npk, size, shared, mode=O.MODE_IEEE)
+    assert not np.array_equal(d4.view(np.uint32), d2.view(np.uint32))
+    sc.close()
+
+
+@pytest.mark.parametrize("name,resx,resy,nl,refl", [("atrium:0.05", 640, 368, 2, False), ("atrium:0.05", 640, 368, 2, True), ("box", 256, 256, 1, True),
+                                                     ("stress:0.05", 320, 192, 3, True), ("chain", 128, 96, 1, True), ("atrium:0.05", 250, 130, 0, False)])
+def test_whitted_frames_byte_exact_in_host_sse(torch_mod, name, resx, resy, nl, refl):
+    """Config 3's pipeline (+ the mirrored bounce) in the second arithmetic: shadow-ray generation (Inv(distance), SafeInv), the mirrored
+    rays' SafeInv, the attenuation's FastInv = raw rcpps, 1 / det in every walk."""
+    tv, sc, osc = sse_scene(name)
+    cam = util.camera_for(name, tv)
+    lights = lights_for(osc, cam, nl)
+    want, wst = osc.render_whitted(cam.as_array13(), resx, resy, lights, mode=O.MODE_SSE, reflections=refl)
+    stats = sc.new_stats()
+    got = sc.render_whitted(cam, resx, resy, lights, stats=stats, reflections=refl).cpu().numpy()
+    assert np.array_equal(got, want), (int((got != want).sum()), got.shape)
+    assert np.array_equal(stats.cpu().numpy().astype(np.uint64), wst), (stats.cpu().numpy(), wst)
+    assert want.max() > 0
+    sc.close()
+
+
+@pytest.mark.parametrize("refl", [False, True])
+def test_config3_full_size_frame_byte_exact_in_host_sse(torch_mod, refl):
+    name = "atrium"
+    tv, sc, osc = sse_scene(name)
+    cam = util.camera_for(name, tv)
+    lights = lights_for(osc, cam, 1)
+    want, wst = osc.render_whitted(cam.as_array13(), 1920, 1080, lights, mode=O.MODE_SSE, threads=16, reflections=refl)
+    stats = sc.new_stats()
+    got = sc.render_whitted(cam, 1920, 1080, lights, stats=stats, reflections=refl).cpu().numpy()
+    assert np.array_equal(got, want), int((got != want).sum())
+    assert np.array_equal(stats.cpu().numpy().astype(np.uint64), wst), (stats.cpu().numpy(), wst)
+    sc.close()
+
+
+@pytest.mark.parametrize("mode", ["lights", "refl", "depth"])
+def test_tile_renderer_in_host_sse(torch_mod, mode):
+    """The host-pointer tile API (depth shading fused into the traversal kernel; 4x antialiasing with the depth / colour reduction)."""
+    from snail_amd.scene import Scene
+    name, resx, resy = "atrium:0.05", 250, 130
+    tv, sc, osc = sse_scene(name)
+    cam = util.camera_for(name, tv)
+    lights = lights_for(osc, cam, 1)
+    for aa in (False, True):
+        flags = (Scene.RENDER_AA4 if aa else 0) | (Scene.RENDER_REFLECTIONS if mode == "refl" else 0) | (Scene.RENDER_DEPTH if mode == "depth" else 0)
+        want, wst = osc.render_whitted(cam.as_array13(), resx, resy, lights, mode=O.MODE_SSE, reflections=mode == "refl", antialias=aa, depth=mode == "depth")
+        img, st = sc.render_image_host(cam, resx, resy, lights, flags)
+        assert np.array_equal(img, want), (aa, int((img != want).sum()))
+        assert np.array_equal(st, wst), (aa, st, wst)
+    # the stand-alone depth shading of existing hit records, special values included
+    t = torch_mod.tensor([[float("inf"), 1e-6, float("nan"), 1.0, 3.0e38, 1.0e-39] + [2.0] * 250], dtype=torch_mod.float32, device="cuda")
+    b = sc.shade_depth(t, arith="host_sse").cpu().numpy().reshape(-1, 3)
+    assert np.array_equal(b, O.shade_depth(t.cpu().numpy(), mode=O.MODE_SSE))
+    sc.close()
+
+
+def test_transparency_stage_in_host_sse(torch_mod):
+    name, resx, resy = "atrium:0.05", 320, 192
+    tv, sc, osc = sse_scene(name)
+    cam = util.camera_for(name, tv)
+    xy, tp, ip, sel, lights = util.transparency_case(osc, cam, resx, resy, 5, mode=O.MODE_SSE)
+    want, wst = osc.trace_transparency(cam.as_array13(), resx, resy, xy, tp, sel, lights[:1], mode=O.MODE_SSE)
+    dev = lambda a: torch_mod.from_numpy(np.ascontiguousarray(a)).cuda()
+    stats = sc.new_stats()
+    got = sc.trace_transparency(cam, resx, resy, dev(xy), dev(tp), dev(ip), dev(sel), lights[:1], stats=stats)
+    torch_mod.cuda.synchronize()
+    util.assert_bit_equal(got.cpu().numpy(), want, "transColor")
+    assert np.array_equal(stats.cpu().numpy().astype(np.uint64), wst), (stats.cpu().numpy(), wst)
+    sc.close()
+
+
+def test_batched_ordered_launches_in_host_sse(torch_mod):
+    """The bench's launch form (several frames per launch, a fed-back dispatch order) in the second arithmetic."""
+    name, resx, resy = "atrium:0.05", 328, 200
+    tv, sc, osc = sse_scene(name)
+    cam = util.camera_for(name, tv)
+    n = sc.primary_slots(resx, resy)
+    cost = torch_mod.zeros(n, dtype=torch_mod.int32, device="cuda")
+    sc.trace_primary(cam, resx, resy, slot_cost=cost)
+    order = sc.order_from_cost(cost)
+    outs = [sc.alloc_frame(resx, resy) for _ in range(3)]
+    sc.trace_primary_batch([cam] * 3, resx, resy, outs, order=order)
+    torch_mod.cuda.synchronize()
+    ref = osc.render_primary(cam.as_array13(), resx, resy, mode=O.MODE_SSE)
+    for f in outs:
+        compare_frames(f, ref, "batched host_sse")
+    sc.close()

@@ -132,11 +132,11 @@ def frame_to_packets(plane, xy):
     return out
 
 
-def transparency_case(osc, cam, resx, resy, seed):
+def transparency_case(osc, cam, resx, resy, seed, mode=O.MODE_IEEE):
     """Inputs of a Scene::TraceTransparency call as the reference's RayTrace makes it (src/scene_trace.cpp:468-477): the packets of a frame,
     their hit distances and triangle ids, a seeded selector (random lane sets, some packets fully selected -- the RayGroup<0,0> branch of
     :631 --, some not at all) and one light."""
-    t, u, v, tid, _ = osc.render_primary(cam.as_array13(), resx, resy, mode=O.MODE_IEEE)
+    t, u, v, tid, _ = osc.render_primary(cam.as_array13(), resx, resy, mode=mode)
     xy = np.array([(x, y) for y in range(0, resy, 16) for x in range(0, resx, 16)], dtype=np.int32)
     tp, ip = frame_to_packets(t, xy), frame_to_packets(tid, xy)
     if resx % 16 or resy % 16:      # rays of edge packets outside the image: a miss, as the device hands them back
