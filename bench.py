@@ -127,6 +127,22 @@ def orbit_cameras(scenes, FPSCamera, scene_name, n, step_deg=0.2, sweep_deg=20.0
     return cams
 
 
+def dolly_cameras(scenes, FPSCamera, scene_name, n, step=0.01, sweep=4.0):
+    """--camera-path dolly: the camera's POSITION advances by `step` scene units along its viewing direction every frame, forth and back
+    over `sweep` units (the reference's viewer translates its camera every frame it is steered, src/rtracer.cpp:76-148).  Every frame then has
+    an origin of its own: a new origin-relative node array (dev::k_rel_nodes + an entry of the scene's 16-entry cache), and dispatch orders
+    that are predictions from an older view."""
+    import numpy as np
+    pos, ang, pitch = scenes.stress_camera() if scene_name.startswith("stress") else scenes.atrium_camera()
+    front = np.asarray(FPSCamera(pos, ang, pitch).camera().front, dtype=np.float64)
+    half = int(round(sweep / step))
+    cams = []
+    for i in range(min(n, 2 * half)):
+        k = i if i <= half else 2 * half - i          # 0 .. half .. 1
+        cams.append(FPSCamera((np.asarray(pos, dtype=np.float64) + front * (k * step)).astype(np.float32), ang, pitch).camera())
+    return cams
+
+
 def pmc_counters(workload_key: str):
     """Per-launch PMC figures of the dominant kernel from the committed rocprofv3 passes of this same command
     (profiles/traffic.json): HBM bytes = FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, and
@@ -143,6 +159,47 @@ def pmc_counters(workload_key: str):
         tr = dict(tr)
         tr["_stale"] = d.get("_kernel_sha16") != kernel_source_sha16()
     return tr
+
+
+def verify_outputs(rnd, scene_name, resx, resy, config, arith, lights):
+    """What the timed path produced, against the committed digests of the oracle's frame of this workload (tests/golden/oracle_full_size.json;
+    made by tests/golden/full_size.py -- `ieee` in the build container, `host_sse` per host CPU): every output buffer the renderer's launches
+    wrote (one per slot and per frame of a multi-frame launch) must hold the same frame (compared on the device), and that frame's SHA-256
+    must be the committed one.  Returns {"verified": True | False | None, ...}; None = no committed digest for this workload / CPU."""
+    import ctypes as C
+    import hashlib
+    import numpy as np
+    import torch
+    from snail_amd import _lib
+    sha = lambda t: hashlib.sha256(np.ascontiguousarray(t.cpu().numpy()).tobytes()).hexdigest()
+    bufs = rnd.output_buffers()
+    if not bufs:
+        return {"verified": None, "note": "no output buffer on this rank"}
+    hits = hasattr(bufs[0], "tri_id")
+    planes = (lambda f: (f.t, f.u, f.v, f.tri_id)) if hits else (lambda f: (f,))
+    same = all(torch.equal(a, b) for f in bufs[1:] for a, b in zip(planes(f), planes(bufs[0])))
+    got = dict(zip(("sha_t", "sha_u", "sha_v", "sha_id"), (sha(x) for x in planes(bufs[0])))) if hits else {"sha_bgr" if lights else "sha_depth_bgr": sha(bufs[0])}
+    res = {"verified": None, "buffers": len(bufs), "buffers_identical": bool(same), "digest": got}
+    try:
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_full_size.json")))
+    except Exception as e:
+        res["note"] = "tests/golden/oracle_full_size.json: %s" % e
+        return res
+    key = "%s_%dx%d_c%s" % (scene_name, resx, resy, config)
+    if arith == "ieee":
+        sec, where = gold.get("ieee", {}), "ieee"
+    else:
+        tab = np.zeros(3 * 4096, dtype=np.uint32)
+        _lib.check(_lib.lib().snail_host_sse_tables(tab.ctypes.data_as(C.c_void_p)), "snail_host_sse_tables")
+        cpu = hashlib.sha256(tab.tobytes()).hexdigest()[:16]
+        sec, where = gold.get("host_sse", {}).get(cpu, {}), "host_sse[%s]" % cpu
+    want = sec.get(key)
+    if want is None:
+        res["note"] = "no committed digest for %s in section %s" % (key, where)
+        return res
+    res["verified"] = bool(same and all(want.get(k) == v for k, v in got.items()))
+    res["against"] = "tests/golden/oracle_full_size.json %s.%s" % (where, key)
+    return res
 
 
 def weak_frame_size(n_gpus: int, res):
@@ -198,9 +255,10 @@ def main():
     ap.add_argument("--feedback-order", type=int, default=1, help="1 (default) = dispatch packets heaviest first by the node visits of an earlier frame (DistributedRenderer feedback_order)")
     ap.add_argument("--frames-per-launch", type=int, default=0, help="trace this many frames (1..8) with one launch -- and, at N > 1, move them with one collective (DistributedRenderer frames_per_launch); 0 = enough for a launch to hold 8160 packets (one 1080p frame), at least 2, at most 8: 2 / 2 / 4 / 8 at N = 1 / 2 / 4 / 8; config 3 always 1")
     ap.add_argument("--lone-frames", type=int, default=12, help="frames (N > 1: launches through the whole route) traced one at a time after the timed region (lone_frame_ms / lone_launch_ms); 0 = skip")
-    ap.add_argument("--camera-path", default="static", choices=["static", "orbit"], help="orbit = the camera turns 0.2 degrees every step (dispatch orders are then predictions from an older view, re-derived every --order-refresh frames of a slot, inside the timed region)")
+    ap.add_argument("--camera-path", default="static", choices=["static", "orbit", "dolly"], help="dolly = the camera's position advances 0.01 units along its viewing direction every step (every frame needs a new origin-relative node array); orbit = the camera turns 0.2 degrees every step (dispatch orders are then predictions from an older view, re-derived every --order-refresh frames of a slot, inside the timed region)")
     ap.add_argument("--settle-ms", type=float, default=30.0, help="untimed frames for this many milliseconds BEFORE the W warm-up steps: the part's clocks ramp for tens of ms after an idle start (2.09 -> 1.91 -> 2.2 GHz over the first 600 frames, profiles/README.md), which a 20-step timed region would otherwise measure instead of the kernel; 0 = off; reported as config.settle_ms")
     ap.add_argument("--dry-run", action="store_true", help="start the ranks, rendezvous, one all-reduce over the chosen backend, print {dry_run, ranks} and exit: checks the launch path without a GPU (with --backend gloo)")
+    ap.add_argument("--reflections", action="store_true", help="config 3 only: + the one mirrored bounce of gVals[7] (Scene::TraceReflection: mirrored packets with per-ray origins through the same RayTrace)")
     ap.add_argument("--arith", default="ieee", choices=["ieee", "host_sse"], help="arithmetic of the path's approximate operations (include/snail_hip.h): ieee = veclib's scalar definitions; host_sse = veclib's SSE definitions as this host's CPU executes them (rcpps / rsqrtps reproduced on the device + Newton), i.e. the reference's x86 results bit for bit")
     ap.add_argument("--order-refresh", type=int, default=16, help="frames of a slot between two derivations of its dispatch order while the camera moves (DistributedRenderer order_refresh)")
     args = ap.parse_args()
@@ -274,11 +332,12 @@ def main():
     per_rank = ((resx + 15) // 16) * ((resy + 15) // 16) / float(world)
     auto_fpl = int(min(8, max(2, math.ceil(8160.0 / max(1.0, per_rank)))))
     rnd = DistributedRenderer(scene, resx, resy, rank, world, slots=args.streams if args.streams > 0 else None, stage_cpu=rehearsal,
-                              feedback_order=bool(args.feedback_order), lights7=lights7, rank0_share=args.rank0_share,
+                              feedback_order=bool(args.feedback_order), lights7=lights7, reflections=bool(args.reflections and cfg["lights"]), rank0_share=args.rank0_share,
                               frames_per_launch=args.frames_per_launch if args.frames_per_launch > 0 else auto_fpl, order_refresh=args.order_refresh)
     primary_rays = rnd.rays_per_frame() if world > 1 else resx * ((resy + 15) // 16 * 16)
     # the cameras of the timed steps: one fixed view, or a view that turns every step (built here, outside the timed region)
-    path = orbit_cameras(scenes, FPSCamera, scene_name, args.steps + args.warmup) if (args.camera_path == "orbit" and not args.scene) else [cam]
+    moving = args.camera_path != "static" and not args.scene
+    path = ((orbit_cameras if args.camera_path == "orbit" else dolly_cameras)(scenes, FPSCamera, scene_name, args.steps + args.warmup + 4096) if moving else [cam])
     cam_at = lambda i: path[i % len(path)]
 
     def barrier():
@@ -294,14 +353,36 @@ def main():
     tot = rnd.reduce_stats(st) if world > 1 else st
     total_rays = int(tot.cpu().numpy()[2]) if (rank == 0 and cfg["lights"]) else primary_rays
     node_visits = int(tot.cpu().numpy()[1]) if rank == 0 else 0
-    # settle: a FIXED number of untimed frames (12 per millisecond asked for = the single-GPU rate of the headline workload), the same on
-    # every rank -- the ranks' collectives must pair up, so the count cannot depend on a rank's clock
-    settle_frames = int(args.settle_ms * 12.0) // rnd.batch * rnd.batch if args.settle_ms > 0 else 0
-    for _ in range(settle_frames):
-        rnd.render(cam)
-    # (no flush: the warm-up steps follow in the same pipeline)
+    # settle: untimed frames of the run's own camera path for `--settle-ms`.  The count comes from a measured probe of THIS workload (two
+    # rounds of the pipeline, rank 0's clock) and is the same on every rank -- the ranks' collectives must pair up -- by a MAX all-reduce
+    settle_frames, settle_measured_ms = 0, 0.0
+    if args.settle_ms > 0:
+        probe = 2 * rnd.nslots * rnd.batch
+        for i in range(probe):          # every slot's first frame (scratch allocations, first dispatch orders), untimed
+            rnd.render(cam_at(i))
+        rnd.flush()
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(2 * probe):
+            rnd.render(cam_at(i))
+        rnd.flush()
+        barrier()
+        per_frame_ms = (time.perf_counter() - t1) * 1e3 / (2 * probe)
+        want = min(4000, int(args.settle_ms / max(per_frame_ms, 1e-3)))
+        if world > 1:
+            tt = torch.tensor([want], dtype=torch.int64, device="cpu" if rehearsal else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            want = int(tt.item())
+        settle_frames = max(rnd.batch, want // rnd.batch * rnd.batch)
+        t1 = time.perf_counter()
+        for i in range(settle_frames):
+            rnd.render(cam_at(3 * probe + i))
+        rnd.flush()
+        torch.cuda.synchronize()
+        settle_measured_ms = (time.perf_counter() - t1) * 1e3
+    warm0 = settle_frames + (6 * rnd.nslots * rnd.batch if args.settle_ms > 0 else 0)     # the path goes on where the settle frames stopped
     for i in range(args.warmup):
-        rnd.render(cam_at(i))
+        rnd.render(cam_at(warm0 + i))
     rnd.flush()
     barrier()
 
@@ -318,7 +399,7 @@ def main():
     # (a launch of B frames keeps ONE pair, that of its first frame: the stride is a multiple of B)
     every = -(-max(1, args.event_every) // rnd.batch) * rnd.batch
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if i % every == 0 else None for i in range(args.steps)]
-    cams_timed = [cam_at(args.warmup + i) for i in range(args.steps)]
+    cams_timed = [cam_at(warm0 + args.warmup + i) for i in range(args.steps)]
     t0 = time.perf_counter()
     for e, c in zip(ev, cams_timed):
         rnd.render(c, events=e)
@@ -329,6 +410,17 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # ---- what the timed region produced (rank 0), before anything else overwrites the renderer's buffers ----
+    verify = None
+    if len(path) > 1:    # a moving camera: every slot holds another view -- send one more round of the FIXED view through the same renderer (same
+        for _ in range(rnd.nslots * rnd.batch):      # launch form, the dispatch orders it has arrived at) and check that, after the clock has stopped
+            rnd.render(cam)
+        rnd.flush()
+        barrier()
+    if rank == 0:
+        verify = verify_outputs(rnd, scene_name, resx, resy, "%d%s" % (args.config, "r" if (args.reflections and cfg["lights"]) else ""), args.arith, cfg["lights"])
+        verify["what"] = ("one more round of the fixed view through the timed renderer after the timed region (the timed frames each hold another view)" if len(path) > 1
+                          else "the last frame each slot traced inside the timed region")
     timed = [e for e in ev if e is not None]
     durs = []
     for e0, e1 in timed:
@@ -392,7 +484,7 @@ def main():
         try:
             scene.set_arith(other_name)
             r2 = DistributedRenderer(scene, resx, resy, 0, 1, slots=args.streams if args.streams > 0 else None, feedback_order=bool(args.feedback_order), lights7=lights7,
-                                     frames_per_launch=rnd.batch, order_refresh=args.order_refresh)
+                                     reflections=bool(args.reflections and cfg["lights"]), frames_per_launch=rnd.batch, order_refresh=args.order_refresh)
             for i in range(max(8 * rnd.batch, min(args.warmup, 100) // rnd.batch * rnd.batch)):
                 r2.render(cam_at(i))
             r2.flush()
@@ -413,7 +505,7 @@ def main():
         ms_per_step = elapsed * 1e3 / args.steps
         step_s = ms_per_step * 1e-3
         value = total_rays * args.steps / elapsed / 1e6
-        key = "%s_%dx%d_n%d_c%d" % (scene_name, resx, resy, world, args.config)
+        key = "%s_%dx%d_n%d_c%d%s" % (scene_name, resx, resy, world, args.config, "r" if (args.reflections and cfg["lights"]) else "")
         tr = pmc_counters(key)
         shared_note = ""
         if tr is None and world > 1 and args.scaling == "strong":
@@ -462,18 +554,18 @@ def main():
             par = "tiles16x64-roundrobin-x%d (rank-0 share %.2f) + %s + per-frame RCCL gather of rgb8 tiles to rank 0 (overlapped with the next frames)" % (
                 world, args.rank0_share, "light pipeline" if cfg["lights"] else "depth-shade")
         out = {
-            "metric": "Mrays/sec (primary)" if not cfg["lights"] else "Mrays/sec (primary + shadow)", "value": round(value, 2), "unit": "Mrays/s",
+            "metric": "Mrays/sec (primary)" if not cfg["lights"] else ("Mrays/sec (primary + mirrored + shadow)" if args.reflections else "Mrays/sec (primary + shadow)"), "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: gloo, ranks share one GPU -- not a measurement)",
             "config": {"workload": "BASELINE config %d: %s (%d tris%s) %dx%d %s" % (args.config, scene_name, hbvh.n_tris,
                                                                                      ", sponza.obj stand-in" if scene_name.startswith("atrium") else "", resx, resy, cfg["what"]),
-                       "baseline_config": args.config, "arith": args.arith, "rays_per_step": total_rays, "primary_rays_per_step": primary_rays, "node_visits_per_step": node_visits,
+                       "baseline_config": args.config, "reflections": bool(args.reflections and cfg["lights"]), "arith": args.arith, "rays_per_step": total_rays, "primary_rays_per_step": primary_rays, "node_visits_per_step": node_visits,
                        "packets": "16x16 px = 1 wavefront", "bvh_nodes": hbvh.n_nodes, "bvh_depth": hbvh.depth,
                        "bvh_build_s": round(build_s, 3), "hit_fraction": round(hit_frac, 5), "frames_in_flight": rnd.nslots * rnd.batch, "frames_per_launch": rnd.batch, "launches_in_flight": rnd.nslots,
                        "lone_launch_ms": round(lone_launch_ms, 5) if lone_launch_ms is not None else None,
                        "lone_launch_note": ("host clock of rank 0 around %d frame(s) = one launch + one collective + scatter with nothing else in flight" % rnd.batch) if lone_launch_ms is not None else None,
-                       "settle_ms": args.settle_ms, "settle_frames": settle_frames,
+                       "settle_ms": args.settle_ms, "settle_frames": settle_frames, "settle_measured_ms": round(settle_measured_ms, 2),
                        "camera_path": args.camera_path if len(path) > 1 else "static", "order_refresh": rnd.order_refresh if rnd.feedback else None,
                        "ranks": world, "backend": ("gloo (rehearsal)" if rehearsal else "nccl (RCCL)") if world > 1 else None,
                        "packet_order": "heaviest first (node visits of an earlier frame)" if rnd.feedback else "built-in region interleave",
@@ -481,6 +573,7 @@ def main():
                        "packets_per_rank": [len(p) for p in rnd.plan.packets] if world > 1 else None,
                        "parallelism": par},
             "roofline": roof,
+            "verified": verify.get("verified") if verify else None, "verification": verify,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(tv, cam, resx, resy)
@@ -490,6 +583,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and verify and verify.get("verified") is False:
+        raise SystemExit("bench.py: the timed path's output does NOT match the committed digest: %s" % json.dumps(verify))
 
 
 if __name__ == "__main__":

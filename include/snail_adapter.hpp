@@ -116,6 +116,14 @@ public:
 	}
 	int DeviceCount() const { return (int)handles.size(); }
 	SnailScene *const *Handles() const { return handles.data(); }
+	// Arithmetic of Inv / RSqrt / FastInv on every device copy (include/snail_hip.h): SNAIL_ARITH_HOST_SSE = what the reference's SSE build
+	// computes on THIS host (its rcpps / rsqrtps + veclib's Newton steps), bit for bit; returns false -- the arithmetic stays as it was -- when
+	// the host's instructions cannot be reproduced from tables (snail_last_error() says why).  Call after Upload.
+	bool SetArith(int arith) {
+		for(SnailScene *h : handles)
+			if(snail_scene_set_arith(h, arith) != 0) { for(SnailScene *g : handles) (void)snail_scene_set_arith(g, SNAIL_ARITH_IEEE); return false; }
+		return true;
+	}
 
 	// ---- frame prefetch ----
 	// (const over mutable state: the prefetched frame is a cache of what TraversePrimary would compute, and the reference's renderers
@@ -380,7 +388,8 @@ inline TreeStats Render(const Scene<snail::HipBVH<RefBVH>> &scene, const Camera 
 	(void)rank; (void)threads; // (no tint requested; the host thread pool has no device counterpart)
 	snail::RenderMode mode;
 	mode.depthShading = gVals[1] != 0;
-	mode.reflections = gVals[7] != 0 || options.reflections;
+	mode.reflections = gVals[7] != 0;   // the bounce is gated by gVals[7] alone (src/scene_trace.cpp:454); Options::reflections is stored and never read (src/render.cpp:24,37)
+	(void)options;
 	mode.antialias = gVals[9] != 0;
 	return snail::RenderTiles<TreeStats>(scene, camera, resx, resy, data, coords, offsets, mode);
 }
@@ -391,7 +400,8 @@ inline TreeStats Render(const Scene<snail::HipBVH<RefBVH>> &scene, const Camera 
 	(void)threads;
 	snail::RenderMode mode;
 	mode.depthShading = gVals[1] != 0;
-	mode.reflections = gVals[7] != 0 || options.reflections;
+	mode.reflections = gVals[7] != 0;   // the bounce is gated by gVals[7] alone (src/scene_trace.cpp:454); Options::reflections is stored and never read (src/render.cpp:24,37)
+	(void)options;
 	mode.antialias = gVals[9] != 0;
 	return snail::RenderImage<TreeStats>(scene, camera, image, mode);
 }

@@ -145,8 +145,10 @@ int snail_trace_packets_shaded_dev(SnailScene *, const float cam[13], int resx, 
  * number of its packets; some slots hold no packet) and nPackets for a list:
  *   d_slot_cost (out): node visits of each slot's packet in THIS launch (0 for an empty slot);
  *   d_order     (in) : the slot each workgroup takes, a permutation of [0, nSlots); NULL = the built-in order.
- * snail_order_from_cost_dev turns the costs of one frame into the order of the next (heaviest first; stream-ordered, one small
- * kernel on the CURRENT device, no scratch).  Results never depend on the order: hit records and counters are identical.
+ * snail_order_from_cost_dev turns the costs of one frame into the order of the next (heaviest first: a counting sort over 4096 cost
+ * classes, the order inside a class arbitrary; stream-ordered, one small kernel on the CURRENT device, no scratch; costs below zero count
+ * as zero and, for inputs of up to 49152 slots, costs above 65535 as 65535).  Results never depend on the order: hit records and
+ * counters are identical.
  * The caller keeps d_order unchanged while a launch reading it is in flight. */
 int snail_primary_slots(int w, int h);
 int snail_trace_primary_ordered_dev(SnailScene *, const float cam[13], int resx, int resy, int x0, int y0, int w, int h,
@@ -253,6 +255,21 @@ int snail_planar_to_frame_dev(const int32_t *d_tiles, const int64_t *d_in_offset
 int snail_render_whitted_dev(SnailScene *, const float cam[13], int resx, int resy, const float *lights7, int nLights,
                              const float ambient[3], const float color[3], int flags, uint8_t *d_frame_bgr, int pitch, uint64_t *d_stats,
                              void *stream);
+
+/* The same frame with the dispatch-order feedback of the *_ordered_dev primary launches for EVERY walking stage of the pipeline (the
+ * reference's tile task runs the whole Scene::RayTrace -- primary, reflection, shadow packets -- behind one dynamic queue,
+ * src/render.cpp:258-267, src/thread_pool.cpp:151-180, so every stage of it is balanced): d_order (in) / d_slot_cost (out), either may be
+ * NULL, are SNAIL_WHITTED_STAGES arrays of nSlots = snail_primary_slots(resx, resy) int32 each, back to back:
+ *   stage 0  the primary packets                     (slot = the primary launch's slot)
+ *   stage 1  the shadow packets of the primary hits  (same slots; the FIRST light's node visits)
+ *   stage 2  the mirrored packets                    (slot = packet index cy * ceil(resx / 16) + cx; unused without SNAIL_WHITTED_REFLECTIONS)
+ *   stage 3  the shadow packets of the mirrored hits (slots as stage 0; likewise)
+ * Turn stage k's costs into its next order with snail_order_from_cost_dev(d_slot_cost + k * nSlots, nSlots, d_order + k * nSlots, stream).
+ * Frame bytes and counters never depend on the orders. */
+#define SNAIL_WHITTED_STAGES 4
+int snail_render_whitted_ordered_dev(SnailScene *, const float cam[13], int resx, int resy, const float *lights7, int nLights,
+                                     const float ambient[3], const float color[3], int flags, uint8_t *d_frame_bgr, int pitch, uint64_t *d_stats,
+                                     const int32_t *d_order, int32_t *d_slot_cost, void *stream);
 
 /* The same for an explicit list of packets (a rank's tiles): output = packet-major B,G,R bytes [nPackets][256][3] (4-byte aligned),
  * to be gathered and scattered with snail_packets_bgr_to_frame_dev -- a render node with the reference's simple shading on. */

@@ -59,6 +59,7 @@ SIGNATURES = {
     "snail_packets_bgr_to_planar_dev": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP]),
     "snail_planar_to_frame_dev": (_I, [_VP, _VP, _I, _VP, _VP, _I, _I, _I, _VP]),
     "snail_render_whitted_dev": (_I, [_VP, _F13, _I, _I, _VP, _I, _VP, _VP, _I, _VP, _I, _VP, _VP]),
+    "snail_render_whitted_ordered_dev": (_I, [_VP, _F13, _I, _I, _VP, _I, _VP, _VP, _I, _VP, _I, _VP, _VP, _VP, _VP]),
     "snail_render_whitted_packets_dev": (_I, [_VP, _F13, _I, _I, _VP, _I, _VP, _I, _VP, _VP, _I, _VP, _VP, _VP]),
     "snail_trace_transparency_dev": (_I, [_VP, _F13, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP]),
     "snail_render_tiles": (_I, [_VP, _F13, _I, _I, _VP, _VP, _I, _VP, _I, _VP, _VP, _I, _VP, _VP]),

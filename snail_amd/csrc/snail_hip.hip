@@ -256,6 +256,7 @@ int relFor(SnailScene *s, const float org[3], hipStream_t stream, const uint4 **
 	const int nSlots = s->nNodes + 1;
 	if(!e.d) HIP_TRY(hipMalloc((void **)&e.d, (size_t)nSlots * 32));
 	if(!e.filled) HIP_TRY(hipEventCreateWithFlags(&e.filled, hipEventDisableTiming));
+	HIP_TRY(hipStreamWaitEvent(stream, e.filled, 0));                                       // its previous fill (a fill whose launch never happened has no reader event)
 	for(int k = 0; k < e.nUsed; k++) HIP_TRY(hipStreamWaitEvent(stream, e.used[k], 0));   // its last readers, on whatever streams
 	e.nUsed = 0;
 	hipLaunchKernelGGL(dev::k_rel_nodes, dim3((unsigned)((nSlots + 255) / 256)), dim3(256), 0, stream, (const uint4 *)s->dPF, nSlots, org[0], org[1], org[2], e.d);
@@ -314,11 +315,7 @@ int launchPrimaryFrames(SnailScene *s, const FrameSet &FS, int resx, int resy, i
 	A.packetMajor = packetMajor ? 1 : 0;
 	A.pack = stackPack(s);
 	int relWhich[SNAIL_MAX_BATCH];
-	for(int k = 0; k < FS.n; k++) {
-		relWhich[k] = -1; A.rel[k] = nullptr;
-		if(A.pack && SNAIL_REL_NODES && SNAIL_NODE_PREFETCH)
-			if(int rc = relFor(s, FS.cam[k], stream, &A.rel[k], &relWhich[k])) return rc;   // cam[0..2] = the camera position
-	}
+	for(int k = 0; k < FS.n; k++) { relWhich[k] = -1; A.rel[k] = nullptr; }
 	int blocks;
 	if(dPacketXY) {
 		if(nPackets <= 0) return 0;
@@ -339,6 +336,11 @@ int launchPrimaryFrames(SnailScene *s, const FrameSet &FS, int resx, int resy, i
 	A.nBlocks = blocks;
 	A.nSlots = dPacketXY ? nPackets : blocks;
 	A.order = dOrder; A.slotCost = dSlotCost;
+	// the frames' origin-relative node records (only the record-prefetching loop reads them: not the DEEP kernels' C++ walk); after every
+	// early return above, so that a fill is always followed by its reader's event (relUsed below)
+	if(A.pack && SNAIL_REL_NODES && SNAIL_NODE_PREFETCH && !useDeep(s))
+		for(int k = 0; k < FS.n; k++)
+			if(int rc = relFor(s, FS.cam[k], stream, &A.rel[k], &relWhich[k])) return rc;   // cam[0..2] = the camera position
 	const int gridBlocks = blocks * FS.n;
 	s->lastBlocks = gridBlocks; s->lastThreads = 64;
 	// deferred-packet list of this launch (re-allocated, synchronously, only when a larger launch than ever before arrives)
@@ -437,7 +439,8 @@ void launchRaysKernels(const SnailScene *s, const dev::RaysArgs &A, int blocks, 
 }
 
 int launchRays(SnailScene *s, bool shadow, int nPackets, int size, int sharedOrigin, const float *origin, const float *dir,
-					  const float *idir, const uint8_t *mask, float *distance, int32_t *object, float *bary, uint64_t *dStats, hipStream_t stream) {
+					  const float *idir, const uint8_t *mask, float *distance, int32_t *object, float *bary, uint64_t *dStats, hipStream_t stream,
+					  const int32_t *dOrder = nullptr, int32_t *dSlotCost = nullptr, int nSlots = 0) {
 	if(nPackets <= 0) return 0;
 	if(size < 1 || size > SNAIL_PACKET_QUADS) { snail_set_error("packet size %d outside 1..%d quads", size, SNAIL_PACKET_QUADS); return 1; }
 	if(!origin || !dir || !idir || !distance || (!shadow && !object)) { snail_set_error("null ray array"); return 1; }
@@ -448,7 +451,11 @@ int launchRays(SnailScene *s, bool shadow, int nPackets, int size, int sharedOri
 	A.origin = origin; A.dir = dir; A.idir = idir; A.mask = mask;
 	A.distance = distance; A.object = object; A.bary = bary;
 	A.stats = (dev::u64 *)dStats;
-	const int blocks = ((nPackets + 127) / 128) * 128;
+	int blocks = ((nPackets + 127) / 128) * 128;
+	if(!shadow && (dOrder || dSlotCost) && nSlots >= nPackets) { // dispatch-order feedback of the staged pipeline (k_rays): one block per slot
+		A.order = dOrder; A.slotCost = dSlotCost; A.nSlots = nSlots;
+		if(nSlots > blocks) blocks = ((nSlots + 127) / 128) * 128;
+	}
 	SnailScene::RayDefer &R = s->rayDefer[s->rayCount++ % SnailScene::kDeferSlots];
 	if((size_t)nPackets + 16 > R.cap) { // grown synchronously when a larger batch than ever before arrives
 		HIP_TRY(hipDeviceSynchronize());
@@ -781,7 +788,14 @@ int snail_trace_packets_ordered_dev(SnailScene *s, const float cam[13], int resx
 int snail_order_from_cost_dev(const int32_t *dSlotCost, int nSlots, int32_t *dOrder, void *stream) {
 	if(nSlots <= 0) return 0;
 	if(!dSlotCost || !dOrder) { snail_set_error("snail_order_from_cost_dev: null buffer"); return 1; }
-	hipLaunchKernelGGL(dev::k_order_from_cost, dim3(1), dim3(ORDER_THREADS), 0, (hipStream_t)stream, dSlotCost, nSlots, dOrder);
+	const hipStream_t st = (hipStream_t)stream;
+	const size_t stashBytes = (size_t)((nSlots + 3) / 4 * 4) * 2;
+	bool ldsForm = nSlots <= ORDER_LDS_MAX_SLOTS && ((uintptr_t)dSlotCost & 15) == 0;   // (a caller's array that is not 16-byte aligned, or a frame beyond ~6K x 4K: the multi-pass kernel)
+	if(ldsForm && stashBytes > 32768)   // more dynamic LDS than a kernel gets by default (static 16.4 KB + this)
+		ldsForm = hipFuncSetAttribute((const void *)dev::k_order_from_cost_lds, hipFuncAttributeMaxDynamicSharedMemorySize, ORDER_LDS_MAX_SLOTS * 2) == hipSuccess;
+	if(ldsForm)
+		hipLaunchKernelGGL(dev::k_order_from_cost_lds, dim3(1), dim3(ORDER_THREADS_LDS), stashBytes, st, dSlotCost, nSlots, dOrder);
+	else hipLaunchKernelGGL(dev::k_order_from_cost, dim3(1), dim3(ORDER_THREADS), 0, st, dSlotCost, nSlots, dOrder);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
@@ -961,7 +975,7 @@ int snail_trace_shadow(SnailScene *s, int nPackets, int size, const float *origi
 
 static int renderWhitted(const char *fn, SnailScene *s, const float cam[13], int resx, int resy, const int32_t *dPacketXY, int nPacketsList, const float *lights7,
 						 int nLights, const float ambient[3], const float color[3], int flags, uint8_t *frame, int pitch, uint8_t *bgrPackets, uint64_t *dStats,
-						 void *stream, float *colPackets = nullptr) {
+						 void *stream, float *colPackets = nullptr, const int32_t *dOrder = nullptr, int32_t *dSlotCost = nullptr) {
 	if(int rc = checkScene(s, fn)) return rc;
 	if(resx <= 0 || resy <= 0 || nLights < 0 || nLights > SNAIL_MAX_LIGHTS || (nLights && !lights7) || !ambient || !color || (flags & ~SNAIL_WHITTED_REFLECTIONS) ||
 	   (dPacketXY ? (colPackets ? false : (!bgrPackets || ((unsigned long long)bgrPackets & 3))) : (!frame || pitch < resx * 3 || colPackets))) {
@@ -994,6 +1008,13 @@ static int renderWhitted(const char *fn, SnailScene *s, const float cam[13], int
 	}
 	A.nPackets = packets;
 	A.nBlocks = blocks;
+	A.fuse = nLights == 1 ? 1 : 0;   // one light: its k_light waves finish the packets themselves (no sDist round trip, no k_final launch)
+	// dispatch-order feedback, frame grid only: SNAIL_WHITTED_STAGES arrays of `blocks` entries, back to back -- the primary packets, the shadow
+	// packets of the primary hits (first light), the mirrored packets, the shadow packets of the mirrored hits (include/snail_hip.h)
+	const int32_t *ord[SNAIL_WHITTED_STAGES] = {};
+	int32_t *cst[SNAIL_WHITTED_STAGES] = {};
+	if(!dPacketXY)
+		for(int k = 0; k < SNAIL_WHITTED_STAGES; k++) { ord[k] = dOrder ? dOrder + (size_t)k * blocks : nullptr; cst[k] = dSlotCost ? dSlotCost + (size_t)k * blocks : nullptr; }
 	SnailScene::ShadeScratch &W = s->shade[s->shadeCount++ % SnailScene::kDeferSlots];
 	if(int rc = shadeScratch(s, W, (size_t)packets, (size_t)blocks, refl)) return rc;
 	if(!W.done) HIP_TRY(hipEventCreateWithFlags(&W.done, hipEventDisableTiming));
@@ -1009,17 +1030,19 @@ static int renderWhitted(const char *fn, SnailScene *s, const float cam[13], int
 	// the primary packets (the bench kernel), hit records packet-major
 	if(dPacketXY) {
 		if(int rc = launchPrimary(s, cam, resx, resy, 0, 0, 0, 0, dPacketXY, packets, W.hitT, nullptr, nullptr, W.hitId, dStats, st)) return rc;
-	} else if(int rc = launchPrimary(s, cam, resx, resy, 0, 0, resx, resy, nullptr, 0, W.hitT, nullptr, nullptr, W.hitId, dStats, st, nullptr, true)) return rc;
+	} else if(int rc = launchPrimary(s, cam, resx, resy, 0, 0, resx, resy, nullptr, 0, W.hitT, nullptr, nullptr, W.hitId, dStats, st, nullptr, true, nullptr, ord[0], cst[0])) return rc;
 	if(refl) { // the nested RayTrace of the mirrored packets
 		SNAIL_LAUNCH(sse, ShadeArgs, grid, wave, 0, st, A, k_final<dev::SRC_PRIMARY, dev::DST_MIRROR>);
 		HIP_TRY(hipGetLastError());
-		if(int rc = launchRays(s, false, packets, 64, 0, W.rOrg, W.rDir, W.rIDir, W.rMask, W.rDist, W.rObj, nullptr, dStats, st)) return rc;
+		if(int rc = launchRays(s, false, packets, 64, 0, W.rOrg, W.rDir, W.rIDir, W.rMask, W.rDist, W.rObj, nullptr, dStats, st, ord[2], cst[2], dPacketXY ? 0 : blocks)) return rc;
+		A.order = ord[3]; A.slotCost = cst[3]; A.nSlots = blocks;
 		if(int rc = launchLights<dev::SRC_MIRROR>(s, A, st)) return rc;
-		SNAIL_LAUNCH(sse, ShadeArgs, grid, wave, 0, st, A, k_final<dev::SRC_MIRROR, dev::DST_COLOR>);
+		if(!A.fuse) SNAIL_LAUNCH(sse, ShadeArgs, grid, wave, 0, st, A, k_final<dev::SRC_MIRROR, dev::DST_COLOR>);
 		HIP_TRY(hipGetLastError());
 	}
+	A.order = ord[1]; A.slotCost = cst[1]; A.nSlots = blocks;
 	if(int rc = launchLights<dev::SRC_PRIMARY>(s, A, st)) return rc;
-	SNAIL_LAUNCH(sse, ShadeArgs, grid, wave, 0, st, A, k_final<dev::SRC_PRIMARY, dev::DST_FRAME>);
+	if(!A.fuse) SNAIL_LAUNCH(sse, ShadeArgs, grid, wave, 0, st, A, k_final<dev::SRC_PRIMARY, dev::DST_FRAME>);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(W.done, st));
 	W.used = true;
@@ -1029,6 +1052,12 @@ static int renderWhitted(const char *fn, SnailScene *s, const float cam[13], int
 int snail_render_whitted_dev(SnailScene *s, const float cam[13], int resx, int resy, const float *lights7, int nLights, const float ambient[3],
 							 const float color[3], int flags, uint8_t *frame, int pitch, uint64_t *dStats, void *stream) {
 	return renderWhitted("snail_render_whitted_dev", s, cam, resx, resy, nullptr, 0, lights7, nLights, ambient, color, flags, frame, pitch, nullptr, dStats, stream);
+}
+
+int snail_render_whitted_ordered_dev(SnailScene *s, const float cam[13], int resx, int resy, const float *lights7, int nLights, const float ambient[3],
+									 const float color[3], int flags, uint8_t *frame, int pitch, uint64_t *dStats, const int32_t *dOrder, int32_t *dSlotCost, void *stream) {
+	return renderWhitted("snail_render_whitted_ordered_dev", s, cam, resx, resy, nullptr, 0, lights7, nLights, ambient, color, flags, frame, pitch, nullptr, dStats, stream,
+						 nullptr, dOrder, dSlotCost);
 }
 
 int snail_render_whitted_packets_dev(SnailScene *s, const float cam[13], int resx, int resy, const int32_t *dPacketXY, int nPackets, const float *lights7,
@@ -1077,8 +1106,9 @@ int snail_trace_transparency_dev(SnailScene *s, const float cam[13], int resx, i
 	SNAIL_LAUNCH(sse, ShadeArgs, dim3(blocks), dim3(64), 0, st, A, k_final<dev::SRC_PRIMARY, dev::DST_CONTINUE>);
 	HIP_TRY(hipGetLastError());
 	if(int rc = launchRays(s, false, nPackets, 64, 0, W.rOrg, W.rDir, W.rIDir, W.rMask, W.rDist, W.rObj, nullptr, dStats, st)) return rc;
+	A.fuse = nLights == 1 ? 1 : 0;   // (as in renderWhitted: the only light's waves write the colours themselves)
 	if(int rc = launchLights<dev::SRC_MIRROR>(s, A, st)) return rc;
-	SNAIL_LAUNCH(sse, ShadeArgs, dim3(blocks), dim3(64), 0, st, A, k_final<dev::SRC_MIRROR, dev::DST_COLOR>);
+	if(!A.fuse) SNAIL_LAUNCH(sse, ShadeArgs, dim3(blocks), dim3(64), 0, st, A, k_final<dev::SRC_MIRROR, dev::DST_COLOR>);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(W.done, st));
 	W.used = true;
@@ -1238,7 +1268,7 @@ int snail_debug_anyorder(SnailScene *s, const float cam[13], int resx, int resy,
 	hipStream_t st;
 	HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
 	int relWhich = -1;
-	if(A.pack && SNAIL_REL_NODES && SNAIL_NODE_PREFETCH) {
+	if(A.pack && SNAIL_REL_NODES && SNAIL_NODE_PREFETCH && !useDeep(s)) {
 		if(int rc = relFor(s, cam, st, &A.rel[0], &relWhich)) return rc;
 	}
 	hipEvent_t e0, e1;

@@ -226,6 +226,7 @@ class DistributedRenderer:
                             if (rank == 0 and ((self.multi and payload == "rgb8") or self.whitted_single)) else [])
         self.frame_rgb8 = self.frames_rgb8[0] if self.frames_rgb8 else None
         self.pending = [None] * self.nslots
+        self._outputs = {}      # (slot, index in the launch) -> the buffer a launch of this renderer last wrote there (output_buffers())
         # feedback_order: dispatch the packets of a frame heaviest first, by the node visits counted in an earlier frame of the same
         # slot (snail_order_from_cost_dev, on the slot's own stream, so a launch never reads an order that is being rewritten).  The
         # order of a slot is derived after its first frame and re-derived only when the camera has moved since AND `order_refresh`
@@ -233,14 +234,18 @@ class DistributedRenderer:
         # sort (20 us alone, ~100 us beside four frames in flight) then never sits in a short timed region of a fixed view.
         # Worth 10-12 % on heavy-tailed scenes (stress-1M 9.76 -> 10.79 Grays/s), neutral on the atrium (profiles/README.md).
         # On the tile-sharded rgb8 route a rank's packets all start at once (fewer packets than wave slots): the order cannot matter there.
-        self.feedback = bool(feedback_order) and (not self.multi or payload == "hits") and not self.whitted_single
+        self.feedback = bool(feedback_order) and (not self.multi or payload == "hits")
         self.order_refresh = max(1, int(order_refresh))
         n_real = len(self.plan.packets[share]) if self.multi else 0
         self.n_real = n_real
         if self.feedback:
             n = scene.primary_slots(resx, resy) if not self.multi else n_real
-            self.slot_cost = [torch.zeros(max(1, n), dtype=torch.int32, device=dev)[:n] for _ in range(self.nslots)]
-            self.order_buf = [torch.empty(max(1, n), dtype=torch.int32, device=dev)[:n] for _ in range(self.nslots)]
+            if self.whitted_single:   # the staged pipeline: one order / cost array per walking stage (Scene.render_whitted)
+                self.slot_cost = [torch.zeros((scene.WHITTED_STAGES, n), dtype=torch.int32, device=dev) for _ in range(self.nslots)]
+                self.order_buf = [torch.empty((scene.WHITTED_STAGES, n), dtype=torch.int32, device=dev) for _ in range(self.nslots)]
+            else:
+                self.slot_cost = [torch.zeros(max(1, n), dtype=torch.int32, device=dev)[:n] for _ in range(self.nslots)]
+                self.order_buf = [torch.empty(max(1, n), dtype=torch.int32, device=dev)[:n] for _ in range(self.nslots)]
             self.order_valid = [False] * self.nslots
             self.order_cam = [None] * self.nslots       # camera the slot's order was derived from
             self.order_age = [0] * self.nslots          # frames of the slot since then
@@ -294,7 +299,14 @@ class DistributedRenderer:
         work.wait()
         if self.rank == 0:
             self.frame_rgb8 = self.frames_rgb8[slot]
+            self._outputs[(slot, 0)] = self.frame_rgb8
             self.scene.packets_bgr_to_frame(self.all_xy_cat, self.gathered_all[slot].view(-1, 256, 3), self.frame_rgb8)
+
+    def output_buffers(self):
+        """The buffers this renderer's launches have written (rank 0; complete after flush()): HitFrames on the single-GPU hit-record
+        route, [resy, resx, 3] uint8 frames otherwise -- one per slot and per frame of a multi-frame launch.  bench.py hashes them after its
+        timed region."""
+        return [self._outputs[k] for k in sorted(self._outputs)]
 
     def _order_for(self, slot, cam):
         """the dispatch order this frame uses (or None), and whether to re-derive the slot's order from this frame's costs"""
@@ -306,7 +318,11 @@ class DistributedRenderer:
         return self.order_buf[slot], (key if refresh else None)
 
     def _refresh_order(self, slot, st, key):
-        self.scene.order_from_cost(self.slot_cost[slot], self.order_buf[slot], stream=st)
+        if self.whitted_single:
+            for k in range(self.scene.WHITTED_STAGES if self.reflections else 2):     # stages 2, 3 exist with the mirrored bounce only
+                self.scene.order_from_cost(self.slot_cost[slot][k], self.order_buf[slot][k], stream=st)
+        else:
+            self.scene.order_from_cost(self.slot_cost[slot], self.order_buf[slot], stream=st)
         self.order_valid[slot], self.order_cam[slot], self.order_age[slot] = True, key, 0
 
     def render(self, cam, stats=None, events=None):
@@ -327,9 +343,12 @@ class DistributedRenderer:
         if not self.multi:      # every call below takes the stream explicitly: no stream context to enter (host time per frame matters)
             if events: events[0].record(st)
             if self.whitted_single:
+                order, key = self._order_for(slot, cam) if self.feedback else (None, None)
                 self.frame_rgb8 = sc.render_whitted(cam, p.resx, p.resy, self.lights7, self.ambient, self.color, out=self.frames_rgb8[slot], stats=stats, stream=st,
-                                                    reflections=self.reflections)
+                                                    reflections=self.reflections, order=order, slot_cost=self.slot_cost[slot] if self.feedback else None)
+                self._outputs[(slot, 0)] = self.frame_rgb8
                 if events: events[1].record(st)
+                if key is not None: self._refresh_order(slot, st, key)
                 return self.frame_rgb8
             if self.feedback:
                 order, key = self._order_for(slot, cam)
@@ -340,6 +359,7 @@ class DistributedRenderer:
                 out = sc.trace_primary(cam, p.resx, p.resy, out=self.frames[slot], stats=stats, stream=st)
                 if events: events[1].record(st)
             self.frame = out
+            self._outputs[(slot, 0)] = out
             return out
         # the collective runs on the CURRENT stream: make the slot's stream current for the rest of the call.  (torch.cuda.stream(st) as
         # a context manager costs the host ~16 us per frame -- it looks the device up through is_available() twice -- of the ~45 us a frame
@@ -401,6 +421,7 @@ class DistributedRenderer:
                 gather_planes(self.local[slot], self.rank, self.world, self.group, self.gathered[slot] if self.rank == 0 else None)
                 if self.rank == 0:
                     self.frame = self.frames[slot]
+                    self._outputs[(slot, 0)] = self.frame
                     for k, xy in enumerate(self.all_xy):
                         g = self.gathered[slot][k]
                         sc.packets_to_frame(xy, (g[0], g[1], g[2], g[3].view(torch.int32)), self.frame, stream=st)
@@ -423,6 +444,7 @@ class DistributedRenderer:
                 dist.gather(self.bgr[slot], self.gathered[slot] if self.rank == 0 else None, dst=0, group=self.group, async_op=False)
                 if self.rank == 0:
                     self.frame_rgb8 = self.frames_rgb8[slot]
+                    self._outputs[(slot, 0)] = self.frame_rgb8
                     sc.packets_bgr_to_frame(self.all_xy_cat, self.gathered_all[slot].view(-1, 256, 3), self.frame_rgb8)
                 return self.frame_rgb8
             self.pending[slot] = dist.gather(self.bgr[slot], self.gathered[slot] if self.rank == 0 else None, dst=0, group=self.group, async_op=True)
@@ -452,6 +474,7 @@ class DistributedRenderer:
             sc.trace_primary_batch(cams, p.resx, p.resy, outs, stats=stats, stream=st)
             if events: events[1].record(st)
         self.frame = outs[-1]
+        for k, o in enumerate(outs): self._outputs[(slot, k)] = o
 
     def _launch_batch_multi(self, cams, events, stats, slot, st):
         """the tile-sharded route for a batch: one launch (this rank's packets x the batch's cameras), one collective, one scatter per frame"""
@@ -474,6 +497,7 @@ class DistributedRenderer:
             n = self.plan.padded
             for k in range(len(cams)):
                 self.frame_rgb8 = self.framesB_rgb8[slot][k]
+                self._outputs[(slot, k)] = self.frame_rgb8
                 sc.packets_bgr_to_frame_chunked(self.all_xy_cat, n, self.batch * n * 768, self.gatheredB_all[slot][0, k], self.frame_rgb8, stream=st)
         return self.frame_rgb8
 

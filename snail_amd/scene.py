@@ -332,8 +332,10 @@ class Scene:
         _lib.check(rc, "snail_planar_to_frame_dev")
         return frame_rgb8
 
+    WHITTED_STAGES = 4
+
     def render_whitted(self, cam: Camera, resx: int, resy: int, lights7, ambient=(0.1, 0.1, 0.1), color=(1.0, 1.0, 1.0), out=None, stats=None,
-                       stream=None, reflections: bool = False):
+                       stream=None, reflections: bool = False, order=None, slot_cost=None):
         """Scene::RayTrace in the reference's simple-shading configuration (primary + one shadow packet per point light;
         reflections=True = gVals[7], one mirrored bounce shaded the same way), staged on the device; returns the interleaved
         [resy,resx,3] uint8 (B,G,R) frame.  lights7 = n x {pos, color, radius} (class Light, src/light.h:5-16); defaults =
@@ -344,6 +346,17 @@ class Scene:
         lights = np.ascontiguousarray(lights7, dtype=np.float32).reshape(-1, 7)
         cam13 = np.ascontiguousarray(cam.as_array13(), dtype=np.float32)
         amb = np.ascontiguousarray(ambient, dtype=np.float32); col = np.ascontiguousarray(color, dtype=np.float32)
+        if order is not None or slot_cost is not None:
+            # dispatch-order feedback of every walking stage: int32 device tensors [WHITTED_STAGES, primary_slots(resx, resy)] (snail_render_whitted_ordered_dev)
+            n = self.primary_slots(resx, resy)
+            for a in (order, slot_cost):
+                if a is not None and (tuple(a.shape) != (self.WHITTED_STAGES, n) or a.dtype != torch.int32 or not a.is_contiguous()):
+                    raise ValueError(f"order / slot_cost must be contiguous int32 tensors of shape ({self.WHITTED_STAGES}, {n})")
+            rc = _lib.lib().snail_render_whitted_ordered_dev(self._h, _lib.ptr(cam13), resx, resy, _lib.ptr(lights), len(lights), _lib.ptr(amb), _lib.ptr(col),
+                                                             1 if reflections else 0, _lib.ptr(out), resx * 3, _lib.ptr(stats), _lib.ptr(order), _lib.ptr(slot_cost),
+                                                             _stream_ptr(stream))
+            _lib.check(rc, "snail_render_whitted_ordered_dev")
+            return out
         rc = _lib.lib().snail_render_whitted_dev(self._h, _lib.ptr(cam13), resx, resy, _lib.ptr(lights), len(lights), _lib.ptr(amb), _lib.ptr(col),
                                                  1 if reflections else 0, _lib.ptr(out), resx * 3, _lib.ptr(stats), _stream_ptr(stream))
         _lib.check(rc, "snail_render_whitted_dev")

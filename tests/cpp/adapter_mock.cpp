@@ -31,7 +31,7 @@ struct TreeStats {
 	void Skip(unsigned v = 1) { sk += v; }
 	void TracingRays(unsigned v = 1) { rays += v; }
 };
-struct Options { bool reflections = false, rdtscShader = false; };
+struct Options { Options(bool refl, bool rdtsc) : reflections(refl), rdtscShader(rdtsc) {} Options() { reflections = rdtscShader = 0; } bool reflections, rdtscShader; };   // src/render.h:9-14
 struct Light { Vec3f pos, color; float radius, radSq, iRadius; };
 struct MipmapTexture {
 	int w = 0, h = 0, pitch = 0; std::vector<unsigned char> bytes;
@@ -201,7 +201,9 @@ int main(int argc, char **argv) {
 			std::fprintf(fs, "tiles_multi %d %d\n", (int)same, scene3.geometry.DeviceCount());
 		}
 		MipmapTexture img; img.w = resx; img.h = resy; img.pitch = (resx * 3 + 63) / 64 * 64; img.bytes.assign((size_t)img.pitch * resy, 0xCD);
-		const TreeStats si = Render(scene, cam, img, Options(), 4u);
+		// Options(true, ...) must change NOTHING: the reference stores its Options and never reads them (src/render.cpp:24,37); the bounce is
+		// gVals[7]'s alone (src/scene_trace.cpp:454).  With gVals[7] == 0 this call must give the no-bounce picture.
+		const TreeStats si = Render(scene, cam, img, Options(true, false), 4u);
 		f = std::fopen((d + "out_image.bin").c_str(), "wb"); dump(f, img.bytes); std::fclose(f);
 		std::fprintf(fs, "image %u %u %u %u %d\n", si.in, si.it, si.rays, si.sk, img.pitch);
 	}

@@ -1334,6 +1334,20 @@ def test_dispatch_order_feedback_changes_nothing_but_the_order(torch_mod, name, 
         sh = 0
         while (max(int(cst.max()), 0) >> sh) > 4095: sh += 1
         assert (np.diff(np.minimum(np.maximum(cst[od], 0) >> sh, 4095)) <= 0).all(), m2
+    # round 4's one-read form (up to 49152 slots, 16-byte aligned input): the bench's sizes (8192 = 1080p, 32640 = 4K: more than 32 KB of
+    # dynamic LDS), its limits (49152 / 49153: the multi-pass kernel again), ragged tails, an unaligned input (multi-pass kernel), and costs
+    # beyond 16 bits (clamped: every slot of 65535 visits or more shares the heaviest class)
+    for m2, hi, off in ((8192, 3000, 0), (32640, 60000, 0), (49152, 65535, 0), (49153, 65535, 0), (8191, 500, 0), (8189, 500, 0), (5, 9, 0), (8192, 3000, 1),
+                        (4097, 1 << 20, 0)):
+        cst = rng.integers(0, hi + 1, m2 + off).astype(np.int32)
+        cst[rng.integers(0, m2 + off, max(1, m2 // 50))] = hi       # a heavy tail
+        dev_c = torch_mod.from_numpy(cst).cuda()[off:]            # off = 1: a view that starts 4 bytes into the allocation
+        od = sc.order_from_cost(dev_c).cpu().numpy()
+        c2 = np.minimum(cst[off:], 65535) if m2 <= 49152 and off == 0 else cst[off:]
+        assert np.array_equal(np.sort(od), np.arange(m2)), (m2, off)
+        sh = 0
+        while (int(c2.max()) >> sh) > 4095: sh += 1
+        assert (np.diff(np.minimum(c2[od] >> sh, 4095)) <= 0).all(), (m2, off)
     # the renderer with the feedback on: every frame of a moving camera equals the oracle's
     rnd = R.DistributedRenderer(sc, resx, resy, feedback_order=True, order_refresh=2)
     bmin, bmax = osc.nodes[0]["bmin"], osc.nodes[0]["bmax"]
@@ -1494,4 +1508,60 @@ def test_tiny_masked_per_ray_origin_packets(torch_mod, name):
         assert np.array_equal(ctx.distance.cpu().numpy().view(np.uint32), d2.view(np.uint32)), (b, size, npk)
         assert np.array_equal(ctx.barycentric.cpu().numpy().view(np.uint32), b2.view(np.uint32)), (b, size, npk)
         assert s[0] == ost[0] and s[1] == ost[1], (b, size, npk, s, ost)
+    sc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,resx,resy,nl,refl", [("atrium:0.05", 640, 368, 1, False), ("atrium:0.05", 640, 368, 1, True), ("atrium:0.05", 328, 200, 2, True),
+                                                     ("stress:0.05", 250, 130, 1, True), ("box", 64, 64, 1, True)])
+def test_staged_pipeline_dispatch_orders_change_nothing_but_the_order(torch_mod, name, resx, resy, nl, refl):
+    """snail_render_whitted_ordered_dev: every walking stage of the staged pipeline (primary packets, their shadow packets, the mirrored
+    packets, their shadow packets) takes a dispatch order and returns its packets' node visits.  The frame and the counters are those of
+    the plain call -- and the oracle's -- under the fed-back orders, reversed orders and random ones; the costs add up to the counters."""
+    tv, sc, osc = gpu_scene(name)
+    cam = util.camera_for(name, tv)
+    bmin, bmax = osc.nodes[0]["bmin"], osc.nodes[0]["bmax"]
+    c, e = (bmin + bmax) * 0.5, (bmax - bmin)
+    lights = np.array([[c[0], c[1] + 0.35 * e[1], c[2], 1.0, 0.9, 0.8, 2.0 * float(e.max())],
+                       [c[0] - 0.3 * e[0], c[1] + 0.1 * e[1], c[2] + 0.2 * e[2], 0.3, 0.5, 1.0, 0.6 * float(e.max())]], dtype=np.float32)[:nl]
+    want, wst = osc.render_whitted(cam.as_array13(), resx, resy, lights, mode=O.MODE_IEEE, reflections=refl)
+    n = sc.primary_slots(resx, resy)
+    S = sc.WHITTED_STAGES
+    cost = torch_mod.full((S, n), -7, dtype=torch_mod.int32, device="cuda")
+    st0 = sc.new_stats()
+    got = sc.render_whitted(cam, resx, resy, lights, stats=st0, reflections=refl, slot_cost=cost).cpu().numpy()
+    assert np.array_equal(got, want), int((got != want).sum())
+    assert np.array_equal(st0.cpu().numpy().astype(np.uint64), wst)
+    cst = cost.cpu().numpy()
+    stages = range(S) if refl else range(2)
+    for k in stages:
+        assert (cst[k] >= 0).all(), k                               # every slot of a stage that ran was written
+    if nl == 1:                                                      # one light: the stages' node visits are ALL the frame's node visits
+        assert int(cst[list(stages)].astype(np.int64).sum()) == int(wst[1]), (cst[list(stages)].sum(axis=1), wst)
+    rng = np.random.default_rng(3)
+    fed = torch_mod.empty((S, n), dtype=torch_mod.int32, device="cuda")
+    for k in range(S):
+        sc.order_from_cost(cost[k] if k in stages else torch_mod.zeros(n, dtype=torch_mod.int32, device="cuda"), fed[k])
+    rev = torch_mod.flip(fed, dims=[1]).contiguous()
+    rnd = torch_mod.from_numpy(np.stack([rng.permutation(n) for _ in range(S)]).astype(np.int32)).cuda()
+    for what, order in (("fed back", fed), ("reversed", rev), ("random", rnd)):
+        st = sc.new_stats()
+        c2 = torch_mod.zeros((S, n), dtype=torch_mod.int32, device="cuda")
+        g = sc.render_whitted(cam, resx, resy, lights, stats=st, reflections=refl, order=order, slot_cost=c2).cpu().numpy()
+        assert np.array_equal(g, want), (what, int((g != want).sum()))
+        assert np.array_equal(st.cpu().numpy().astype(np.uint64), wst), (what, st.cpu().numpy(), wst)
+        for k in stages:
+            assert np.array_equal(c2[k].cpu().numpy(), cst[k]), (what, k)        # a packet's cost does not depend on when it ran
+    # the renderer with the feedback on (bench.py --config 3): frames of a moving camera equal the oracle's
+    from snail_amd import render as R
+    r = R.DistributedRenderer(sc, resx, resy, lights7=lights, reflections=refl, feedback_order=True, order_refresh=2)
+    assert r.feedback and r.whitted_single
+    cams = [cam] * 5 + [FPSCamera(np.asarray(cam.pos) + np.float32(0.05 * i) * np.asarray(cam.front), *((scenes.atrium_camera() if name.startswith("atrium") else (None, 0.3, 0.1))[1:])).camera()
+                        for i in range(1, 8)]
+    for i, cm in enumerate(cams):
+        f = r.render(cm)
+        r.flush()
+        w2, _ = osc.render_whitted(cm.as_array13(), resx, resy, lights, mode=O.MODE_IEEE, reflections=refl)
+        assert np.array_equal(f.cpu().numpy(), w2), i
+    assert all(r.order_valid)
     sc.close()
