@@ -446,6 +446,23 @@ def main():
         lone_launch_ms = ts[len(ts) // 2]
         barrier()
 
+    # ---- N > 1: the line audits its own ranks -- what the process group itself reports (a one per rank, all-reduced over the group the
+    # collectives use), the GPU each rank sits on (distinct UUIDs unless this is the one-GPU rehearsal), whether every rank's renderer
+    # switches streams the fast way, and the collective alone (rank 0's inbound bytes / time) ----
+    audit = None
+    if world > 1:
+        one = torch.ones(1, dtype=torch.int64, device="cpu" if rehearsal else torch.device("cuda", local_rank))
+        dist.all_reduce(one)
+        props = torch.cuda.get_device_properties(local_rank)
+        mine = {"rank": rank, "device_index": local_rank, "uuid": str(getattr(props, "uuid", "")), "name": props.name, "raw_stream_switch": bool(rnd._raw_stream_switch)}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        gb = rnd.measure_gather(20)
+        if rank == 0:
+            uu = [e["uuid"] for e in everyone]
+            audit = {"rccl_ranks_seen": int(one.item()), "ranks": everyone, "devices_distinct": len(set(uu)) == world and all(uu),
+                     "raw_stream_switch_all": all(e["raw_stream_switch"] for e in everyone), "gather": gb}
+
     # ---- one frame at a time (N = 1): the latency a frame has when nothing else is in flight ----
     lone_ms = None
     if rank == 0 and world == 1 and args.lone_frames > 0:
@@ -567,7 +584,10 @@ def main():
                        "lone_launch_note": ("host clock of rank 0 around %d frame(s) = one launch + one collective + scatter with nothing else in flight" % rnd.batch) if lone_launch_ms is not None else None,
                        "settle_ms": args.settle_ms, "settle_frames": settle_frames, "settle_measured_ms": round(settle_measured_ms, 2),
                        "camera_path": args.camera_path if len(path) > 1 else "static", "order_refresh": rnd.order_refresh if rnd.feedback else None,
-                       "ranks": world, "backend": ("gloo (rehearsal)" if rehearsal else "nccl (RCCL)") if world > 1 else None,
+                       "ranks": world, "rccl_ranks_seen": audit["rccl_ranks_seen"] if audit else None, "devices_distinct": audit["devices_distinct"] if audit else None,
+                       "raw_stream_switch": audit["raw_stream_switch_all"] if audit else None, "gather_alone": audit["gather"] if audit else None,
+                       "rank_devices": [{k: e[k] for k in ("rank", "device_index", "uuid")} for e in audit["ranks"]] if audit else None,
+                       "backend": ("gloo (rehearsal)" if rehearsal else "nccl (RCCL)") if world > 1 else None,
                        "packet_order": "heaviest first (node visits of an earlier frame)" if rnd.feedback else "built-in region interleave",
                        "traversal_stack": "VGPR pair per wave (lane i = slot i), at most bvh_depth = %d slots; LDS 0 B/wave in the main kernel (3328 B/wave only in the deferred M_EXACT pass)" % hbvh.depth,
                        "packets_per_rank": [len(p) for p in rnd.plan.packets] if world > 1 else None,

@@ -501,6 +501,38 @@ class DistributedRenderer:
                 sc.packets_bgr_to_frame_chunked(self.all_xy_cat, n, self.batch * n * 768, self.gatheredB_all[slot][0, k], self.frame_rgb8, stream=st)
         return self.frame_rgb8
 
+    def measure_gather(self, iters: int = 20):
+        """The collective ALONE (every rank calls it, after flush()): `iters` gathers of slot 0's payload buffer with nothing else in flight;
+        returns, on rank 0, {"bytes_per_collective": what rank 0 receives from the OTHER ranks, "ms": mean time of one collective, "GBps"}
+        -- the inbound rate of rank 0's links when the backend is RCCL, of the host staging when it is the gloo rehearsal -- elsewhere None."""
+        import time
+        import torch.distributed as dist
+        torch = self.torch
+        if not self.multi or self.payload != "rgb8":
+            return None
+        send = self.bgrB[0] if self.batch > 1 else self.bgr[0]
+        recv = (self.gatheredB[0] if self.batch > 1 else self.gathered[0]) if self.rank == 0 else None
+        def one():
+            if self.stage_cpu:
+                host = send.cpu()
+                dist.gather(host, [torch.empty_like(host) for _ in range(self.world)] if self.rank == 0 else None, dst=0, group=self.group)
+            else:
+                dist.gather(send, recv, dst=0, group=self.group, async_op=False)
+        one()
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier(group=self.group)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            one()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / iters
+        if self.rank != 0:
+            return None
+        nbytes = int(send.numel()) * int(send.element_size()) * (self.world - 1)
+        return {"bytes_per_collective": nbytes, "ms": round(ms, 4), "GBps": round(nbytes / ms / 1e6, 2) if ms > 0 else None,
+                "frames_per_collective": self.batch, "transport": "host staging (gloo rehearsal)" if self.stage_cpu else "device buffers"}
+
     def reduce_stats(self, stats):
         """Sum the ranks' TreeStats accumulators (device int64[4], Scene.new_stats()) onto rank 0; call after flush()."""
         if self.stage_cpu and self.world > 1:

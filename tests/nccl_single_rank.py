@@ -106,6 +106,21 @@ def main():
     out["uneven_sizes"] = sizes
     out["uneven_frame_equal"] = bool(len(set(sizes)) > 1 and np.array_equal(union, want2))
     out["uneven_stats_equal"] = bool(np.array_equal(total.astype(np.uint64), ref2[4]))
+    # what bench.py --gpus N adds to its line at N > 1 (the self-audit), over the same RCCL group: a one per rank all-reduced on the device, every
+    # rank's device record through all_gather_object, the collective alone (batched and single-frame payload buffers)
+    one = torch.ones(1, dtype=torch.int64, device="cuda")
+    dist.all_reduce(one)
+    props = torch.cuda.get_device_properties(0)
+    everyone = [None]
+    dist.all_gather_object(everyone, {"rank": 0, "uuid": str(getattr(props, "uuid", ""))})
+    gb = []
+    for fpl in (1, 4):
+        rnd = DistributedRenderer(sc, resx, resy, 0, 1, force_collective=True, frames_per_launch=fpl)
+        for _ in range(2 * fpl):
+            rnd.render(cam)
+        rnd.flush()
+        gb.append(rnd.measure_gather(5))
+    out["audit_ok"] = bool(int(one.item()) == 1 and everyone[0]["uuid"] != "" and all(g and g["ms"] > 0 and g["bytes_per_collective"] == 0 for g in gb))
     dist.destroy_process_group()
     print(json.dumps(out), flush=True)
 
