@@ -157,7 +157,8 @@ def pmc_counters(workload_key: str):
     tr = d.get(workload_key)
     if tr is not None:
         tr = dict(tr)
-        tr["_stale"] = d.get("_kernel_sha16") != kernel_source_sha16()
+        # (another build of the library loaded through SNAIL_LIB_PATH -- tools/variant.sh -- is never what the counters were measured on)
+        tr["_stale"] = d.get("_kernel_sha16") != kernel_source_sha16() or bool(os.environ.get("SNAIL_LIB_PATH"))
     return tr
 
 
@@ -522,13 +523,13 @@ def main():
         ms_per_step = elapsed * 1e3 / args.steps
         step_s = ms_per_step * 1e-3
         value = total_rays * args.steps / elapsed / 1e6
-        key = "%s_%dx%d_n%d_c%d%s" % (scene_name, resx, resy, world, args.config, "r" if (args.reflections and cfg["lights"]) else "")
+        key = "%s_%dx%d_n%d_c%d%s%s" % (scene_name, resx, resy, world, args.config, "r" if (args.reflections and cfg["lights"]) else "", "_sse" if args.arith == "host_sse" else "")
         tr = pmc_counters(key)
         shared_note = ""
         if tr is None and world > 1 and args.scaling == "strong":
             # N ranks share the SAME frame: its counters are those of the one-GPU pass of this workload (the walk of a packet does not depend
             # on which rank traces it; the depth-shading epilogue of the tile route adds < 1 % vector instructions), priced against N GPUs' peak
-            tr = pmc_counters("%s_%dx%d_n1_c%d" % (scene_name, resx, resy, args.config))
+            tr = pmc_counters("%s_%dx%d_n1_c%d%s%s" % (scene_name, resx, resy, args.config, "r" if (args.reflections and cfg["lights"]) else "", "_sse" if args.arith == "host_sse" else ""))
             shared_note = " [N = %d: the frame's counters from the one-GPU pass, peak = %d x one GPU's]" % (world, world)
         valu = tr.get("valu_insts_per_launch") if tr else None
         traffic = tr.get("bytes_per_launch") if tr else None

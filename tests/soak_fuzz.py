@@ -1,6 +1,7 @@
 """Long seeded fuzz run (not collected by pytest; uses the oracle, hence lives under tests/): random cameras, frame sizes, lights,
 scenes and tree builders, GPU hit records / staged config-3 frames / counters against the oracle, bit for bit.
-Usage: python tests/soak_fuzz.py [cases] [seed] [focus]   (focus = "refl": the stress scene with the mirrored bounce only, differences printed)"""
+Usage: python tests/soak_fuzz.py [cases] [seed] [focus]   (focus = "refl": the stress scene with the mirrored bounce only, differences printed;
+focus = "sse": every case in SNAIL_ARITH_HOST_SSE against the oracle's ORC_MODE_SSE -- this CPU's rcpps / rsqrtps on both sides)"""
 import math, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -17,6 +18,8 @@ scn = {}
 for n in names:
     tv, hb, osc = util.scene_pair(n)
     scn[n] = (tv, Scene(hb, 0), osc)
+    if focus == "sse": scn[n][1].set_arith("host_sse")
+MODE = O.MODE_SSE if focus == "sse" else O.MODE_IEEE
 L_ = O.lib(); L_.orc_caller_mxcsr.restype = __import__("ctypes").c_uint
 print("caller MXCSR 0x%04x (0x1f80 = default); float32 denormals in numpy: %s" % (L_.orc_caller_mxcsr(), "kept" if float(np.float32(1e-40) * np.float32(0.5)) != 0.0 else "FLUSHED"), flush=True)
 bad = 0; t0 = time.time()
@@ -31,7 +34,7 @@ for case in range(cases):
     pitch = (rng.rand() - 0.5) * 3.0 if rng.rand() < 0.8 else 0.0
     cam = FPSCamera(pos.astype(np.float32), yaw, pitch, plane_dist=float(np.exp(rng.uniform(-2.0, 2.0)))).camera()
     resx, resy = int(rng.randint(1, 260)), int(rng.randint(1, 200))
-    want = osc.render_primary(cam.as_array13(), resx, resy, mode=O.MODE_IEEE)
+    want = osc.render_primary(cam.as_array13(), resx, resy, mode=MODE)
     st = sc.new_stats(); fr = sc.trace_primary(cam, resx, resy, stats=st); torch.cuda.synchronize()
     ok = all(np.array_equal(g.cpu().numpy().view(np.uint32), w.view(np.uint32)) for g, w in zip((fr.t, fr.u, fr.v, fr.tri_id), want[:4]))
     ok = ok and np.array_equal(st.cpu().numpy().astype(np.uint64), want[4])
@@ -41,7 +44,7 @@ for case in range(cases):
     for k in range(nl):
         lights[k, :3] = c + (rng.rand(3) - 0.5) * e * 1.2
         lights[k, 3:6] = rng.rand(3); lights[k, 6] = float(e.max()) * float(np.exp(rng.uniform(-2.5, 1.0)))
-    wimg, wst = osc.render_whitted(cam.as_array13(), resx, resy, lights, mode=O.MODE_IEEE, reflections=refl)
+    wimg, wst = osc.render_whitted(cam.as_array13(), resx, resy, lights, mode=MODE, reflections=refl)
     st = sc.new_stats(); img = sc.render_whitted(cam, resx, resy, lights, stats=st, reflections=refl); torch.cuda.synchronize()
     ok2 = np.array_equal(img.cpu().numpy(), wimg) and np.array_equal(st.cpu().numpy().astype(np.uint64), wst)
     if not (ok and ok2):
