@@ -91,7 +91,7 @@ def kernel_source_sha16() -> str:
     old instruction count."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("snail_hip.hip", "snail_dev.inc", "lbvh.inc", "render_host.inc", "host_sse.h", "Makefile"):
+    for f in ("snail_hip.hip", "snail_dev.inc", "lbvh.inc", "host_sse.h", "Makefile"):
         with open(os.path.join(ROOT, "snail_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

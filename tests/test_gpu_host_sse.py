@@ -159,6 +159,20 @@ def test_tile_renderer_in_host_sse(torch_mod, mode):
         img, st = sc.render_image_host(cam, resx, resy, lights, flags)
         assert np.array_equal(img, want), (aa, int((img != want).sum()))
         assert np.array_equal(st, wst), (aa, st, wst)
+    # the tile list dealt over two handles of the scene: both in the host's arithmetic -> the same bytes; mixed arithmetics are refused
+    from snail_amd import render as R
+    tiles = R.divide_image(resx, resy)
+    sc2 = Scene(sc.bvh, 0)
+    with pytest.raises(Exception, match="another arithmetic"):
+        sc.render_tiles_host(cam, resx, resy, tiles, lights, 0, scenes=[sc, sc2])
+    sc2.set_arith("host_sse")
+    want, wst = osc.render_whitted(cam.as_array13(), resx, resy, lights, mode=O.MODE_SSE, reflections=mode == "refl", depth=mode == "depth")
+    fl = (Scene.RENDER_REFLECTIONS if mode == "refl" else 0) | (Scene.RENDER_DEPTH if mode == "depth" else 0)
+    data, offsets, tst = sc.render_tiles_host(cam, resx, resy, tiles, lights, fl, scenes=[sc, sc2])
+    for k, wp in enumerate(O.planar_encode(want, tiles)):
+        assert np.array_equal(data[offsets[k]:offsets[k] + len(wp)], wp), ("tile", k)
+    assert np.array_equal(tst, wst), (tst, wst)
+    sc2.close()
     # the stand-alone depth shading of existing hit records, special values included
     t = torch_mod.tensor([[float("inf"), 1e-6, float("nan"), 1.0, 3.0e38, 1.0e-39] + [2.0] * 250], dtype=torch_mod.float32, device="cuda")
     b = sc.shade_depth(t, arith="host_sse").cpu().numpy().reshape(-1, 3)
