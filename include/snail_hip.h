@@ -103,6 +103,13 @@ int snail_scene_arith(const SnailScene *, int *arith);
 /* The host CPU's tables: T_rcp[4096] (bits of rcpps(1.m), index m >> 11), T_rsqrt[4096] for [1, 2), T_rsqrt[4096] for [2, 4); NULL = only
  * the status.  No device needed. */
 int snail_host_sse_tables(uint32_t *tables12288);
+/* SNAIL_ARITH_HOST_SSE with the tables of ANOTHER CPU (3 x 4096 words in the layout above, e.g. what snail_host_sse_tables returned on that
+ * machine; NULL = this host's own again): every machine of a render farm then computes what the reference computes on the CPU the tables came
+ * from, whatever its own CPU is -- the reference's own cluster mixed CPU families (readme_distributed.txt), whose rcpps / rsqrtps differ.
+ * Process-wide; a device's copy is refreshed by the next snail_scene_set_arith(scene, SNAIL_ARITH_HOST_SSE) of a scene on it (which waits for
+ * that device's work in flight): set the tables first, then the scenes' arithmetic.  snail_host_sse_tables returns the tables in force;
+ * snail_host_sse_check keeps comparing with THIS host's instructions.  Returns 1 for tables that are not tables of reciprocals. */
+int snail_arith_set_tables(const uint32_t *tables12288);
 /* The table rule against the instruction itself over the float bit patterns [first, first + count) (fn 0 = rcpps, 1 = rsqrtps), on
  * `threads` host threads: *mismatches = inputs whose result bits differ, *firstBad = the lowest of them.  No device needed. */
 int snail_host_sse_check(int fn, uint64_t first, uint64_t count, int threads, uint64_t *mismatches, uint32_t *firstBad);

@@ -25,6 +25,11 @@ struct Tables {
 };
 Tables g_tables;
 std::once_flag g_once;
+// tables of ANOTHER CPU, given by the caller (hostSseSetTables): what hostSseTables() returns while set
+Tables g_given;
+std::mutex g_givenMu;
+bool g_haveGiven = false;
+unsigned g_generation = 1;
 
 void buildTables() {
 	Tables &T = g_tables;
@@ -75,9 +80,39 @@ template <class F> void parallelFor(unsigned long long n, int threads, F fn) {
 } // namespace
 
 const unsigned *hostSseTables(const char **why) {
+	{
+		std::lock_guard<std::mutex> lock(g_givenMu);
+		if(g_haveGiven) { if(why) *why = ""; return g_given.tab; }
+	}
 	std::call_once(g_once, buildTables);
 	if(why) *why = g_tables.why;
 	return g_tables.ok ? g_tables.tab : nullptr;
+}
+
+unsigned hostSseGeneration() {
+	std::lock_guard<std::mutex> lock(g_givenMu);
+	return g_generation;
+}
+
+int hostSseSetTables(const unsigned *tab, const char **why) {
+	std::lock_guard<std::mutex> lock(g_givenMu);
+	if(why) *why = "";
+	if(tab) {
+		// what the rule of host_sse.h assumes of a table: every entry in (0.5, 1] (sign clear, biased exponent 126, or 127 with a zero mantissa for an
+		// exact 1.0) and non-increasing with the index (1 / x and 1 / sqrt(x) fall)
+		for(int f = 0; f < 3; f++)
+			for(int i = 0; i < kHostSseEntries; i++) {
+				const unsigned v = tab[f * kHostSseEntries + i], e = v >> 23;
+				if(!(e == 126u || v == 0x3f800000u) || (i && v > tab[f * kHostSseEntries + i - 1])) {
+					if(why) *why = "entries must lie in (0.5, 1] and must not increase with the index";
+					return 1;
+				}
+			}
+		memcpy(g_given.tab, tab, sizeof g_given.tab);
+		g_haveGiven = true;
+	} else g_haveGiven = false;
+	g_generation++;
+	return 0;
 }
 
 unsigned long long hostSseMismatches(int fn, unsigned long long first, unsigned long long count, int threads, unsigned *firstBad) {

@@ -191,16 +191,18 @@ dev::GenConst makeGen(const float cam[13], int w, int h) {
 // Host-SSE arithmetic (host_sse.h): this CPU's rcpps / rsqrtps tables into the CURRENT device's copy of dev_sse::g_hostTab, once per device.
 int hostSseUpload(const char *fn) {
 	static std::mutex mu;
-	static bool done[64] = {};
+	static unsigned done[64] = {};   // per device: the generation of the tables it holds (0 = none)
 	const char *why = "";
+	const unsigned gen = hostSseGeneration();
 	const unsigned *tab = hostSseTables(&why);
 	if(!tab) { snail_set_error("%s: SNAIL_ARITH_HOST_SSE is not available on this host: %s", fn, why); return 2; }
 	int devId = 0;
 	HIP_TRY(hipGetDevice(&devId));
 	std::lock_guard<std::mutex> lock(mu);
-	if(devId >= 0 && devId < 64 && done[devId]) return 0;
+	if(devId >= 0 && devId < 64 && done[devId] == gen) return 0;
+	HIP_TRY(hipDeviceSynchronize());   // (tables are replaced between frames, not under them: snail_arith_set_tables)
 	HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(dev_sse::g_hostTab), tab, sizeof(unsigned) * 3 * kHostSseEntries, 0, hipMemcpyHostToDevice));
-	if(devId >= 0 && devId < 64) done[devId] = true;
+	if(devId >= 0 && devId < 64) done[devId] = gen;
 	return 0;
 }
 
@@ -730,6 +732,11 @@ int snail_scene_set_arith(SnailScene *s, int arith) {
 int snail_scene_arith(const SnailScene *s, int *arith) {
 	if(int rc = checkScene(s, "snail_scene_arith")) return rc;
 	if(arith) *arith = s->arith;
+	return 0;
+}
+int snail_arith_set_tables(const uint32_t *tables12288) {
+	const char *why = "";
+	if(hostSseSetTables(tables12288, &why)) { snail_set_error("snail_arith_set_tables: %s", why); return 1; }
 	return 0;
 }
 int snail_host_sse_tables(uint32_t *tables12288) {

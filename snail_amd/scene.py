@@ -84,6 +84,24 @@ class ShadowContext:
         return self.dir.shape[0] // self.size
 
 
+def host_sse_tables() -> np.ndarray:
+    """The rcpps / rsqrtps tables in force for SNAIL_ARITH_HOST_SSE: uint32[3, 4096] (snail_host_sse_tables) -- this host CPU's unless
+    set_arith_tables() gave others."""
+    tab = np.zeros((3, 4096), dtype=np.uint32)
+    _lib.check(_lib.lib().snail_host_sse_tables(_lib.ptr(tab)), "snail_host_sse_tables")
+    return tab
+
+
+def set_arith_tables(tables) -> None:
+    """Tables of another CPU for SNAIL_ARITH_HOST_SSE (uint32[3, 4096]; None = this host's again): process-wide, in force for a scene from its next
+    set_arith("host_sse") on (snail_arith_set_tables)."""
+    if tables is None:
+        _lib.check(_lib.lib().snail_arith_set_tables(None), "snail_arith_set_tables")
+        return
+    tab = np.ascontiguousarray(tables, dtype=np.uint32).reshape(3 * 4096)
+    _lib.check(_lib.lib().snail_arith_set_tables(_lib.ptr(tab)), "snail_arith_set_tables")
+
+
 class Scene:
     """A BVH resident in one GPU's HBM (the reference ships the same arrays to a render node in
     SendBVH, src/server.cpp:144-164)."""

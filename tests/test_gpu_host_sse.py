@@ -211,3 +211,63 @@ def test_batched_ordered_launches_in_host_sse(torch_mod):
     for f in outs:
         compare_frames(f, ref, "batched host_sse")
     sc.close()
+
+
+def test_tables_of_another_cpu_reproduce_that_cpus_results(torch_mod):
+    """snail_arith_set_tables: SNAIL_ARITH_HOST_SSE with the tables of ANOTHER CPU (tests/golden/rcp_tables.npz: the build container's Xeon, on
+    which the survey ran the reference, and the pool's EPYC 9575F).  With the Xeon's tables, whatever this box's CPU is:
+      * box 256x256 from the survey's camera gives the numbers the survey RECORDED FROM THE REFERENCE ITSELF (SURVEY.md section 8c,
+        tests/golden/survey_digests.json): 45 369 hits, sum(triId) 204 078, sum(t) 114 934.835 -- a pin of the HIP path that does not pass
+        through the oracle;
+      * the bench's atrium frame hashes to the digest committed from the build container (the oracle in ORC_MODE_SSE on that Xeon).
+    Back on this host's own tables the frame hashes to this CPU's committed digest (if the file knows the CPU)."""
+    import hashlib
+    import json
+    from snail_amd import HostBVH, scenes, survey_camera
+    from snail_amd.scene import Scene, host_sse_tables, set_arith_tables
+    from tests.golden import full_size as FS
+    gold_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    tabs = np.load(os.path.join(gold_dir, "rcp_tables.npz"))
+    own = host_sse_tables()
+    own_key = hashlib.sha256(own.tobytes()).hexdigest()[:16]
+    sha = lambda t: hashlib.sha256(np.ascontiguousarray(t.cpu().numpy()).tobytes()).hexdigest()
+    full = json.load(open(os.path.join(gold_dir, "oracle_full_size.json")))["host_sse"]
+    try:
+        set_arith_tables(tabs["xeon_skylake_sp"])
+        assert np.array_equal(host_sse_tables(), tabs["xeon_skylake_sp"])
+        xeon_key = hashlib.sha256(np.ascontiguousarray(tabs["xeon_skylake_sp"]).tobytes()).hexdigest()[:16]
+        # (1) the survey's box digest, recorded from the reference on that CPU
+        d = json.load(open(os.path.join(gold_dir, "survey_digests.json")))["box"]
+        tv = scenes.box_scene()
+        sc = Scene(HostBVH.build(tv), 0)
+        sc.set_arith("host_sse")
+        fr = sc.trace_primary(survey_camera(tv), 256, 256)
+        torch_mod.cuda.synchronize()
+        t, tid = fr.t.cpu().numpy(), fr.tri_id.cpu().numpy()
+        hit = np.isfinite(t)
+        assert int(hit.sum()) == d["hits"] and int(tid[hit].astype(np.int64).sum()) == d["sum_id"], (int(hit.sum()), int(tid[hit].astype(np.int64).sum()))
+        assert abs(float(t[hit].astype(np.float64).sum()) - d["sum_t"]) < 0.0006
+        sc.close()
+        # (2) the bench's frame: the digest the build container committed for ITS CPU, reproduced here
+        tv, hb, _ = util.scene_pair("atrium")
+        sc = Scene(hb, 0)
+        sc.set_arith("host_sse")
+        cam = FS.bench_camera("atrium")
+        want = full[xeon_key]["atrium_1920x1080_c1"]
+        fr = sc.trace_primary(cam, 1920, 1080)
+        assert (sha(fr.t), sha(fr.u), sha(fr.v), sha(fr.tri_id)) == (want["sha_t"], want["sha_u"], want["sha_v"], want["sha_id"])
+        # back to this host's tables: in force from the next set_arith on
+        set_arith_tables(None)
+        assert np.array_equal(host_sse_tables(), own)
+        sc.set_arith("host_sse")
+        fr = sc.trace_primary(cam, 1920, 1080)
+        if own_key in full:
+            want = full[own_key]["atrium_1920x1080_c1"]
+            assert (sha(fr.t), sha(fr.u), sha(fr.v), sha(fr.tri_id)) == (want["sha_t"], want["sha_u"], want["sha_v"], want["sha_id"])
+        if own_key != xeon_key:
+            assert sha(fr.t) != full[xeon_key]["atrium_1920x1080_c1"]["sha_t"]        # two CPUs, two sets of last bits
+        sc.close()
+        with pytest.raises(Exception, match="reciprocals|must lie"):
+            set_arith_tables(np.zeros((3, 4096), dtype=np.uint32))
+    finally:
+        set_arith_tables(None)

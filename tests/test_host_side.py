@@ -373,3 +373,33 @@ def test_host_sse_tables_reproduce_this_cpus_rcpps_and_rsqrtps():
         want = np.float32(np.float32(r + r) - np.float32(np.float32(np.float32(x) * r) * r))
         got = np.float32(O.lib().orc_inv(C.c_float(float(x)), O.MODE_SSE))
         assert got.view(np.uint32) == want.view(np.uint32), (x, got, want)
+
+
+def test_arith_tables_of_another_cpu_are_taken_and_given_back():
+    """snail_arith_set_tables (no GPU needed for the host side): the committed tables of the two CPUs seen so far are accepted and returned by
+    snail_host_sse_tables while in force, garbage is refused, NULL restores this host's own -- and the build container's own tables ARE the
+    committed `xeon_skylake_sp` set when it runs on that CPU (the survey's)."""
+    import ctypes as C
+    import numpy as np
+    from snail_amd._lib import check, lib
+    from snail_amd.scene import host_sse_tables, set_arith_tables
+    tabs = np.load(os.path.join(ROOT, "tests", "golden", "rcp_tables.npz"))
+    own = host_sse_tables()
+    try:
+        for name in ("xeon_skylake_sp", "epyc_9575f"):
+            set_arith_tables(tabs[name])
+            assert np.array_equal(host_sse_tables(), tabs[name])
+            bad = C.c_uint64(0)
+            check(lib().snail_host_sse_check(0, 0x3f800000, 1 << 23, 2, C.byref(bad), None), "snail_host_sse_check")
+            assert (bad.value == 0) == np.array_equal(tabs[name][0], own[0])     # the check keeps comparing with THIS host's instruction
+        for garbage in (np.zeros((3, 4096), dtype=np.uint32), own[:, ::-1].copy()):
+            with pytest.raises(Exception, match="must lie"):
+                set_arith_tables(garbage)
+        assert np.array_equal(host_sse_tables(), tabs["epyc_9575f"])             # a refused call changes nothing
+    finally:
+        set_arith_tables(None)
+    assert np.array_equal(host_sse_tables(), own)
+    with open("/proc/cpuinfo") as f:
+        model = next((l for l in f if l.startswith("model name")), "")
+    if "Xeon(R) Processor @ 2.10GHz" in model:
+        assert np.array_equal(own, tabs["xeon_skylake_sp"])
