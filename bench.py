@@ -261,6 +261,7 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="start the ranks, rendezvous, one all-reduce over the chosen backend, print {dry_run, ranks} and exit: checks the launch path without a GPU (with --backend gloo)")
     ap.add_argument("--reflections", action="store_true", help="config 3 only: + the one mirrored bounce of gVals[7] (Scene::TraceReflection: mirrored packets with per-ray origins through the same RayTrace)")
     ap.add_argument("--arith", default="ieee", choices=["ieee", "host_sse"], help="arithmetic of the path's approximate operations (include/snail_hip.h): ieee = veclib's scalar definitions; host_sse = veclib's SSE definitions as this host's CPU executes them (rcpps / rsqrtps reproduced on the device + Newton), i.e. the reference's x86 results bit for bit")
+    ap.add_argument("--arith-tables", default=None, help="with --arith host_sse: compute with the committed rcpps / rsqrtps tables of a NAMED CPU (tests/golden/rcp_tables.npz: xeon_skylake_sp, epyc_9575f) instead of this host's own -- the same bits on any host (snail_arith_set_tables)")
     ap.add_argument("--order-refresh", type=int, default=16, help="frames of a slot between two derivations of its dispatch order while the camera moves (DistributedRenderer order_refresh)")
     args = ap.parse_args()
 
@@ -322,6 +323,11 @@ def main():
         from snail_amd import survey_camera
         cam = survey_camera(tv)
     scene = Scene(hbvh, local_rank)
+    if args.arith_tables:
+        if args.arith != "host_sse":
+            raise SystemExit("--arith-tables needs --arith host_sse")
+        from snail_amd.scene import set_arith_tables
+        set_arith_tables(np.load(os.path.join(ROOT, "tests", "golden", "rcp_tables.npz"))[args.arith_tables])
     scene.set_arith(args.arith)
     resx, resy = cfg["res"] if (world == 1 or args.scaling == "strong") else weak_frame_size(world, cfg["res"])
     lights7 = None
@@ -578,7 +584,7 @@ def main():
             "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: gloo, ranks share one GPU -- not a measurement)",
             "config": {"workload": "BASELINE config %d: %s (%d tris%s) %dx%d %s" % (args.config, scene_name, hbvh.n_tris,
                                                                                      ", sponza.obj stand-in" if scene_name.startswith("atrium") else "", resx, resy, cfg["what"]),
-                       "baseline_config": args.config, "reflections": bool(args.reflections and cfg["lights"]), "arith": args.arith, "rays_per_step": total_rays, "primary_rays_per_step": primary_rays, "node_visits_per_step": node_visits,
+                       "baseline_config": args.config, "reflections": bool(args.reflections and cfg["lights"]), "arith": args.arith, "arith_tables": args.arith_tables or ("host CPU" if args.arith == "host_sse" else None), "rays_per_step": total_rays, "primary_rays_per_step": primary_rays, "node_visits_per_step": node_visits,
                        "packets": "16x16 px = 1 wavefront", "bvh_nodes": hbvh.n_nodes, "bvh_depth": hbvh.depth,
                        "bvh_build_s": round(build_s, 3), "hit_fraction": round(hit_frac, 5), "frames_in_flight": rnd.nslots * rnd.batch, "frames_per_launch": rnd.batch, "launches_in_flight": rnd.nslots,
                        "lone_launch_ms": round(lone_launch_ms, 5) if lone_launch_ms is not None else None,
