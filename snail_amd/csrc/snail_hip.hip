@@ -372,7 +372,10 @@ int launchPrimaryFrames(SnailScene *s, const FrameSet &FS, int resx, int resy, i
 		else SNAIL_LAUNCH(sse, PrimaryArgs, dim3(blocks), dim3(64), 0, stream, A, k_primary_diag<false>);
 	} else if(useDeep(s)) SNAIL_LAUNCH(sse, PrimaryArgs, grid, block, dynLds, stream, A, k_primary<true>);
 	else SNAIL_LAUNCH(sse, PrimaryArgs, grid, block, dynLds, stream, A, k_primary<false>);
-	if(useDeep(s)) SNAIL_LAUNCH(sse, PrimaryArgs, dim3(exactBlocks), dim3(64), 0, stream, A, k_primary_exact<true>);
+	// workbench build, SNAIL_DEBUG_NO_EXACT_PASS=1: what the dependent second launch costs (an experiment: deferred packets are then never traced)
+	static const bool noExact = debugEnvInt("SNAIL_DEBUG_NO_EXACT_PASS") != 0;
+	if(noExact) { }
+	else if(useDeep(s)) SNAIL_LAUNCH(sse, PrimaryArgs, dim3(exactBlocks), dim3(64), 0, stream, A, k_primary_exact<true>);
 	else SNAIL_LAUNCH(sse, PrimaryArgs, dim3(exactBlocks), dim3(64), 0, stream, A, k_primary_exact<false>);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(s->deferDone[slot], stream));
