@@ -92,15 +92,20 @@ def test_full_size_frame_bit_exact_in_host_sse(torch_mod, name):
     sc.close()
 
 
-@pytest.mark.parametrize("shared,masked,size", [(True, False, 64), (False, True, 64), (False, False, 23), (True, True, 16)])
-def test_generic_packets_bit_exact_in_host_sse(torch_mod, shared, masked, size):
+@pytest.mark.parametrize("shared,masked,size,poison", [(True, False, 64, False), (False, True, 64, False), (False, False, 23, False), (True, True, 16, False),
+                                                       (True, False, 64, True), (False, True, 64, True)])
+def test_generic_packets_bit_exact_in_host_sse(torch_mod, shared, masked, size, poison):
     """TraversePrimary<so,mask> with the caller's rays (dir / idir as the reference's SSE code hands them over): 1 / det of the accepted
     hits is the only approximate operation left, and it is the host's."""
     name = "atrium:0.05"
     tv, sc, osc = sse_scene(name)
     cam = util.camera_for(name, tv)
     npk = 24
-    origin, dirs, idir, mask, dist, obj, bary = util.secondary_packets(osc, cam, 640, 368, npk, seed=11 + size, shared=shared, masked=masked, size=size, coherent=size == 64)
+    origin, dirs, idir, mask, dist, obj, bary = util.secondary_packets(osc, cam, 640, 368, npk, seed=11 + size, shared=shared, masked=masked, size=size, coherent=size == 64,
+                                                                       poison=poison)
+    if poison:   # what the reference's SSE SafeInv hands over at its singularity: rcpps(0) = inf, and the Newton step makes it NaN (0 * inf) -> the M_EXACT kernels of dev_sse
+        idir[~np.isfinite(idir)] = np.nan
+        idir[3 * size + 1, 0:4] = np.nan
     d2, o2, b2 = dist.copy(), obj.copy(), bary.copy()
     st2 = osc.trace_rays(origin, dirs, idir, mask, d2, o2, b2, npk, size, shared, mode=O.MODE_SSE)
     d3, o3, b3 = dist.copy(), obj.copy(), bary.copy()
