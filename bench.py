@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- the measurement contract of this repo.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1|3|4|5] [--scaling strong|weak] [--rank0-share F] [--camera-path static|orbit]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1|3|4|5] [--reflections] [--arith auto|host_sse|ieee] [--scaling strong|weak] [--rank0-share F]
+                  [--camera-path static|orbit|dolly]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 Both forms work for N > 1: started WITHOUT torch.distributed.run (no WORLD_SIZE in the environment), `bench.py --gpus N` starts its own N ranks
 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a CHILD
@@ -28,11 +29,18 @@ a render node returns in the reference (src/node.cpp:336-349) -- which scatters 
 are inside the timed region.  `--rank0-share F` = the fraction of a fair tile share rank 0 renders itself (the reference's server
 renders nothing: 0).  `--scaling weak` = the round-1 mode: N x the pixels at N GPUs (both axes x sqrt N).
 
+Arithmetic: the reference's x86 build computes Inv / RSqrt / FastInv with rcpps / rsqrtps + one Newton step (veclib/sse/base.h:84-92), and north_star's
+parity bar is against THAT path.  `--arith auto` (default) therefore runs the kernels in SNAIL_ARITH_HOST_SSE -- the host CPU's two instructions reproduced on
+the device from verified tables, results equal to the reference's SSE path bit for bit -- and falls back to veclib's scalar definitions (SNAIL_ARITH_IEEE,
+host-independent results, ~2 % faster) only on a host whose instructions cannot be tabulated; `config.arith` says which ran, `roofline.other_arith` carries
+the other arithmetic's rate for the same K steps (N = 1), and `verified` = the timed region's output hashed equal to the committed digest of the oracle's frame.
+
 Mrays = rays launched (every lane of every traced packet, hit or miss), as TreeStats::TracingRays counts them
 (src/scene_trace.cpp:116-117): frames are padded to whole 16x16 packets (1920x1080 -> 1920x1088); config 3 adds the shadow
 lanes with N.L > 0 (:554-557).
 
-Before the W warm-up steps the pipeline runs untimed for `--settle-ms` (default 30 ms, ~350 frames; reported as config.settle_ms / settle_frames): from an
+Before the W warm-up steps the pipeline runs untimed for `--settle-ms` (default 30 ms; the frame count is measured per workload by a probe and reported as
+config.settle_frames / settle_measured_ms): from an
 idle start the part's shader clock ramps for tens of milliseconds (profiles/README.md), and a short timed region would measure that ramp.  W warm-up
 steps, the barrier + synchronize, and EXACTLY K timed steps follow as the contract says.
 
@@ -260,7 +268,7 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=30.0, help="untimed frames for this many milliseconds BEFORE the W warm-up steps: the part's clocks ramp for tens of ms after an idle start (2.09 -> 1.91 -> 2.2 GHz over the first 600 frames, profiles/README.md), which a 20-step timed region would otherwise measure instead of the kernel; 0 = off; reported as config.settle_ms")
     ap.add_argument("--dry-run", action="store_true", help="start the ranks, rendezvous, one all-reduce over the chosen backend, print {dry_run, ranks} and exit: checks the launch path without a GPU (with --backend gloo)")
     ap.add_argument("--reflections", action="store_true", help="config 3 only: + the one mirrored bounce of gVals[7] (Scene::TraceReflection: mirrored packets with per-ray origins through the same RayTrace)")
-    ap.add_argument("--arith", default="ieee", choices=["ieee", "host_sse"], help="arithmetic of the path's approximate operations (include/snail_hip.h): ieee = veclib's scalar definitions; host_sse = veclib's SSE definitions as this host's CPU executes them (rcpps / rsqrtps reproduced on the device + Newton), i.e. the reference's x86 results bit for bit")
+    ap.add_argument("--arith", default="auto", choices=["auto", "ieee", "host_sse"], help="arithmetic of the path's approximate operations (include/snail_hip.h): host_sse = veclib's SSE definitions as this host's CPU executes them (rcpps / rsqrtps reproduced on the device + Newton), i.e. the reference's x86 results bit for bit -- the arithmetic north_star's parity bar is about; ieee = veclib's scalar definitions (host-independent results, ~2 %% faster); auto (default) = host_sse, or ieee on a host whose instructions cannot be tabulated (config.arith says which ran)")
     ap.add_argument("--arith-tables", default=None, help="with --arith host_sse: compute with the committed rcpps / rsqrtps tables of a NAMED CPU (tests/golden/rcp_tables.npz: xeon_skylake_sp, epyc_9575f) instead of this host's own -- the same bits on any host (snail_arith_set_tables)")
     ap.add_argument("--order-refresh", type=int, default=16, help="frames of a slot between two derivations of its dispatch order while the camera moves (DistributedRenderer order_refresh)")
     args = ap.parse_args()
@@ -323,11 +331,20 @@ def main():
         from snail_amd import survey_camera
         cam = survey_camera(tv)
     scene = Scene(hbvh, local_rank)
+    arith_note = None
     if args.arith_tables:
-        if args.arith != "host_sse":
+        if args.arith == "ieee":
             raise SystemExit("--arith-tables needs --arith host_sse")
+        args.arith = "host_sse"
         from snail_amd.scene import set_arith_tables
         set_arith_tables(np.load(os.path.join(ROOT, "tests", "golden", "rcp_tables.npz"))[args.arith_tables])
+    if args.arith == "auto":      # the reference's own arithmetic where this host's CPU can be reproduced (every x86 CPU seen so far), veclib's scalar one otherwise
+        from snail_amd._lib import SnailError
+        try:
+            scene.set_arith("host_sse")
+            args.arith = "host_sse"
+        except SnailError as e:
+            args.arith, arith_note = "ieee", "host_sse is not available here: %s" % e
     scene.set_arith(args.arith)
     resx, resy = cfg["res"] if (world == 1 or args.scaling == "strong") else weak_frame_size(world, cfg["res"])
     lights7 = None
@@ -584,7 +601,7 @@ def main():
             "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: gloo, ranks share one GPU -- not a measurement)",
             "config": {"workload": "BASELINE config %d: %s (%d tris%s) %dx%d %s" % (args.config, scene_name, hbvh.n_tris,
                                                                                      ", sponza.obj stand-in" if scene_name.startswith("atrium") else "", resx, resy, cfg["what"]),
-                       "baseline_config": args.config, "reflections": bool(args.reflections and cfg["lights"]), "arith": args.arith, "arith_tables": args.arith_tables or ("host CPU" if args.arith == "host_sse" else None), "rays_per_step": total_rays, "primary_rays_per_step": primary_rays, "node_visits_per_step": node_visits,
+                       "baseline_config": args.config, "reflections": bool(args.reflections and cfg["lights"]), "arith": args.arith, "arith_note": arith_note, "arith_tables": args.arith_tables or ("host CPU" if args.arith == "host_sse" else None), "rays_per_step": total_rays, "primary_rays_per_step": primary_rays, "node_visits_per_step": node_visits,
                        "packets": "16x16 px = 1 wavefront", "bvh_nodes": hbvh.n_nodes, "bvh_depth": hbvh.depth,
                        "bvh_build_s": round(build_s, 3), "hit_fraction": round(hit_frac, 5), "frames_in_flight": rnd.nslots * rnd.batch, "frames_per_launch": rnd.batch, "launches_in_flight": rnd.nslots,
                        "lone_launch_ms": round(lone_launch_ms, 5) if lone_launch_ms is not None else None,

@@ -780,7 +780,7 @@ def test_depth_shading_and_tile_pipeline(torch_mod):
 
 @pytest.mark.parametrize("extra,scaling,res", [([], "strong", (1920, 1080)), (["--rank0-share", "0.25"], "strong", (1920, 1080)),
                                                (["--scaling", "weak"], "weak", (2720, 1528)), (["--config", "3"], "strong", (1920, 1080)),
-                                               (["--frames-per-launch", "1"], "strong", (1920, 1080)), (["FULL"], "strong", (1920, 1080)),
+                                               (["--frames-per-launch", "1"], "strong", (1920, 1080)), (["FULL", "--arith", "ieee"], "strong", (1920, 1080)),
                                                (["FULL", "--config", "3"], "strong", (1920, 1080))])
 def test_two_rank_bench_rehearsal(torch_mod, extra, scaling, res):
     """The N>1 flow of bench.py end to end with two ranks sharing this GPU (gloo, payload staged through the host --
@@ -796,7 +796,7 @@ def test_two_rank_bench_rehearsal(torch_mod, extra, scaling, res):
     extra = [e for e in extra if e != "FULL"]
     tail = ["--gpus", "2", "--steps", "6", "--warmup", "2", "--backend", "gloo"] + ([] if full else ["--scene", "atrium:0.05"]) + extra
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    if extra in ([], ["--frames-per-launch", "1"]):
+    if extra in ([], ["--frames-per-launch", "1"], ["--arith", "ieee"]):
         # the PLAIN command, as the driver's scaling run issues it: bench.py starts its own two ranks (a child torch.distributed.run)
         cmd = [sys.executable, os.path.join(root, "bench.py")] + tail
     else:
@@ -828,8 +828,9 @@ def test_two_rank_bench_rehearsal(torch_mod, extra, scaling, res):
     assert c["raw_stream_switch"] in (True, False)
     g = c["gather_alone"]
     assert g["bytes_per_collective"] == c["frames_per_launch"] * max(c["packets_per_rank"]) * 768 and g["ms"] > 0 and g["GBps"] > 0
-    if full:
-        assert d["verified"] is True, d["verification"]      # the gathered frame = the oracle's depth-shaded (config 3: lit) frame, by committed digest
+    if full:      # the gathered frame = the oracle's depth-shaded (config 3: lit) frame, by committed digest (host_sse: if the file knows this box's CPU)
+        assert d["verified"] is True or (d["config"]["arith"] == "host_sse" and d["verified"] is None), d["verification"]
+        assert d["config"]["arith"] == ("ieee" if "--arith" in extra else "host_sse")      # the default arithmetic is the reference's own
     else:
         assert d["verified"] is None and "no committed digest" in d["verification"]["note"]
 

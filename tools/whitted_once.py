@@ -1,5 +1,5 @@
 """A few frames of the staged light pipeline, one at a time (for PMC passes: tools/pmc_cmd.sh).
-usage: python3 tools/whitted_once.py [scene] [lights] [refl] -- absolute paths only under rocprofv3 (cwd is /tmp)"""
+usage: python3 tools/whitted_once.py [scene] [lights] [refl|norefl] [ieee|host_sse] -- absolute paths only under rocprofv3 (cwd is /tmp)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,6 +13,7 @@ tv = scenes.scene_by_name(name); h = HostBVH.build(tv)
 pos, ang, pitch = scenes.atrium_camera() if name.startswith("atrium") else scenes.stress_camera()
 cam = FPSCamera(pos, ang, pitch).camera()
 sc = Scene(h, 0)
+sc.set_arith(sys.argv[4] if len(sys.argv) > 4 else "ieee")
 bmin, bmax = h.bbox(); c, e = (bmin + bmax) * 0.5, (bmax - bmin)
 lights = np.array([[c[0], c[1] + 0.35 * e[1], c[2], 1.0, 0.9, 0.8, 2.0 * float(e.max())]], dtype=np.float32)[:nl]   # bench.py --config 3's light
 st = sc.new_stats()
