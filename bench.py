@@ -526,7 +526,7 @@ def main():
             scene.set_arith(other_name)
             r2 = DistributedRenderer(scene, resx, resy, 0, 1, slots=args.streams if args.streams > 0 else None, feedback_order=bool(args.feedback_order), lights7=lights7,
                                      reflections=bool(args.reflections and cfg["lights"]), frames_per_launch=rnd.batch, order_refresh=args.order_refresh)
-            for i in range(max(8 * rnd.batch, min(args.warmup, 100) // rnd.batch * rnd.batch)):
+            for i in range(max(8 * rnd.batch, (settle_frames + args.warmup) // rnd.batch * rnd.batch)):      # the same settle + warm-up as the timed region had
                 r2.render(cam_at(i))
             r2.flush()
             torch.cuda.synchronize()
