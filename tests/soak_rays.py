@@ -1,6 +1,7 @@
 """Seeded soak of the generic entry points (not collected by pytest): random batches of secondary packets (shared / per-ray origins,
 lane masks, packet sizes 1..64, optional non-finite poison -> M_EXACT deferral) and shadow packets, GPU against the oracle bit for bit.
-Usage: python tests/soak_rays.py [batches] [seed] [focus]   (focus = "perray": per-ray-origin masked packet batches only, "perray1": those with 1..3 quads per packet; differences are printed)"""
+Usage: python tests/soak_rays.py [batches] [seed] [focus]   (focus = "perray": per-ray-origin masked packet batches only, "perray1": those with 1..3 quads per packet; differences are printed;
+"sse": every batch in SNAIL_ARITH_HOST_SSE against ORC_MODE_SSE -- the caller's rays as they are, 1 / det of the accepted hits in the host's arithmetic)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -16,6 +17,8 @@ scn = {}
 for n in names:
     tv, hb, osc = util.scene_pair(n)
     scn[n] = (tv, Scene(hb, 0), osc, util.camera_for(n, tv))
+    if focus == "sse": scn[n][1].set_arith("host_sse")
+MODE = O.MODE_SSE if focus == "sse" else O.MODE_IEEE
 tt = torch.from_numpy
 L_ = O.lib(); L_.orc_caller_mxcsr.restype = __import__("ctypes").c_uint
 print("caller MXCSR 0x%04x (0x1f80 = default); float32 denormals in numpy: %s" % (L_.orc_caller_mxcsr(), "kept" if float(np.float32(1e-40) * np.float32(0.5)) != 0.0 else "FLUSHED"), flush=True)
@@ -33,7 +36,7 @@ for b in range(batches):
         origin, dirs, idir, mask, dist, obj, bary = util.secondary_packets(osc, cam, 640, 368, npk, seed=int(rng.randint(1 << 30)), shared=shared, masked=masked,
                                                                            size=size, poison=poison)
         d2, o2, b2 = dist.copy(), obj.copy(), bary.copy()
-        ost = osc.trace_rays(origin, dirs, idir, mask, d2, o2, b2, npk, size, shared, mode=O.MODE_IEEE)
+        ost = osc.trace_rays(origin, dirs, idir, mask, d2, o2, b2, npk, size, shared, mode=MODE)
         ctx = Context(tt(origin).cuda(), tt(dirs).cuda(), tt(idir).cuda(), tt(dist.copy()).cuda(), tt(obj.copy()).cuda(), tt(bary.copy()).cuda(),
                       size=size, shared_origin=shared, mask=None if mask is None else tt(mask).cuda())
         st = sc.new_stats(); sc.traverse_primary(ctx, stats=st); torch.cuda.synchronize()
@@ -53,7 +56,7 @@ for b in range(batches):
     else:
         origin, dirs, idir, dist = util.shadow_packets(osc, npk, seed=int(rng.randint(1 << 30)), size=size)
         d2 = dist.copy()
-        ost = osc.trace_shadow(origin, dirs, idir, d2, npk, size, mode=O.MODE_IEEE)
+        ost = osc.trace_shadow(origin, dirs, idir, d2, npk, size, mode=MODE)
         ctx = ShadowContext(tt(origin).cuda(), tt(dirs).cuda(), tt(idir).cuda(), tt(dist.copy()).cuda(), size=size)
         st = sc.new_stats(); sc.traverse_shadow(ctx, stats=st); torch.cuda.synchronize()
         s = st.cpu().numpy().astype(np.uint64)
