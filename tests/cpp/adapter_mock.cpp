@@ -120,6 +120,10 @@ int main(int argc, char **argv) {
 	}
 	snail::HipBVH<MockBVH> &acc = scene.geometry;
 	acc.Upload(bvh, 0);
+	// meta[8] != 0: the arithmetic the reference's SSE build executes on this host ("Arithmetic"): every expectation of the
+	// test then comes from the oracle's ORC_MODE_SSE, which runs this CPU's rcpps / rsqrtps
+	const bool hostSse = meta.size() > 8 && meta[8] != 0;
+	if(hostSse && !acc.SetArith(SNAIL_ARITH_HOST_SSE)) { std::fprintf(stderr, "SetArith(HOST_SSE): %s\n", snail_last_error()); return 3; }
 	FILE *fs = std::fopen((d + "stats.txt").c_str(), "w");
 
 	{ // ---- prefetched primary path ----
@@ -195,6 +199,7 @@ int main(int argc, char **argv) {
 			Scene<snail::HipBVH<MockBVH>> scene3;
 			scene3.lights = scene.lights; scene3.ambientLight = scene.ambientLight;
 			scene3.geometry.Upload(bvh, std::vector<int>{0, 0, 0});
+			if(hostSse && !scene3.geometry.SetArith(SNAIL_ARITH_HOST_SSE)) return 3;
 			std::vector<unsigned char> data3(total, 0xAB);
 			const TreeStats s3 = Render(scene3, cam, (uint)resx, (uint)resy, data3.data(), coords, offsets, Options(), 0u, 4u);
 			const bool same = data3 == data && s3.in == st.in && s3.it == st.it && s3.rays == st.rays && s3.sk == st.sk;

@@ -573,13 +573,15 @@ def test_gpu_against_committed_fixtures(torch_mod):
     sc.close()
 
 
-@pytest.mark.parametrize("refl,depth_mode", [(False, False), (True, False), (False, True)])
-def test_cpp_adapter_end_to_end(torch_mod, tmp_path, refl, depth_mode):
+@pytest.mark.parametrize("refl,depth_mode,host_sse", [(False, False, False), (True, False, False), (False, True, False), (True, False, True), (False, True, True)])
+def test_cpp_adapter_end_to_end(torch_mod, tmp_path, refl, depth_mode, host_sse):
     """A C++ host in the reference's shape (tests/cpp/adapter_mock.cpp over include/snail_adapter.hpp, mock types with the reference's
     member names) gets the oracle's bytes from every path of the adapter: the prefetched primary path (HipBVH::BeginFrame + per-packet
     TraversePrimary(Context<1,0>) copies, frame TreeStats delivered), the immediate path (TraverseShadow, TraversePrimary(Context<0,1>)),
     the batched path (ShadowBatch, RayBatch), and the two Render(...) overloads with the reference's signatures (src/render.h:16-23):
-    tile list -> planar R, G-R, B-R bytes at data + offsets[k] and image -> rgb8, with the TreeStats they return."""
+    tile list -> planar R, G-R, B-R bytes at data + offsets[k] and image -> rgb8, with the TreeStats they return.  host_sse: the same after
+    HipBVH::SetArith(SNAIL_ARITH_HOST_SSE), every expectation from the oracle's ORC_MODE_SSE."""
+    MODE = O.MODE_SSE if host_sse else O.MODE_IEEE
     import subprocess
     from snail_amd import render as R
     from tests.test_host_side import build_adapter_mock
@@ -606,7 +608,7 @@ def test_cpp_adapter_end_to_end(torch_mod, tmp_path, refl, depth_mode):
     tiles = plan.tiles[plan.owner == 1]                      # one rank's tiles, as a render node receives them
     offsets = (np.arange(len(tiles), dtype=np.int32)[::-1].copy()) * (3 * 16 * 64)      # any layout of the per-tile buffers: here reversed
     tiles.astype(np.int32).tofile(str(d / "tiles.bin")); offsets.tofile(str(d / "offsets.bin"))
-    np.array([hb.depth, resx, resy, n_sh, n_ry, int(refl), int(depth_mode)], dtype=np.int32).tofile(str(d / "meta.bin"))
+    np.array([hb.depth, resx, resy, n_sh, n_ry, int(refl), int(depth_mode), 0, int(host_sse)], dtype=np.int32).tofile(str(d / "meta.bin"))
     exe = build_adapter_mock(tmp_path)
     r = subprocess.run([exe, str(d)], capture_output=True, text=True)
     assert r.returncode == 0 and "adapter ok" in r.stdout, r.stdout + r.stderr
@@ -615,20 +617,20 @@ def test_cpp_adapter_end_to_end(torch_mod, tmp_path, refl, depth_mode):
     raw = np.fromfile(str(d / "out_primary.bin"), dtype=np.uint8)
     t = raw[:resx * resy * 4].view(np.float32).reshape(resy, resx)
     tid = raw[resx * resy * 4:].view(np.int32).reshape(resy, resx)
-    ref = osc.render_primary(cam.as_array13(), resx, resy, mode=O.MODE_IEEE)
+    ref = osc.render_primary(cam.as_array13(), resx, resy, mode=MODE)
     util.assert_bit_equal(t, ref[0], "adapter t"); util.assert_bit_equal(tid, ref[3], "adapter triId")
     assert stats["primary"][:2] == [int(ref[4][0]), int(ref[4][1])]
     # shadow packets: immediate (packet 0) and batched (all)
     want = sdist.copy()
-    wst = osc.trace_shadow(so, sd, si, want, n_sh, 64)
+    wst = osc.trace_shadow(so, sd, si, want, n_sh, 64, mode=MODE)
     util.assert_bit_equal(np.fromfile(str(d / "out_sh_batch.bin"), dtype=np.float32).reshape(-1, 4), want, "shadow batch")
     util.assert_bit_equal(np.fromfile(str(d / "out_sh_imm.bin"), dtype=np.float32).reshape(-1, 4), want[:64], "shadow immediate")
     assert stats["shadow_batch"] == [int(wst[0]), int(wst[1]), 0, int(wst[3])]
-    w0 = sdist[:64].copy(); st0 = osc.trace_shadow(so[:1], sd[:64], si[:64], w0, 1, 64)
+    w0 = sdist[:64].copy(); st0 = osc.trace_shadow(so[:1], sd[:64], si[:64], w0, 1, 64, mode=MODE)
     assert stats["shadow_imm"] == [int(st0[0]), int(st0[1]), 0, int(st0[3])]
     # secondary packets RayGroup<0,1>
     wd, wo, wb = rdist.copy(), robj.copy(), rbary.copy()
-    wst = osc.trace_rays(ro, rd, ri, rmask, wd, wo, wb, n_ry, 64, False)
+    wst = osc.trace_rays(ro, rd, ri, rmask, wd, wo, wb, n_ry, 64, False, mode=MODE)
     raw = np.fromfile(str(d / "out_ry_batch.bin"), dtype=np.uint8)
     nq = n_ry * 64
     util.assert_bit_equal(raw[:nq * 16].view(np.float32).reshape(-1, 4), wd, "rays batch dist")
@@ -640,10 +642,10 @@ def test_cpp_adapter_end_to_end(torch_mod, tmp_path, refl, depth_mode):
     util.assert_bit_equal(raw[64 * 16:64 * 32].view(np.int32).reshape(-1, 4), wo[:64], "rays immediate obj")
     # the tile API: planar bytes per tile and the rgb8 image, against the oracle's frame
     if depth_mode:
-        want_frame = O.shade_depth(ref[0]).reshape(resy, resx, 3)
+        want_frame = O.shade_depth(ref[0], mode=MODE).reshape(resy, resx, 3)
         wst = ref[4]
     else:
-        want_frame, wst = osc.render_whitted(cam.as_array13(), resx, resy, lights, mode=O.MODE_IEEE, reflections=refl)
+        want_frame, wst = osc.render_whitted(cam.as_array13(), resx, resy, lights, mode=MODE, reflections=refl)
     data = np.fromfile(str(d / "out_tiles.bin"), dtype=np.uint8)
     for k, wp in enumerate(O.planar_encode(want_frame, tiles)):
         assert np.array_equal(data[offsets[k]:offsets[k] + len(wp)], wp), ("tile", k)
@@ -657,7 +659,7 @@ def test_cpp_adapter_end_to_end(torch_mod, tmp_path, refl, depth_mode):
     if depth_mode:
         mine = np.zeros(4, dtype=np.uint64)
         for x, y, w, h in tiles.tolist():
-            mine += osc.render_primary(cam.as_array13(), resx, resy, rect=(x, y, w, h), mode=O.MODE_IEEE, threads=1)[4]
+            mine += osc.render_primary(cam.as_array13(), resx, resy, rect=(x, y, w, h), mode=MODE, threads=1)[4]
         assert stats["tiles"] == [int(mine[0]), int(mine[1]), int(mine[2]), int(mine[3])]
     else:
         assert 0 < stats["tiles"][1] < int(wst[1]) and stats["tiles"][2] >= len(R.tile_packets(tiles)) * 256
