@@ -1186,6 +1186,32 @@ def test_dev_entry_points_are_graph_capturable(torch_mod):
     torch_mod.cuda.synchronize()
     assert torch_mod.equal(fr.t, ref.t) and torch_mod.equal(fr.tri_id, ref.tri_id) and torch_mod.equal(fr.u, ref.u)
     assert torch_mod.equal(img, ref_img)
+    # round 4: the staged pipeline with its per-stage dispatch orders, the order kernel itself, and the host's SSE arithmetic, captured as well
+    n = sc.primary_slots(resx, resy)
+    cost = torch_mod.zeros((sc.WHITTED_STAGES, n), dtype=torch_mod.int32, device="cuda")
+    order = torch_mod.empty_like(cost)
+    sc.render_whitted(cam, resx, resy, lights, reflections=True, slot_cost=cost)
+    for k in range(sc.WHITTED_STAGES):
+        sc.order_from_cost(cost[k], order[k])
+    sc.set_arith("host_sse")
+    ref_sse = sc.render_whitted(cam, resx, resy, lights, reflections=True)
+    for _ in range(10):
+        sc.render_whitted(cam, resx, resy, lights, reflections=True, order=order, slot_cost=cost)
+    torch_mod.cuda.synchronize()
+    img2 = torch_mod.zeros_like(ref_img)
+    order2 = torch_mod.empty_like(order)
+    g2 = torch_mod.cuda.CUDAGraph()
+    with torch_mod.cuda.graph(g2):
+        sc.render_whitted(cam, resx, resy, lights, out=img2, reflections=True, order=order, slot_cost=cost)
+        for k in range(sc.WHITTED_STAGES):
+            sc.order_from_cost(cost[k], order2[k])
+    img2.fill_(0)
+    for _ in range(3):
+        g2.replay()
+    torch_mod.cuda.synchronize()
+    assert torch_mod.equal(img2, ref_sse) and not torch_mod.equal(ref_sse, ref_img)
+    for k in range(sc.WHITTED_STAGES):
+        assert torch_mod.equal(torch_mod.sort(order2[k]).values, torch_mod.arange(n, dtype=torch_mod.int32, device="cuda"))
     sc.close()
 
 
