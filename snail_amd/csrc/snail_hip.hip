@@ -242,7 +242,13 @@ int stackPack(const SnailScene *s) {
 
 // The node slots relative to `org` for a launch on `stream` (stream-ordered: filled on this stream on a miss; a later user on another stream
 // waits for the fill; a slot that is recycled waits for its last users).  *which = the cache entry, for relUsed() after the consumer's launch.
-int relFor(SnailScene *s, const float org[3], hipStream_t stream, const uint4 **out, int *which) {
+// `pend` given: a miss is not filled here but appended to *pend, and relFlush() fills all of a launch's misses with ONE kernel (the frames of a
+// multi-frame launch of a moving camera each have an origin of their own).
+struct RelPending {
+	dev::RelFillArgs fill;
+	int entry[SNAIL_MAX_BATCH];
+};
+int relFor(SnailScene *s, const float org[3], hipStream_t stream, const uint4 **out, int *which, RelPending *pend = nullptr) {
 	SnailScene::RelNodes *hit = nullptr, *victim = nullptr;
 	for(auto &e : s->rel) {
 		if(e.valid && memcmp(e.org, org, 12) == 0) { hit = &e; break; }
@@ -261,11 +267,26 @@ int relFor(SnailScene *s, const float org[3], hipStream_t stream, const uint4 **
 	HIP_TRY(hipStreamWaitEvent(stream, e.filled, 0));                                       // its previous fill (a fill whose launch never happened has no reader event)
 	for(int k = 0; k < e.nUsed; k++) HIP_TRY(hipStreamWaitEvent(stream, e.used[k], 0));   // its last readers, on whatever streams
 	e.nUsed = 0;
-	hipLaunchKernelGGL(dev::k_rel_nodes, dim3((unsigned)((nSlots + 255) / 256)), dim3(256), 0, stream, (const uint4 *)s->dPF, nSlots, org[0], org[1], org[2], e.d);
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipEventRecord(e.filled, stream));
+	if(pend && pend->fill.n < SNAIL_MAX_BATCH) {
+		const int k = pend->fill.n++;
+		memcpy(pend->fill.org[k], org, 12); pend->fill.dst[k] = e.d; pend->entry[k] = (int)(&e - s->rel);
+	} else {
+		hipLaunchKernelGGL(dev::k_rel_nodes, dim3((unsigned)((nSlots + 255) / 256)), dim3(256), 0, stream, (const uint4 *)s->dPF, nSlots, org[0], org[1], org[2], e.d);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipEventRecord(e.filled, stream));
+	}
 	memcpy(e.org, org, 12); e.valid = true; e.stamp = ++s->relClock;
 	*out = e.d; *which = (int)(&e - s->rel);
+	return 0;
+}
+// the pending fills of one launch, on its stream, before the launch that reads them
+int relFlush(SnailScene *s, RelPending &pend, hipStream_t stream) {
+	if(pend.fill.n == 0) return 0;
+	const int nSlots = s->nNodes + 1;
+	hipLaunchKernelGGL(dev::k_rel_nodes_multi, dim3((unsigned)((nSlots + 255) / 256)), dim3(256), 0, stream, (const uint4 *)s->dPF, nSlots, pend.fill);
+	HIP_TRY(hipGetLastError());
+	for(int k = 0; k < pend.fill.n; k++) HIP_TRY(hipEventRecord(s->rel[pend.entry[k]].filled, stream));
+	pend.fill.n = 0;
 	return 0;
 }
 // after the launch that reads entry `which` was enqueued on `stream`
@@ -340,9 +361,13 @@ int launchPrimaryFrames(SnailScene *s, const FrameSet &FS, int resx, int resy, i
 	A.order = dOrder; A.slotCost = dSlotCost;
 	// the frames' origin-relative node records (only the record-prefetching loop reads them: not the DEEP kernels' C++ walk); after every
 	// early return above, so that a fill is always followed by its reader's event (relUsed below)
-	if(A.pack && SNAIL_REL_NODES && SNAIL_NODE_PREFETCH && !useDeep(s))
+	if(A.pack && SNAIL_REL_NODES && SNAIL_NODE_PREFETCH && !useDeep(s)) {
+		RelPending pend;
+		pend.fill.n = 0;
 		for(int k = 0; k < FS.n; k++)
-			if(int rc = relFor(s, FS.cam[k], stream, &A.rel[k], &relWhich[k])) return rc;   // cam[0..2] = the camera position
+			if(int rc = relFor(s, FS.cam[k], stream, &A.rel[k], &relWhich[k], &pend)) return rc;   // cam[0..2] = the camera position
+		if(int rc = relFlush(s, pend, stream)) return rc;   // the launch's new origins (a moving camera: every frame's) in ONE pass over the records
+	}
 	const int gridBlocks = blocks * FS.n;
 	s->lastBlocks = gridBlocks; s->lastThreads = 64;
 	// deferred-packet list of this launch (re-allocated, synchronously, only when a larger launch than ever before arrives)
