@@ -505,7 +505,7 @@ def main():
     if rank == 0 and world == 1 and rnd.batch > 1 and args.lone_frames > 0:
         r1 = DistributedRenderer(scene, resx, resy, 0, 1, slots=args.streams if args.streams > 0 else None, feedback_order=bool(args.feedback_order),
                                  frames_per_launch=1, order_refresh=args.order_refresh)
-        for i in range(max(8, min(args.warmup, 100))):
+        for i in range(max(8, settle_frames + args.warmup)):      # the same settle + warm-up as the timed region had
             r1.render(cam_at(i))
         r1.flush()
         torch.cuda.synchronize()
