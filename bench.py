@@ -94,12 +94,13 @@ CONFIGS = {
 
 
 def kernel_source_sha16() -> str:
-    """Hash of the kernel sources the PMC counters of profiles/traffic.json were measured on (tools/make_traffic.py stores it beside them):
+    """Hash of the DEVICE sources and build inputs (the kernels: snail_dev.inc, included by snail_hip.hip once per arithmetic; the GPU builder; the
+    table rule the kernels share with the host; the Makefile's flags) the PMC counters of profiles/traffic.json were measured on (tools/make_traffic.py stores it beside them):
     a kernel edit without a fresh counter pass makes the bench line say `counters_stale: true` instead of pricing the new kernel with the
     old instruction count."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("snail_hip.hip", "snail_dev.inc", "lbvh.inc", "host_sse.h", "Makefile"):
+    for f in ("snail_dev.inc", "lbvh.inc", "host_sse.h", "Makefile"):
         with open(os.path.join(ROOT, "snail_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

@@ -280,12 +280,23 @@ int relFor(SnailScene *s, const float org[3], hipStream_t stream, const uint4 **
 	return 0;
 }
 // the pending fills of one launch, on its stream, before the launch that reads them
+// (an entry is marked valid when it is appended: should the fill never be enqueued -- an error between relFor and relFlush, or in it -- relDrop
+// takes the entries back, so that no later launch finds an array that was never written)
+void relDrop(SnailScene *s, RelPending &pend) {
+	for(int k = 0; k < pend.fill.n; k++) s->rel[pend.entry[k]].valid = false;
+	pend.fill.n = 0;
+}
 int relFlush(SnailScene *s, RelPending &pend, hipStream_t stream) {
 	if(pend.fill.n == 0) return 0;
 	const int nSlots = s->nNodes + 1;
 	hipLaunchKernelGGL(dev::k_rel_nodes_multi, dim3((unsigned)((nSlots + 255) / 256)), dim3(256), 0, stream, (const uint4 *)s->dPF, nSlots, pend.fill);
-	HIP_TRY(hipGetLastError());
-	for(int k = 0; k < pend.fill.n; k++) HIP_TRY(hipEventRecord(s->rel[pend.entry[k]].filled, stream));
+	hipError_t e = hipGetLastError();
+	for(int k = 0; k < pend.fill.n && e == hipSuccess; k++) e = hipEventRecord(s->rel[pend.entry[k]].filled, stream);
+	if(e != hipSuccess) {
+		relDrop(s, pend);
+		snail_set_error("origin-relative node records: %s", hipGetErrorString(e));
+		return 100 + (int)e;
+	}
 	pend.fill.n = 0;
 	return 0;
 }
@@ -365,7 +376,7 @@ int launchPrimaryFrames(SnailScene *s, const FrameSet &FS, int resx, int resy, i
 		RelPending pend;
 		pend.fill.n = 0;
 		for(int k = 0; k < FS.n; k++)
-			if(int rc = relFor(s, FS.cam[k], stream, &A.rel[k], &relWhich[k], &pend)) return rc;   // cam[0..2] = the camera position
+			if(int rc = relFor(s, FS.cam[k], stream, &A.rel[k], &relWhich[k], &pend)) { relDrop(s, pend); return rc; }   // cam[0..2] = the camera position
 		if(int rc = relFlush(s, pend, stream)) return rc;   // the launch's new origins (a moving camera: every frame's) in ONE pass over the records
 	}
 	const int gridBlocks = blocks * FS.n;

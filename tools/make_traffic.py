@@ -48,7 +48,7 @@ for a in sys.argv[1:]:
                             "every kernel of the frame summed" % (os.path.basename(f), frames)}
     print(key, d[key]["bytes_per_launch"], d[key]["valu_insts_per_launch"])
 h = hashlib.sha256()
-for f in ("snail_hip.hip", "snail_dev.inc", "lbvh.inc", "host_sse.h", "Makefile"):     # bench.py kernel_source_sha16(): the sources these counters were measured on
+for f in ("snail_dev.inc", "lbvh.inc", "host_sse.h", "Makefile"):     # bench.py kernel_source_sha16(): the sources these counters were measured on
     h.update(open(os.path.join(ROOT, "snail_amd", "csrc", f), "rb").read())
 d["_kernel_sha16"] = h.hexdigest()[:16]
 json.dump(d, open(path, "w"), indent=1)
