@@ -276,3 +276,30 @@ def test_tables_of_another_cpu_reproduce_that_cpus_results(torch_mod):
             set_arith_tables(np.zeros((3, 4096), dtype=np.uint32))
     finally:
         set_arith_tables(None)
+
+
+def test_gpu_built_tree_in_host_sse(torch_mod):
+    """The arithmetic is a property of the scene handle, whatever built its tree: a linear BVH built on the device (snail_scene_create_lbvh), walked
+    in the host's SSE arithmetic, against the oracle's walk of the SAME tree in ORC_MODE_SSE."""
+    from snail_amd.scene import Scene
+    name = "atrium:0.05"
+    tv, _, _ = util.scene_pair(name)
+    cam = util.camera_for(name, tv)
+    sc = Scene.from_lbvh(tv, 0, max_leaf_tris=4)
+    sc.set_arith("host_sse")
+    osc2 = O.OracleScene.__new__(O.OracleScene)
+    osc2.tris = np.ascontiguousarray(sc.bvh.tris.view(O.TRI_DTYPE)); osc2.nodes = np.ascontiguousarray(sc.bvh.nodes.view(O.NODE_DTYPE))
+    osc2.depth = sc.bvh.depth; osc2.perm = sc.perm
+    resx, resy = 320, 192
+    want = osc2.render_primary(cam.as_array13(), resx, resy, mode=O.MODE_SSE)
+    stats = sc.new_stats()
+    fr = sc.trace_primary(cam, resx, resy, stats=stats)
+    torch_mod.cuda.synchronize()
+    compare_frames(fr, want, "lbvh host_sse")
+    assert np.array_equal(stats.cpu().numpy().astype(np.uint64), want[4])
+    lights = lights_for(osc2, cam, 1)
+    wimg, wst = osc2.render_whitted(cam.as_array13(), resx, resy, lights, mode=O.MODE_SSE, reflections=True)
+    st = sc.new_stats()
+    img = sc.render_whitted(cam, resx, resy, lights, stats=st, reflections=True).cpu().numpy()
+    assert np.array_equal(img, wimg) and np.array_equal(st.cpu().numpy().astype(np.uint64), wst)
+    sc.close()
