@@ -212,6 +212,25 @@ def verify_outputs(rnd, scene_name, resx, resy, config, arith, lights):
     return res
 
 
+def have_digest(scene_name, resx, resy, config, arith) -> bool:
+    """Is there a committed digest for this workload in this arithmetic (host_sse: for the CPU tables in force)?  The same answer on every rank of a node."""
+    import ctypes as C
+    import hashlib
+    import numpy as np
+    from snail_amd import _lib
+    try:
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_full_size.json")))
+    except Exception:
+        return False
+    key = "%s_%dx%d_c%s" % (scene_name, resx, resy, config)
+    if arith == "ieee":
+        return key in gold.get("ieee", {})
+    tab = np.zeros(3 * 4096, dtype=np.uint32)
+    if _lib.lib().snail_host_sse_tables(tab.ctypes.data_as(C.c_void_p)) != 0:
+        return False
+    return key in gold.get("host_sse", {}).get(hashlib.sha256(tab.tobytes()).hexdigest()[:16], {})
+
+
 def weak_frame_size(n_gpus: int, res):
     """N x the pixels, same aspect, on the 16 x 64 tile grid (--scaling weak)."""
     s = math.sqrt(n_gpus)
@@ -270,7 +289,7 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="start the ranks, rendezvous, one all-reduce over the chosen backend, print {dry_run, ranks} and exit: checks the launch path without a GPU (with --backend gloo)")
     ap.add_argument("--reflections", action="store_true", help="config 3 only: + the one mirrored bounce of gVals[7] (Scene::TraceReflection: mirrored packets with per-ray origins through the same RayTrace)")
     ap.add_argument("--arith", default="auto", choices=["auto", "ieee", "host_sse"], help="arithmetic of the path's approximate operations (include/snail_hip.h): host_sse = veclib's SSE definitions as this host's CPU executes them (rcpps / rsqrtps reproduced on the device + Newton), i.e. the reference's x86 results bit for bit -- the arithmetic north_star's parity bar is about; ieee = veclib's scalar definitions (host-independent results, ~2 %% faster); auto (default) = host_sse, or ieee on a host whose instructions cannot be tabulated (config.arith says which ran)")
-    ap.add_argument("--arith-tables", default=None, help="with --arith host_sse: compute with the committed rcpps / rsqrtps tables of a NAMED CPU (tests/golden/rcp_tables.npz: xeon_skylake_sp, epyc_9575f) instead of this host's own -- the same bits on any host (snail_arith_set_tables)")
+    ap.add_argument("--arith-tables", default=None, help="with --arith host_sse: compute with the committed rcpps / rsqrtps tables of a NAMED CPU (tests/golden/rcp_tables.npz: xeon_skylake_sp, epyc_9575f; or a .npy file of uint32[3, 4096]) instead of this host's own -- the same bits on any host (snail_arith_set_tables)")
     ap.add_argument("--order-refresh", type=int, default=16, help="frames of a slot between two derivations of its dispatch order while the camera moves (DistributedRenderer order_refresh)")
     args = ap.parse_args()
 
@@ -338,7 +357,7 @@ def main():
             raise SystemExit("--arith-tables needs --arith host_sse")
         args.arith = "host_sse"
         from snail_amd.scene import set_arith_tables
-        set_arith_tables(np.load(os.path.join(ROOT, "tests", "golden", "rcp_tables.npz"))[args.arith_tables])
+        set_arith_tables(np.load(args.arith_tables) if args.arith_tables.endswith(".npy") else np.load(os.path.join(ROOT, "tests", "golden", "rcp_tables.npz"))[args.arith_tables])
     if args.arith == "auto":      # the reference's own arithmetic where this host's CPU can be reproduced (every x86 CPU seen so far), veclib's scalar one otherwise
         from snail_amd._lib import SnailError
         try:
@@ -442,10 +461,25 @@ def main():
             rnd.render(cam)
         rnd.flush()
         barrier()
+    vkey = "%d%s" % (args.config, "r" if (args.reflections and cfg["lights"]) else "")
     if rank == 0:
-        verify = verify_outputs(rnd, scene_name, resx, resy, "%d%s" % (args.config, "r" if (args.reflections and cfg["lights"]) else ""), args.arith, cfg["lights"])
+        verify = verify_outputs(rnd, scene_name, resx, resy, vkey, args.arith, cfg["lights"])
         verify["what"] = ("one more round of the fixed view through the timed renderer after the timed region (the timed frames each hold another view)" if len(path) > 1
                           else "the last frame each slot traced inside the timed region")
+    # host_sse on a CPU the digest file does not know (its results are that CPU's own): the SAME renderer, one more round of the fixed view in the IEEE
+    # arithmetic -- whose digests hold on any host -- so that a run on an unknown CPU is still checked end to end (every rank takes part: collectives pair up)
+    if args.arith == "host_sse" and not have_digest(scene_name, resx, resy, vkey, "host_sse") and have_digest(scene_name, resx, resy, vkey, "ieee"):
+        scene.set_arith("ieee")
+        for _ in range(rnd.nslots * rnd.batch):
+            rnd.render(cam)
+        rnd.flush()
+        barrier()
+        if rank == 0:
+            v2 = verify_outputs(rnd, scene_name, resx, resy, vkey, "ieee", cfg["lights"])
+            verify = {"verified": v2.get("verified"), "host_sse": verify, "ieee_round": v2,
+                      "what": "no committed host_sse digest for this CPU's rcpps / rsqrtps tables: one more round of the fixed view through the timed renderer in the IEEE arithmetic, "
+                              "whose digests hold on any host (the host_sse frame's digest is reported, unchecked, under `host_sse`)"}
+        scene.set_arith(args.arith)
     timed = [e for e in ev if e is not None]
     durs = []
     for e0, e1 in timed:

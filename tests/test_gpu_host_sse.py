@@ -303,3 +303,28 @@ def test_gpu_built_tree_in_host_sse(torch_mod):
     img = sc.render_whitted(cam, resx, resy, lights, stats=st, reflections=True).cpu().numpy()
     assert np.array_equal(img, wimg) and np.array_equal(st.cpu().numpy().astype(np.uint64), wst)
     sc.close()
+
+
+def test_bench_checks_itself_on_a_cpu_without_committed_digests(torch_mod, tmp_path):
+    """bench.py's `verified` on a host whose rcpps / rsqrtps tables the digest file does not know (simulated: the Xeon's tables with one entry replaced by
+    its neighbour's -- tables of no CPU): the host_sse frame has no digest to be held against, so the SAME renderer runs one more round in the IEEE
+    arithmetic, whose digests hold everywhere; `verified` comes from that round, the unchecked host_sse digest is reported beside it."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tabs = np.load(os.path.join(root, "tests", "golden", "rcp_tables.npz"))["xeon_skylake_sp"].copy()
+    tabs[0, 1001] = tabs[0, 1002]          # (the Xeon's entries come in equal pairs: 1000 = 1001 > 1002) still non-increasing, in (0.5, 1]
+    assert tabs[0, 1001] != tabs[0, 1000]
+    f = str(tmp_path / "nobody.npy")
+    np.save(f, tabs)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "8", "--warmup", "2", "--settle-ms", "0", "--no-cpu-baseline", "--lone-frames", "0",
+                        "--arith", "host_sse", "--arith-tables", f], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["arith"] == "host_sse" and d["verified"] is True, d["verification"]
+    v = d["verification"]
+    assert v["host_sse"]["verified"] is None and "no committed digest" in v["host_sse"]["note"]
+    assert v["ieee_round"]["verified"] is True and v["ieee_round"]["against"].endswith("ieee.atrium_1920x1080_c1")
+    assert v["host_sse"]["digest"]["sha_t"] != v["ieee_round"]["digest"]["sha_t"]
