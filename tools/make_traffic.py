@@ -22,9 +22,9 @@ for a in sys.argv[1:]:
         d[key] = {"bytes_per_launch": int(round((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)), "valu_insts_per_launch": int(round(v["SQ_INSTS_VALU"])),
                   "salu_insts_per_launch": int(round(v.get("SQ_INSTS_SALU", 0))), "smem_insts_per_launch": int(round(v.get("SQ_INSTS_SMEM", 0))),
                   "lanes_live_per_valu_inst": round(v["SQ_THREAD_CYCLES_VALU"] / v["SQ_INSTS_VALU"], 2) if "SQ_THREAD_CYCLES_VALU" in v else None,
-                  "fetch_size_kb": v["FETCH_SIZE"], "write_size_kb": v["WRITE_SIZE"], "kernel": "dev::k_primary",
+                  "fetch_size_kb": v["FETCH_SIZE"], "write_size_kb": v["WRITE_SIZE"], "kernel": "dev_sse::k_primary" if key.endswith("_sse") else "dev::k_primary",
                   "source": "profiles/%s: rocprofv3 --pmc FETCH_SIZE (%.1f KB per dispatch, doubled per the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md section HBM) + --pmc WRITE_SIZE (%.1f KB), "
-                            "separate passes with --kernel-trace only, mean over the dev::k_primary<false> dispatches (one frame each) of `python bench.py --steps 10 --warmup 2 --no-cpu-baseline --frames-per-launch 1` of this workload; "
+                            "separate passes with --kernel-trace only, mean over the k_primary<false> dispatches (one frame each) of `python bench.py --steps 10 --warmup 2 --no-cpu-baseline --frames-per-launch 1 --arith ieee|host_sse` of this workload; "
                             "SQ_INSTS_VALU from the sq1 pass" % (os.path.basename(f), v["FETCH_SIZE"], v["WRITE_SIZE"])}
     else:
         per = collections.defaultdict(dict)      # kernel -> counter -> per-frame total
