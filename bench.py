@@ -207,9 +207,61 @@ def verify_outputs(rnd, scene_name, resx, resy, config, arith, lights):
     if want is None:
         res["note"] = "no committed digest for %s in section %s" % (key, where)
         return res
-    res["verified"] = bool(same and all(want.get(k) == v for k, v in got.items()))
+    res["committed"] = bool(all(want.get(k) == v for k, v in got.items()))
+    res["verified"] = bool(same and res["committed"])
     res["against"] = "tests/golden/oracle_full_size.json %s.%s" % (where, key)
     return res
+
+
+def live_oracle_check(verify, tv, cam, resx, resy, arith, tables_given, lights7, reflections, scalar_sse_digest=None):
+    """The timed arithmetic checked LIVE (rank 0, outside the timed region; the second place bench.py touches oracle/, again as the checker): the
+    oracle renders this workload's frame here and now -- ORC_MODE_IEEE; ORC_MODE_SSE = this CPU's own rcpps / rsqrtps when the library computes with
+    this host's tables; ORC_MODE_TABLE over the tables in force when `--arith-tables` named another CPU -- and its SHA-256s must be those of the
+    buffers the timed launches wrote (`verify["digest"]`).  So `verified` never depends on a digest having been committed for this CPU: the
+    committed digests (tests/golden/oracle_full_size.json) remain as the second, independent check.  Folds the result into `verify`."""
+    import hashlib
+    import numpy as np
+    if not verify or not verify.get("digest"):
+        return verify
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    try:
+        from tests import oracle_lib as O
+        if arith == "ieee":
+            mode, how = O.MODE_IEEE, "ORC_MODE_IEEE"
+        elif tables_given:
+            import ctypes as C
+            from snail_amd import _lib
+            tab = np.zeros(3 * 4096, dtype=np.uint32)
+            _lib.check(_lib.lib().snail_host_sse_tables(tab.ctypes.data_as(C.c_void_p)), "snail_host_sse_tables")
+            O.set_tables(tab)
+            mode, how = O.MODE_TABLE, "ORC_MODE_TABLE over the tables in force (--arith-tables %s)" % tables_given
+        else:
+            mode, how = O.MODE_SSE, "ORC_MODE_SSE (this CPU's rcpps / rsqrtps)"
+        got = verify["digest"]
+        threads = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), CPU_THREADS_CAP))
+        t0 = time.perf_counter()
+        if "sha_bgr" in got:
+            osc = O.OracleScene(tv)
+            frame, _ = osc.render_whitted(cam.as_array13(), resx, resy, lights7, mode=mode, threads=threads, reflections=reflections)
+            want = {"sha_bgr": sha(frame)}
+        elif scalar_sse_digest is not None and mode == O.MODE_SSE and "sha_t" in got:
+            want = dict(scalar_sse_digest)          # the frame cpu_baseline() rendered for its scalar timing, hashed there
+            how += ", the frame of the cpu_baseline leg"
+        else:
+            osc = O.OracleScene(tv)
+            t, u, v, tid, _ = osc.render_primary(cam.as_array13(), resx, resy, mode=mode, threads=threads)
+            want = {"sha_t": sha(t), "sha_u": sha(u), "sha_v": sha(v), "sha_id": sha(tid)} if "sha_t" in got else {"sha_depth_bgr": sha(O.shade_depth(t, mode=mode).reshape(resy, resx, 3))}
+        live = all(want.get(k) == v for k, v in got.items())
+        verify["live_oracle"] = bool(live)
+        verify["live_oracle_how"] = "%s, %d threads, %.2f s" % (how, threads, time.perf_counter() - t0)
+    except Exception as e:      # (the oracle is test infrastructure: its absence must not fail a measurement -- the committed digests still stand)
+        verify["live_oracle"] = None
+        verify["live_oracle_how"] = "not run: %s" % e
+    checks = [c for c in (verify.get("live_oracle"), verify.get("committed")) if c is not None]
+    verify["verified"] = None if not checks else bool(all(checks) and verify.get("buffers_identical", False))
+    if verify.get("buffers_identical") is False:
+        verify["verified"] = False
+    return verify
 
 
 def have_digest(scene_name, resx, resy, config, arith) -> bool:
@@ -237,7 +289,7 @@ def weak_frame_size(n_gpus: int, res):
     return int(round(res[0] * s / 16.0)) * 16, int(round(res[1] * s / 8.0)) * 8
 
 
-def cpu_baseline(tv, cam, resx, resy):
+def cpu_baseline(tv, cam, resx, resy, digest_out=None):
     """Rank 0, N=1 only.  The ONLY place bench.py touches oracle/ -- as the reported CPU baseline: the oracle's primary path written four
     lanes wide with SSE intrinsics (oracle/snail_sse4.inc, one SSE quad per __m128 as the reference's f32x4 code runs; pinned bit-exactly to
     the scalar restatement by tests/test_oracle_semantics.py), rcpps / rsqrtps arithmetic, std::thread workers over the packets."""
@@ -258,8 +310,13 @@ def cpu_baseline(tv, cam, resx, resy):
     rays = resx * ((resy + 15) // 16 * 16)
     # the scalar restatement beside it (one frame): what rounds 1-2 reported as the baseline
     t0 = time.perf_counter()
-    osc.render_primary(cam13, resx, resy, mode=O.MODE_SSE, threads=cores)
+    st, su, sv, sid, _ = osc.render_primary(cam13, resx, resy, mode=O.MODE_SSE, threads=cores)
     scalar_s = time.perf_counter() - t0
+    if digest_out is not None:       # the same frame serves live_oracle_check(): what the timed host_sse buffers must hash to on THIS CPU
+        import hashlib
+        import numpy as np
+        sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+        digest_out.update({"sha_t": sha(st), "sha_u": sha(su), "sha_v": sha(sv), "sha_id": sha(sid)})
     return {"value": round(rays / med / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port", "variant": "sse4",
             "scalar_port_value": round(rays / scalar_s / 1e6, 3),
             "sample": "%d full frame(s) of the same workload (%dx%d, %d primary rays each), median frame time %.4f s, %d threads; the oracle's primary path "
@@ -277,6 +334,7 @@ def main():
     ap.add_argument("--rank0-share", type=float, default=1.0, help="N > 1: fraction of a fair tile share that rank 0 (which also gathers and scatters) renders; the reference's server renders nothing = 0")
     ap.add_argument("--scene", default=None, help="override the config's scene (e.g. an OBJ dropped into scenes/, or atrium:0.05)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-check", action="store_true", help="skip the live oracle check of the timed output (rank 0, after the timed region); `verified` then rests on the committed digests alone")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal only: all ranks share GPU 0 and the per-frame gather is staged through host memory")
     ap.add_argument("--streams", type=int, default=0, help="frames in flight (HIP streams); 0 = the renderer's default (4); 1 = strictly serial frames")
@@ -466,20 +524,6 @@ def main():
         verify = verify_outputs(rnd, scene_name, resx, resy, vkey, args.arith, cfg["lights"])
         verify["what"] = ("one more round of the fixed view through the timed renderer after the timed region (the timed frames each hold another view)" if len(path) > 1
                           else "the last frame each slot traced inside the timed region")
-    # host_sse on a CPU the digest file does not know (its results are that CPU's own): the SAME renderer, one more round of the fixed view in the IEEE
-    # arithmetic -- whose digests hold on any host -- so that a run on an unknown CPU is still checked end to end (every rank takes part: collectives pair up)
-    if args.arith == "host_sse" and not have_digest(scene_name, resx, resy, vkey, "host_sse") and have_digest(scene_name, resx, resy, vkey, "ieee"):
-        scene.set_arith("ieee")
-        for _ in range(rnd.nslots * rnd.batch):
-            rnd.render(cam)
-        rnd.flush()
-        barrier()
-        if rank == 0:
-            v2 = verify_outputs(rnd, scene_name, resx, resy, vkey, "ieee", cfg["lights"])
-            verify = {"verified": v2.get("verified"), "host_sse": verify, "ieee_round": v2,
-                      "what": "no committed host_sse digest for this CPU's rcpps / rsqrtps tables: one more round of the fixed view through the timed renderer in the IEEE arithmetic, "
-                              "whose digests hold on any host (the host_sse frame's digest is reported, unchecked, under `host_sse`)"}
-        scene.set_arith(args.arith)
     timed = [e for e in ev if e is not None]
     durs = []
     for e0, e1 in timed:
@@ -654,10 +698,14 @@ def main():
             "roofline": roof,
             "verified": verify.get("verified") if verify else None, "verification": verify,
         }
+        scalar_digest = {}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(tv, cam, resx, resy)
+            out["cpu_baseline"] = cpu_baseline(tv, cam, resx, resy, digest_out=scalar_digest)
         else:
             out["cpu_baseline"] = None
+        if verify is not None and not args.no_live_check:
+            verify = live_oracle_check(verify, tv, cam, resx, resy, args.arith, args.arith_tables, lights7, bool(args.reflections and cfg["lights"]), scalar_digest or None)
+            out["verified"], out["verification"] = verify.get("verified"), verify
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -28,6 +28,10 @@
 //   * immediate: every other call (secondary packets <0,*>, un-prefetched primaries, shadow packets) goes
 //     to snail_trace_rays / snail_trace_shadow synchronously -- correct, and intended to be batched by a
 //     host that cares (collect the packets of a tile, call once; the C-ABI takes nPackets).
+// Threads: the reference's Render(..., threads) runs RenderTask::Work on `threads` pthread workers over ONE const scene
+// (src/render.cpp:214-267, src/thread_pool.cpp:151-180); every const member below may be called from any number of them at once -- the
+// C-ABI handle is thread-safe (include/snail_hip.h, "Concurrency"), the announced packet is per thread, the frame's TreeStats go to exactly one
+// caller.  BeginFrame / EndFrame / Upload / SetArith belong to the thread that owns the frame loop.
 //
 // Errors: the C-ABI returns status codes; the reference aborts (FATAL -> FWK_FATAL, src/rtbase.h:13).
 // SNAIL_CHECK keeps the reference's behaviour.
@@ -113,17 +117,27 @@ public:
 			handles.push_back(h);
 		}
 		scene = handles[0];
+		// a re-upload keeps the arithmetic the host had selected (fresh handles start in SNAIL_ARITH_IEEE)
+		if(arith != SNAIL_ARITH_IEEE && !SetArith(arith)) { std::fprintf(stderr, "FATAL: HipBVH::Upload: SetArith(%d): %s\n", arith, snail_last_error()); std::abort(); }
 	}
 	int DeviceCount() const { return (int)handles.size(); }
 	SnailScene *const *Handles() const { return handles.data(); }
 	// Arithmetic of Inv / RSqrt / FastInv on every device copy (include/snail_hip.h): SNAIL_ARITH_HOST_SSE = what the reference's SSE build
-	// computes on THIS host (its rcpps / rsqrtps + veclib's Newton steps), bit for bit; returns false -- the arithmetic stays as it was -- when
-	// the host's instructions cannot be reproduced from tables (snail_last_error() says why).  Call after Upload.
-	bool SetArith(int arith) {
-		for(SnailScene *h : handles)
-			if(snail_scene_set_arith(h, arith) != 0) { for(SnailScene *g : handles) (void)snail_scene_set_arith(g, SNAIL_ARITH_IEEE); return false; }
+	// computes on THIS host (its rcpps / rsqrtps + veclib's Newton steps), bit for bit; returns false -- every handle's arithmetic stays what it
+	// was before the call -- when the host's instructions cannot be reproduced from tables (snail_last_error() says why).  Remembered: a later
+	// Upload() applies it to the new handles.
+	bool SetArith(int a) {
+		std::vector<int> before(handles.size(), SNAIL_ARITH_IEEE);
+		for(size_t k = 0; k < handles.size(); k++) (void)snail_scene_arith(handles[k], &before[k]);
+		for(size_t k = 0; k < handles.size(); k++)
+			if(snail_scene_set_arith(handles[k], a) != 0) {
+				for(size_t g = 0; g < k; g++) (void)snail_scene_set_arith(handles[g], before[g]);   // (handles[k] itself was not changed)
+				return false;
+			}
+		arith = a;
 		return true;
 	}
+	int Arith() const { return arith; }
 
 	// ---- frame prefetch ----
 	// (const over mutable state: the prefetched frame is a cache of what TraversePrimary would compute, and the reference's renderers
@@ -186,6 +200,7 @@ private:
 		handles.clear(); scene = nullptr;
 	}
 	const RefBVH *ref = nullptr;
+	int arith = SNAIL_ARITH_IEEE;         // what SetArith selected last (re-applied by Upload)
 	SnailScene *scene = nullptr;          // = handles[0]
 	std::vector<SnailScene *> handles;    // one per device
 	mutable FrameHits frame;

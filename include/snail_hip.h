@@ -16,9 +16,17 @@
  * synchronise and are graph-capturable (once a first call with that frame size has allocated the handle's scratch); the un-suffixed entry points take HOST pointers, run on the
  * scene's device and return after the results are in the host buffers.
  *
- * Concurrency: a SnailScene may be used from several HIP streams at once -- launches keep their per-launch scratch (deferred-packet
- * lists, the staged shading intermediates) in 8 round-robin slots guarded by events, so a slot's next user waits, on the device,
- * for its previous one -- but the handle is not thread-safe: make the calls on one scene from one host thread at a time.
+ * Concurrency: a SnailScene is THREAD-SAFE.  The reference hands one `const Scene<AccStruct>` to `threads` pthread workers, each of which calls
+ * TraversePrimary / TraverseShadow on it (src/render.cpp:214-267, src/thread_pool.cpp:151-180, src/scene_trace.cpp:119-120,:560-563); any number
+ * of host threads may likewise be inside any entry points of ONE handle at once:
+ *   - the un-suffixed (host-pointer) entry points give every call a stream, counter words and a staging arena of its own, so concurrent calls
+ *     run side by side on the device and each returns its own results and its own stats[4];
+ *   - the `*_dev` entry points may be issued from several threads on several streams: what a launch books in the handle (its slot of the 8
+ *     round-robin scratch sets -- guarded by events, so a slot's next user waits, on the device, for its previous one --, the cache of
+ *     origin-relative node records) is booked under a per-handle lock that is held while a call ENQUEUES, never while it waits for the device;
+ *   - snail_render_tiles / snail_render_image calls on one handle render out of that handle's ONE cached tile job and therefore take turns
+ *     (calls on different handles do not); snail_render_tiles_multi takes its handles' turns in address order.
+ * snail_scene_destroy and snail_scene_set_arith are the caller's to order against calls in flight (set_arith changes what LATER launches compute).
  * snail_last_error() is per host thread.
  *
  * Record layouts are the reference's own:

@@ -42,6 +42,51 @@ template <> inline float RSqrt<ORC_MODE_SSE>(float x) {
 	float t = _mm_cvtss_f32(_mm_rsqrt_ps(_mm_set1_ps(x)));
 	return (0.5f * t) * (3.0f - ((x * t) * t));
 }
+// ORC_MODE_TABLE: the SSE definitions over rcpps / rsqrtps of a NAMED CPU, given as data (orc_set_tables) -- what the reference computes on that CPU,
+// evaluated on any host.  What every x86 CPU probed so far does (profiles/r4_rcp_probe_*.txt): the result's sign is the input's,
+// its 12 significant mantissa bits depend on the top 12 mantissa bits of the input only (rsqrtps: and on the parity of the exponent), the exponent
+// moves exactly; denormal inputs read as zero, results below the normal range are zero, NaNs come back quieted.  The oracle's own restatement of that
+// rule; pinned against the INSTRUCTIONS of this host with tables extracted here (tests/test_oracle_pins.py::test_table_mode_*).
+uint32_t g_rcpTab[4096], g_rsqTab[2][4096];   // bits of rcpps(1.m) | rsqrtps(1.m) for [1, 2) | rsqrtps(2 x 1.m) for [2, 4), index = m >> 11
+inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+inline float rcpTable(float x) {
+	const uint32_t b = f2u(x), sign = b & 0x80000000u, mant = b & 0x007fffffu;
+	const int ex = (int)((b >> 23) & 0xffu);
+	if(ex == 0xff) return u2f(mant ? (b | 0x00400000u) : sign);       // NaN -> quiet NaN, same payload; +-inf -> +-0
+	if(ex == 0) return u2f(sign | 0x7f800000u);                       // +-0 and +-denormals -> +-inf
+	const uint32_t t = g_rcpTab[mant >> 11];                          // in (0.5, 1]: biased exponent 126, or 127 for an exact 1.0
+	const int rex = (int)(t >> 23) + (127 - ex);                      // 1 / (1.m 2^(ex-127)) = T 2^(127-ex)
+	if(rex < 1) return u2f(sign);                                     // would be denormal: flushed
+	return u2f(sign | ((uint32_t)rex << 23) | (t & 0x007fffffu));
+}
+inline float rsqrtTable(float x) {
+	const uint32_t b = f2u(x), mant = b & 0x007fffffu;
+	const int ex = (int)((b >> 23) & 0xffu);
+	if(ex == 0xff && mant) return u2f(b | 0x00400000u);               // NaN -> quiet NaN
+	if(ex == 0) return u2f((b & 0x80000000u) | 0x7f800000u);          // +-0, +-denormals -> +-inf
+	if(b & 0x80000000u) return u2f(0xffc00000u);                      // negative numbers and -inf: the default NaN
+	if(ex == 0xff) return 0.0f;                                       // +inf -> +0
+	const int e = ex - 127;                                           // x = 1.m 2^e = (1.m or 2 x 1.m) 4^k
+	const int par = e & 1, k = (e - par) / 2;
+	const uint32_t t = g_rsqTab[par][mant >> 11];
+	return u2f((uint32_t)((int)(t >> 23) - k) << 23 | (t & 0x007fffffu));
+}
+template <> inline float Inv<ORC_MODE_TABLE>(float x) {
+	float t = rcpTable(x);
+	return (t + t) - ((x * t) * t);
+}
+template <> inline float RSqrt<ORC_MODE_TABLE>(float x) {
+	float t = rsqrtTable(x);
+	return (0.5f * t) * (3.0f - ((x * t) * t));
+}
+// one call per arithmetic mode (a run-time `mode` picks the instantiation)
+#define ORC_BY_MODE(mode, F, ...)                                                                                                            \
+	do {                                                                                                                                   \
+		if((mode) == ORC_MODE_SSE) F<ORC_MODE_SSE>(__VA_ARGS__);                                                                           \
+		else if((mode) == ORC_MODE_TABLE) F<ORC_MODE_TABLE>(__VA_ARGS__);                                                                  \
+		else F<ORC_MODE_IEEE>(__VA_ARGS__);                                                                                                \
+	} while(0)
 
 struct V3 {
 	float x, y, z;
@@ -67,7 +112,7 @@ inline V3 reflect(V3 ray, V3 nrm) { const float dt = dot(nrm, ray); return ray -
 // SafeInv (src/rtbase.h:117-120): Inv(v + 1e-8) per component
 template <int MODE> inline float safeInv(float d) { return Inv<MODE>(d + 0.00000001f); }
 // FastInv(f32x4) = raw rcpps (veclib/sse/f32.h:101); the scalar definition is Inv (veclib/vecbase.h:57)
-template <int MODE> inline float FastInv(float x) { return MODE == ORC_MODE_SSE ? _mm_cvtss_f32(_mm_rcp_ps(_mm_set1_ps(x))) : 1.0f / x; }
+template <int MODE> inline float FastInv(float x) { return MODE == ORC_MODE_SSE ? _mm_cvtss_f32(_mm_rcp_ps(_mm_set1_ps(x))) : MODE == ORC_MODE_TABLE ? rcpTable(x) : 1.0f / x; }
 // the light's attenuation (src/scene_trace.cpp:585-587): Max(0, ((1 - a) * 0.2 + FastInv(16 * a * a)) - 0.0625), a = distance * iRadius
 template <int MODE> inline float attenuation(float distance, float iRadius) {
 	const float atten = distance * iRadius;
@@ -911,8 +956,7 @@ uint64_t orc_fnv_tris(const OrcTri *tris, int n) {
 void orc_gen_packet(const OrcCamera *cam, int resx, int resy, int px, int py, int mode, float *dir, float *idir) {
 	FpEnvGuard fpEnv;
 	RayGen g = makeRayGen(*cam, resx, resy);
-	if(mode == ORC_MODE_SSE) genPacket<ORC_MODE_SSE>(g, px, py, dir, idir);
-	else genPacket<ORC_MODE_IEEE>(g, px, py, dir, idir);
+	ORC_BY_MODE(mode, genPacket, g, px, py, dir, idir);
 }
 
 void orc_trace_rays(const OrcNode *nodes, const OrcTri *tris, int npackets, int size, int sharedOrigin, const float *origin,
@@ -924,8 +968,7 @@ void orc_trace_rays(const OrcNode *nodes, const OrcTri *tris, int npackets, int 
 		size_t qo = (size_t)p * size;
 		Rays r{size, sharedOrigin != 0, origin + (sharedOrigin ? (size_t)p * 12 : qo * 12), dir + qo * 12, idir + qo * 12,
 			   mask ? mask + qo : nullptr};
-		if(mode == ORC_MODE_SSE) traversePrimary<ORC_MODE_SSE>(nodes, tris, r, distance + qo * 4, object + qo * 4, bary + qo * 8, st);
-		else traversePrimary<ORC_MODE_IEEE>(nodes, tris, r, distance + qo * 4, object + qo * 4, bary + qo * 8, st);
+		ORC_BY_MODE(mode, traversePrimary, nodes, tris, r, distance + qo * 4, object + qo * 4, bary + qo * 8, st);
 	}
 	if(stats) { stats[0] += st.intersects; stats[1] += st.iters; stats[2] += st.rays; stats[3] += st.skips; }
 }
@@ -948,8 +991,7 @@ void orc_trace_shadow(const OrcNode *nodes, const OrcTri *tris, int npackets, in
 void orc_render_primary(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam, int resx, int resy, int x0, int y0, int w,
 						int h, float *t, float *u, float *v, int32_t *triId, uint64_t *stats, int mode, int threads) {
 	FpEnvGuard fpEnv;
-	if(mode == ORC_MODE_SSE) renderPrimary<ORC_MODE_SSE>(nodes, tris, cam, resx, resy, x0, y0, w, h, t, u, v, triId, stats, threads);
-	else renderPrimary<ORC_MODE_IEEE>(nodes, tris, cam, resx, resy, x0, y0, w, h, t, u, v, triId, stats, threads);
+	ORC_BY_MODE(mode, renderPrimary, nodes, tris, cam, resx, resy, x0, y0, w, h, t, u, v, triId, stats, threads);
 }
 
 void orc_render_primary_sse4(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam, int resx, int resy, int x0, int y0, int w,
@@ -961,15 +1003,14 @@ void orc_render_primary_sse4(const OrcNode *nodes, const OrcTri *tris, const Orc
 void orc_account_primary(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam, int resx, int resy, int x0, int y0, int w,
 						 int h, uint64_t *out, int mode, int threads) {
 	FpEnvGuard fpEnv;
-	if(mode == ORC_MODE_SSE) accountPrimary<ORC_MODE_SSE>(nodes, tris, cam, resx, resy, x0, y0, w, h, out, threads);
-	else accountPrimary<ORC_MODE_IEEE>(nodes, tris, cam, resx, resy, x0, y0, w, h, out, threads);
+	ORC_BY_MODE(mode, accountPrimary, nodes, tris, cam, resx, resy, x0, y0, w, h, out, threads);
 }
 
 void orc_shade_depth(const float *t, int n, uint8_t *bgr, int mode) {
 	FpEnvGuard fpEnv;
 	for(int i = 0; i < n; i++) {
 		// Condition(tDistance > maxDist(+inf), 0, Inv(tDistance)): the comparison is never true (src/scene_trace.cpp:130)
-		float dist = mode == ORC_MODE_SSE ? Inv<ORC_MODE_SSE>(t[i]) : Inv<ORC_MODE_IEEE>(t[i]);
+		float dist = orc_inv(t[i], mode);
 		float c[3] = {dist * 20.0f, dist * 250.0f, dist * 2.0f}; // r, g, b
 		int q[3];
 		for(int k = 0; k < 3; k++) q[k] = convChannel(c[k]); // Trunc(Clamp(..)), src/render.cpp:11-17
@@ -980,8 +1021,7 @@ void orc_shade_depth(const float *t, int n, uint8_t *bgr, int mode) {
 void orc_render_whitted(const OrcNode *nodes, const OrcTri *tris, const OrcCamera *cam, int resx, int resy, const float *lights7, int nLights,
 						const float ambient[3], const float color[3], int flags, uint8_t *frame_bgr, int pitch, uint64_t *stats, int mode, int threads) {
 	FpEnvGuard fpEnv;
-	if(mode == ORC_MODE_SSE) renderWhitted<ORC_MODE_SSE>(nodes, tris, cam, resx, resy, lights7, nLights, ambient, color, flags, frame_bgr, pitch, stats, threads);
-	else renderWhitted<ORC_MODE_IEEE>(nodes, tris, cam, resx, resy, lights7, nLights, ambient, color, flags, frame_bgr, pitch, stats, threads);
+	ORC_BY_MODE(mode, renderWhitted, nodes, tris, cam, resx, resy, lights7, nLights, ambient, color, flags, frame_bgr, pitch, stats, threads);
 }
 
 // the `compress` store of RenderTask::Work (src/render.cpp:140-163): planes R, G-R, B-R of a tile, from the interleaved B,G,R frame
@@ -994,8 +1034,7 @@ void orc_trace_transparency(const OrcNode *nodes, const OrcTri *tris, const OrcC
 	Stats st;
 	for(int p = 0; p < nPackets; p++) {
 		float (*col)[3] = (float (*)[3])(out_color + (size_t)p * 768);
-		if(mode == ORC_MODE_SSE) transparencyPacket<ORC_MODE_SSE>(nodes, tris, *cam, g, packet_xy[p * 2], packet_xy[p * 2 + 1], t + (size_t)p * 256, sel + (size_t)p * 64, L, col, st);
-		else transparencyPacket<ORC_MODE_IEEE>(nodes, tris, *cam, g, packet_xy[p * 2], packet_xy[p * 2 + 1], t + (size_t)p * 256, sel + (size_t)p * 64, L, col, st);
+		ORC_BY_MODE(mode, transparencyPacket, nodes, tris, *cam, g, packet_xy[p * 2], packet_xy[p * 2 + 1], t + (size_t)p * 256, sel + (size_t)p * 64, L, col, st);
 	}
 	if(stats) { stats[0] += st.intersects; stats[1] += st.iters; stats[2] += st.rays; stats[3] += st.skips; }
 }
@@ -1052,6 +1091,10 @@ void orc_veclib_exprs(const float *in, uint32_t *out, int mode) {
 			out[45 + l] = bits(FastInv<ORC_MODE_SSE>(qa[l]));
 			out[49 + l] = bits(attenuation<ORC_MODE_SSE>(qa[l], qb[l]));
 			out[53 + l] = bits(safeInv<ORC_MODE_SSE>(qa[l]));
+		} else if(mode == ORC_MODE_TABLE) {
+			out[45 + l] = bits(FastInv<ORC_MODE_TABLE>(qa[l]));
+			out[49 + l] = bits(attenuation<ORC_MODE_TABLE>(qa[l], qb[l]));
+			out[53 + l] = bits(safeInv<ORC_MODE_TABLE>(qa[l]));
 		} else {
 			out[45 + l] = bits(FastInv<ORC_MODE_IEEE>(qa[l]));
 			out[49 + l] = bits(attenuation<ORC_MODE_IEEE>(qa[l], qb[l]));
@@ -1060,8 +1103,29 @@ void orc_veclib_exprs(const float *in, uint32_t *out, int mode) {
 	}
 }
 
-float orc_inv(float x, int mode) { return mode == ORC_MODE_SSE ? Inv<ORC_MODE_SSE>(x) : Inv<ORC_MODE_IEEE>(x); }
-float orc_rsqrt(float x, int mode) { return mode == ORC_MODE_SSE ? RSqrt<ORC_MODE_SSE>(x) : RSqrt<ORC_MODE_IEEE>(x); }
+float orc_inv(float x, int mode) { return mode == ORC_MODE_SSE ? Inv<ORC_MODE_SSE>(x) : mode == ORC_MODE_TABLE ? Inv<ORC_MODE_TABLE>(x) : Inv<ORC_MODE_IEEE>(x); }
+float orc_rsqrt(float x, int mode) { return mode == ORC_MODE_SSE ? RSqrt<ORC_MODE_SSE>(x) : mode == ORC_MODE_TABLE ? RSqrt<ORC_MODE_TABLE>(x) : RSqrt<ORC_MODE_IEEE>(x); }
+// ORC_MODE_TABLE's data: 3 x 4096 words -- bits of rcpps(1.m), of rsqrtps(1.m) and of rsqrtps(2 x 1.m), index m >> 11 (the layout of the product's
+// snail_host_sse_tables / tests/golden/rcp_tables.npz)
+void orc_set_tables(const uint32_t *tables12288) {
+	memcpy(g_rcpTab, tables12288, sizeof g_rcpTab);
+	memcpy(g_rsqTab, tables12288 + 4096, sizeof g_rsqTab);
+}
+// ... taken from THIS host's instructions (no check of the block structure here: the tests compare rule and instruction)
+void orc_tables_of_this_cpu(uint32_t *tables12288) {
+	for(uint32_t i = 0; i < 4096; i++) {
+		tables12288[i] = f2u(_mm_cvtss_f32(_mm_rcp_ps(_mm_set1_ps(u2f(0x3f800000u | (i << 11))))));
+		tables12288[4096 + i] = f2u(_mm_cvtss_f32(_mm_rsqrt_ps(_mm_set1_ps(u2f(0x3f800000u | (i << 11))))));
+		tables12288[8192 + i] = f2u(_mm_cvtss_f32(_mm_rsqrt_ps(_mm_set1_ps(u2f(0x40000000u | (i << 11))))));
+	}
+}
+// raw look-ups, bit patterns in and out: fn 0 = rcpps, 1 = rsqrtps; by the table rule (table != 0) or by this host's instruction
+void orc_raw_approx(int fn, int table, const uint32_t *in, uint32_t *out, int n) {
+	for(int i = 0; i < n; i++) {
+		const float x = u2f(in[i]);
+		out[i] = f2u(table ? (fn == 0 ? rcpTable(x) : rsqrtTable(x)) : (fn == 0 ? _mm_cvtss_f32(_mm_rcp_ps(_mm_set1_ps(x))) : _mm_cvtss_f32(_mm_rsqrt_ps(_mm_set1_ps(x)))));
+	}
+}
 float orc_min(float a, float b) { return Min(a, b); }
 float orc_max(float a, float b) { return Max(a, b); }
 

@@ -20,6 +20,9 @@
  *   ORC_MODE_SSE  (1): veclib's SSE definitions     rcpps/rsqrtps + one Newton step
  *                      (veclib/sse/base.h:84-92)    -- what the reference executes on x86; the raw
  *                      approximations are CPU-vendor specific.
+ *   ORC_MODE_TABLE (2): the SSE definitions with rcpps / rsqrtps of a NAMED CPU given as tables (orc_set_tables; 3 x 4096 words, the layout of
+ *                      tests/golden/rcp_tables.npz): what the reference computes on that CPU, on any host.  With this host's own tables
+ *                      (orc_tables_of_this_cpu) it equals ORC_MODE_SSE bit for bit (tests/test_oracle_pins.py::test_table_mode_*).
  */
 #ifndef SNAIL_ORACLE_H
 #define SNAIL_ORACLE_H
@@ -29,7 +32,7 @@
 extern "C" {
 #endif
 
-enum { ORC_MODE_IEEE = 0, ORC_MODE_SSE = 1 };
+enum { ORC_MODE_IEEE = 0, ORC_MODE_SSE = 1, ORC_MODE_TABLE = 2 };
 
 /* 64-byte triangle record, identical to the reference's `Triangle` (src/triangle.h:133-135):
  * a, ba, ca, t0, it0, pad, plane(nx,ny,nz,n.a) */
@@ -153,6 +156,12 @@ void orc_veclib_exprs(const float *in8, uint32_t *out57, int mode);
 /* arithmetic primitives exposed for the veclib pin test */
 float orc_inv(float x, int mode);
 float orc_rsqrt(float x, int mode);
+/* ORC_MODE_TABLE: the rcpps / rsqrtps tables every later call in that mode computes with (process-wide: set once, before the calls) -- bits of
+ * rcpps(1.m), rsqrtps(1.m), rsqrtps(2 x 1.m), index = m >> 11; orc_tables_of_this_cpu reads them out of this host's instructions;
+ * orc_raw_approx: n raw look-ups (fn 0 = rcpps, 1 = rsqrtps; bit patterns) by the table rule (table != 0) or by this host's instruction. */
+void orc_set_tables(const uint32_t *tables12288);
+void orc_tables_of_this_cpu(uint32_t *tables12288);
+void orc_raw_approx(int fn, int table, const uint32_t *in, uint32_t *out, int n);
 float orc_min(float a, float b);
 float orc_max(float a, float b);
 

@@ -34,7 +34,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -126,7 +128,6 @@ struct SnailScene {
 	int nestedOK = 1; // every child box lies inside its parent's (stackPack)
 	int pfOKButNesting = 0;
 	int lastBlocks = 0, lastThreads = 0;
-	unsigned long long *dStats = nullptr; // 4 x u64 scratch for the host-pointer entry points
 	enum { kDeferSlots = 8 };
 	int *dDefer[kDeferSlots] = {};        // deferred-packet lists, one per launch in flight (round-robin)
 	// a slot's buffers are reused by the 8th launch after it, possibly on another stream and possibly while the host runs far
@@ -152,6 +153,22 @@ struct SnailScene {
 	// deferred-packet lists of snail_trace_rays*, same slot discipline
 	struct RayDefer { int *p = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool used = false; } rayDefer[kDeferSlots];
 	unsigned rayCount = 0;
+	// ---- concurrency (include/snail_hip.h, "Concurrency"): the reference hands ONE const Scene<AccStruct> to `threads` pthread workers, each of which
+	// calls TraversePrimary / TraverseShadow on it (src/render.cpp:214-267, src/thread_pool.cpp:151-180, src/scene_trace.cpp:119-120,:560-563) ----
+	// mu: everything a launch books in this handle -- the slot rotations above, the origin-relative node cache, scratch growth, lastBlocks, arith.
+	// Held while a call ENQUEUES (microseconds), never while it waits for the device.
+	std::mutex mu;
+	// renderMu: a whole snail_render_tiles / _image call (they render out of ONE cached job per scene); taken before mu.
+	std::mutex renderMu;
+	// What a host-pointer call owns for its duration: a stream of its own, its own counter words and a staging arena (grown, never shrunk).  Taken
+	// from / returned to this free list under mu; as many exist as calls were ever in flight at once.
+	struct HostCall {
+		hipStream_t stream = nullptr;
+		unsigned long long *dStats = nullptr;
+		char *arena = nullptr;
+		size_t cap = 0, used = 0;
+	};
+	std::vector<HostCall *> hostFree;
 };
 
 namespace {
@@ -166,6 +183,73 @@ struct DeviceGuard {
 	~DeviceGuard() {
 		int cur = -1;
 		if(prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+	}
+};
+
+// A host-pointer call's private stream, counter words and staging arena (SnailScene::HostCall) for the duration of the call: two host threads
+// inside snail_trace_shadow / _rays / _primary / _frame_packets / snail_render_* on ONE scene share nothing but the handle's bookkeeping, which they
+// touch under SnailScene::mu.  Everything the call moves goes through its own stream in order: staged inputs -> kernels -> results -> ONE wait.
+struct HostCallScope {
+	SnailScene *s;
+	SnailScene::HostCall *c = nullptr;
+	int rc = 0;
+	HostCallScope(SnailScene *scene, const char *fn) : s(scene) {
+		{
+			std::lock_guard<std::mutex> lock(s->mu);
+			if(!s->hostFree.empty()) { c = s->hostFree.back(); s->hostFree.pop_back(); }
+		}
+		if(!c) {
+			c = new SnailScene::HostCall();
+			hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+			if(e == hipSuccess) e = hipMalloc((void **)&c->dStats, 4 * sizeof(unsigned long long));
+			if(e != hipSuccess) {
+				snail_set_error("%s: per-call stream / counters: %s", fn, hipGetErrorString(e));
+				if(c->stream) (void)hipStreamDestroy(c->stream);
+				delete c; c = nullptr; rc = 100 + (int)e;
+			}
+		}
+		if(c) c->used = 0;
+	}
+	~HostCallScope() {
+		if(!c) return;
+		std::lock_guard<std::mutex> lock(s->mu);
+		s->hostFree.push_back(c);
+	}
+	HostCallScope(const HostCallScope &) = delete;
+	HostCallScope &operator=(const HostCallScope &) = delete;
+	hipStream_t stream() const { return c->stream; }
+	uint64_t *stats() const { return (uint64_t *)c->dStats; }
+	static size_t pad(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+	// the bytes the call is going to carve, all at once (the arena is re-allocated only when a larger call than ever before arrives; its previous
+	// user has returned -- calls are synchronous -- so nothing in flight reads it)
+	int reserve(size_t bytes) {
+		if(bytes <= c->cap) return 0;
+		if(c->arena) (void)hipFree(c->arena);
+		c->arena = nullptr; c->cap = 0;
+		const size_t want = bytes + bytes / 4 + 4096;
+		HIP_TRY(hipMalloc((void **)&c->arena, want));
+		c->cap = want;
+		return 0;
+	}
+	void *carve(size_t bytes) { void *p = c->arena + c->used; c->used += pad(bytes); return p; }
+	// carve + copy in (src may be null: carve only)
+	int put(void **d, const void *src, size_t bytes) {
+		*d = carve(bytes);
+		if(src && bytes) HIP_TRY(hipMemcpyAsync(*d, src, bytes, hipMemcpyHostToDevice, c->stream));
+		return 0;
+	}
+	int get(void *dst, const void *d, size_t bytes) {
+		if(dst && bytes) HIP_TRY(hipMemcpyAsync(dst, d, bytes, hipMemcpyDeviceToHost, c->stream));
+		return 0;
+	}
+	int zeroStats() { HIP_TRY(hipMemsetAsync(c->dStats, 0, 4 * sizeof(unsigned long long), c->stream)); return 0; }
+	// wait for everything the call enqueued, then add its counters to the caller's
+	int finish(uint64_t *stats) {
+		unsigned long long hs[4] = {0, 0, 0, 0};
+		if(stats) HIP_TRY(hipMemcpyAsync(hs, c->dStats, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		if(stats) for(int k = 0; k < 4; k++) stats[k] += hs[k];
+		return 0;
 	}
 };
 
@@ -322,6 +406,10 @@ int checkScene(const SnailScene *s, const char *fn) {
 	return 0;
 }
 
+// every entry point that books a launch in the handle holds SnailScene::mu while it ENQUEUES (launchPrimary*, launchRays, launchLights, renderWhitted,
+// relFor / relUsed and the slot rotations assume it is held); nothing waits for the device under it except the rare synchronous scratch growth
+#define SNAIL_LOCK(s) std::lock_guard<std::mutex> snailLock_((s)->mu)
+
 // the frames of one launch: cameras (13 floats each) and output planes per frame (any plane may be null)
 struct FrameSet {
 	int n = 0;
@@ -390,6 +478,7 @@ int launchPrimaryFrames(SnailScene *s, const FrameSet &FS, int resx, int resy, i
 			HIP_TRY(hipMalloc((void **)&s->dDefer[k], (size_t)(gridBlocks + 2) * sizeof(int)));
 			HIP_TRY(hipMemset(s->dDefer[k], 0, 2 * sizeof(int)));
 		}
+		HIP_TRY(hipDeviceSynchronize());   // (a memset is ordered on the null stream only: the launches may run on streams that do not wait for it)
 		s->deferCap = gridBlocks + 2;
 	}
 	const int slot = (int)(s->launchCount++ % SnailScene::kDeferSlots);
@@ -451,6 +540,7 @@ int shadeScratch(SnailScene *s, SnailScene::ShadeScratch &W, size_t packets, siz
 	W.hitId = (int *)base; base += rays * 4;
 	W.defer = (int *)base; base += deferInts * 4;
 	HIP_TRY(hipMemset(W.defer, 0, 16 * sizeof(int)));
+	HIP_TRY(hipDeviceSynchronize());   // (ordered on the null stream only, see launchPrimaryFrames)
 	W.sDist = (float *)base; base += rays * 4 * SNAIL_MAX_LIGHTS;
 	if(refl) {
 		W.rOrg = (float *)base; base += quads * 48;
@@ -504,6 +594,7 @@ int launchRays(SnailScene *s, bool shadow, int nPackets, int size, int sharedOri
 		R.p = nullptr; R.cap = 0;
 		HIP_TRY(hipMalloc((void **)&R.p, ((size_t)nPackets + 16) * sizeof(int)));
 		HIP_TRY(hipMemset(R.p, 0, 16 * sizeof(int)));
+		HIP_TRY(hipDeviceSynchronize());   // (ordered on the null stream only, see launchPrimaryFrames)
 		R.cap = (size_t)nPackets + 16;
 	}
 	if(!R.done) HIP_TRY(hipEventCreateWithFlags(&R.done, hipEventDisableTiming));
@@ -653,7 +744,6 @@ SnailScene *snail_scene_create(const void *nodes32, int nNodes, const void *tris
 	}
 	hipError_t e;
 	if((e = hipMalloc((void **)&s->dNodes, (size_t)nNodes * 32)) != hipSuccess || (e = hipMalloc((void **)&s->dPF, fits ? pfBytes : (size_t)nTris * 64)) != hipSuccess ||
-	   (e = hipMalloc((void **)&s->dStats, 4 * sizeof(unsigned long long))) != hipSuccess ||
 	   (e = hipMemcpy(s->dNodes, nodes32, (size_t)nNodes * 32, hipMemcpyHostToDevice)) != hipSuccess ||
 	   (e = hipMemcpy(s->dPF + s->trisOff, tris64, (size_t)nTris * 64, hipMemcpyHostToDevice)) != hipSuccess ||
 	   (!pf.empty() && (e = hipMemcpy(s->dPF, pf.data(), pf.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)) {
@@ -688,8 +778,7 @@ SnailScene *snail_scene_create_lbvh(const float *tri_verts, int nTris, int devic
 	s->nestedOK = 1; s->pfOKButNesting = s->pfOK = fits ? 1 : 0;
 	hipError_t e;
 	if((e = hipMalloc((void **)&s->dPF, fits ? pfBytes : (size_t)nTris * 64)) != hipSuccess ||
-	   (e = hipMemcpy(s->dPF + s->trisOff, dTris, (size_t)nTris * 64, hipMemcpyDeviceToDevice)) != hipSuccess ||
-	   (e = hipMalloc((void **)&s->dStats, 4 * sizeof(unsigned long long))) != hipSuccess) {
+	   (e = hipMemcpy(s->dPF + s->trisOff, dTris, (size_t)nTris * 64, hipMemcpyDeviceToDevice)) != hipSuccess) {
 		(void)hipFree(dTris);
 		snail_set_error("snail_scene_create_lbvh: %s", hipGetErrorString(e));
 		snail_scene_destroy(s);
@@ -728,7 +817,12 @@ void snail_scene_destroy(SnailScene *s) {
 		if(e.filled) (void)hipEventDestroy(e.filled);
 		for(hipEvent_t ev : e.used) if(ev) (void)hipEventDestroy(ev);
 	}
-	if(s->dStats) (void)hipFree(s->dStats);
+	for(SnailScene::HostCall *c : s->hostFree) {
+		if(c->arena) (void)hipFree(c->arena);
+		if(c->dStats) (void)hipFree(c->dStats);
+		if(c->stream) (void)hipStreamDestroy(c->stream);
+		delete c;
+	}
 	for(int k = 0; k < SnailScene::kDeferSlots; k++) if(s->dDefer[k]) (void)hipFree(s->dDefer[k]);
 	for(int k = 0; k < SnailScene::kDeferSlots; k++) if(s->shade[k].hitT) (void)hipFree(s->shade[k].hitT);
 	for(int k = 0; k < SnailScene::kDeferSlots; k++) {
@@ -765,6 +859,7 @@ int snail_scene_set_arith(SnailScene *s, int arith) {
 		if(!guard.ok) { snail_set_error("snail_scene_set_arith: hipSetDevice(%d) failed", s->device); return 1; }
 		if(int rc = hostSseUpload("snail_scene_set_arith")) return rc;
 	}
+	SNAIL_LOCK(s);
 	s->arith = arith;
 	return 0;
 }
@@ -797,6 +892,7 @@ int snail_host_sse_check(int fn, uint64_t first, uint64_t count, int threads, ui
 
 int snail_last_launch(const SnailScene *s, int *blocks, int *threads) {
 	if(!s) { snail_set_error("snail_last_launch: null scene"); return 1; }
+	std::lock_guard<std::mutex> lock(const_cast<SnailScene *>(s)->mu);
 	if(blocks) *blocks = s->lastBlocks;
 	if(threads) *threads = s->lastThreads;
 	return 0;
@@ -806,6 +902,7 @@ int snail_trace_primary_dev(SnailScene *s, const float cam[13], int resx, int re
 							float *v, int32_t *id, uint64_t *dStats, void *stream) {
 	if(int rc = checkScene(s, "snail_trace_primary_dev")) return rc;
 	DeviceGuard guard(s->device);
+	SNAIL_LOCK(s);
 	return launchPrimary(s, cam, resx, resy, x0, y0, w, h, nullptr, 0, t, u, v, id, dStats, (hipStream_t)stream);
 }
 
@@ -819,6 +916,7 @@ int snail_trace_primary_ordered_dev(SnailScene *s, const float cam[13], int resx
 									float *v, int32_t *id, uint64_t *dStats, const int32_t *dOrder, int32_t *dSlotCost, void *stream) {
 	if(int rc = checkScene(s, "snail_trace_primary_ordered_dev")) return rc;
 	DeviceGuard guard(s->device);
+	SNAIL_LOCK(s);
 	return launchPrimary(s, cam, resx, resy, x0, y0, w, h, nullptr, 0, t, u, v, id, dStats, (hipStream_t)stream, nullptr, false, nullptr, dOrder, dSlotCost);
 }
 
@@ -828,6 +926,7 @@ int snail_trace_packets_ordered_dev(SnailScene *s, const float cam[13], int resx
 	if(!dPacketXY && nPackets > 0) { snail_set_error("snail_trace_packets_ordered_dev: null packet list"); return 1; }
 	if(nPackets <= 0) return 0; // a rank without tiles (the reference's server renders nothing)
 	DeviceGuard guard(s->device);
+	SNAIL_LOCK(s);
 	return launchPrimary(s, cam, resx, resy, 0, 0, 0, 0, dPacketXY, nPackets, t, u, v, id, dStats, (hipStream_t)stream, nullptr, false, nullptr, dOrder, dSlotCost);
 }
 
@@ -852,6 +951,7 @@ int snail_trace_packets_dev(SnailScene *s, const float cam[13], int resx, int re
 	if(!dPacketXY && nPackets > 0) { snail_set_error("snail_trace_packets_dev: null packet list"); return 1; }
 	if(nPackets <= 0) return 0; // a rank without tiles (the reference's server renders nothing)
 	DeviceGuard guard(s->device);
+	SNAIL_LOCK(s);
 	return launchPrimary(s, cam, resx, resy, 0, 0, 0, 0, dPacketXY, nPackets, t, u, v, id, dStats, (hipStream_t)stream);
 }
 
@@ -871,6 +971,7 @@ int snail_trace_primary_batch_dev(SnailScene *s, int nFrames, const float *cams1
 		FS.out[k].t = t ? t[k] : nullptr; FS.out[k].u = u ? u[k] : nullptr; FS.out[k].v = v ? v[k] : nullptr; FS.out[k].id = id ? (int *)id[k] : nullptr;
 	}
 	DeviceGuard guard(s->device);
+	SNAIL_LOCK(s);
 	return launchPrimaryFrames(s, FS, resx, resy, 0, 0, resx, resy, nullptr, 0, dStats, (hipStream_t)stream, nullptr, false, dOrder, dSlotCost);
 }
 
@@ -886,6 +987,7 @@ int snail_trace_packets_shaded_batch_dev(SnailScene *s, int nFrames, const float
 		FS.out[k].bgr = bgr[k];
 	}
 	DeviceGuard guard(s->device);
+	SNAIL_LOCK(s);
 	return launchPrimaryFrames(s, FS, resx, resy, 0, 0, 0, 0, dPacketXY, nPackets, dStats, (hipStream_t)stream);
 }
 
@@ -896,6 +998,7 @@ int snail_trace_packets_shaded_dev(SnailScene *s, const float cam[13], int resx,
 	if(nPackets <= 0) return 0;
 	if((unsigned long long)bgr & 3) { snail_set_error("snail_trace_packets_shaded_dev: d_bgr must be 4-byte aligned"); return 1; }
 	DeviceGuard guard(s->device);
+	SNAIL_LOCK(s);
 	return launchPrimary(s, cam, resx, resy, 0, 0, 0, 0, dPacketXY, nPackets, nullptr, nullptr, nullptr, nullptr, dStats, (hipStream_t)stream, nullptr, false, bgr);
 }
 
@@ -911,33 +1014,28 @@ int snail_packets_to_frame_dev(const int32_t *dPacketXY, int nPackets, int resx,
 int snail_trace_primary(SnailScene *s, const float cam[13], int resx, int resy, int x0, int y0, int w, int h, float *t, float *u, float *v,
 						int32_t *id, uint64_t stats[4]) {
 	if(int rc = checkScene(s, "snail_trace_primary")) return rc;
+	if(resx <= 0 || resy <= 0) { snail_set_error("snail_trace_primary: bad resolution %dx%d", resx, resy); return 1; }
 	DeviceGuard guard(s->device);
-	const size_t n = (size_t)resx * resy;
-	float *dt = nullptr, *du = nullptr, *dv = nullptr;
-	int32_t *did = nullptr;
-	int rc = 0;
-	auto freeAll = [&] { if(dt) (void)hipFree(dt); if(du) (void)hipFree(du); if(dv) (void)hipFree(dv); if(did) (void)hipFree(did); };
-#define TRY_OR_FREE(e) do { hipError_t e_ = (e); if(e_ != hipSuccess) { snail_set_error("%s: %s", #e, hipGetErrorString(e_)); freeAll(); return 100 + (int)e_; } } while(0)
+	HostCallScope hc(s, "snail_trace_primary");
+	if(hc.rc) return hc.rc;
+	const size_t n = (size_t)resx * resy * 4;
 	// the host buffers are full frames of which only the rect is defined: stage through device frames
-	if(t) { TRY_OR_FREE(hipMalloc((void **)&dt, n * 4)); TRY_OR_FREE(hipMemcpy(dt, t, n * 4, hipMemcpyHostToDevice)); }
-	if(u) { TRY_OR_FREE(hipMalloc((void **)&du, n * 4)); TRY_OR_FREE(hipMemcpy(du, u, n * 4, hipMemcpyHostToDevice)); }
-	if(v) { TRY_OR_FREE(hipMalloc((void **)&dv, n * 4)); TRY_OR_FREE(hipMemcpy(dv, v, n * 4, hipMemcpyHostToDevice)); }
-	if(id) { TRY_OR_FREE(hipMalloc((void **)&did, n * 4)); TRY_OR_FREE(hipMemcpy(did, id, n * 4, hipMemcpyHostToDevice)); }
-	if(stats) TRY_OR_FREE(hipMemset(s->dStats, 0, 32));
-	rc = launchPrimary(s, cam, resx, resy, x0, y0, w, h, nullptr, 0, dt, du, dv, did, stats ? (uint64_t *)s->dStats : nullptr, 0);
-	if(rc) { freeAll(); return rc; }
-	TRY_OR_FREE(hipDeviceSynchronize());
-	if(t) TRY_OR_FREE(hipMemcpy(t, dt, n * 4, hipMemcpyDeviceToHost));
-	if(u) TRY_OR_FREE(hipMemcpy(u, du, n * 4, hipMemcpyDeviceToHost));
-	if(v) TRY_OR_FREE(hipMemcpy(v, dv, n * 4, hipMemcpyDeviceToHost));
-	if(id) TRY_OR_FREE(hipMemcpy(id, did, n * 4, hipMemcpyDeviceToHost));
-	if(stats) {
-		unsigned long long hs[4];
-		TRY_OR_FREE(hipMemcpy(hs, s->dStats, 32, hipMemcpyDeviceToHost));
-		for(int k = 0; k < 4; k++) stats[k] += hs[k];
+	if(int rc = hc.reserve(4 * HostCallScope::pad(n))) return rc;
+	void *dt = nullptr, *du = nullptr, *dv = nullptr, *did = nullptr;
+	if(t) { if(int rc = hc.put(&dt, t, n)) return rc; }
+	if(u) { if(int rc = hc.put(&du, u, n)) return rc; }
+	if(v) { if(int rc = hc.put(&dv, v, n)) return rc; }
+	if(id) { if(int rc = hc.put(&did, id, n)) return rc; }
+	if(stats) { if(int rc = hc.zeroStats()) return rc; }
+	{
+		SNAIL_LOCK(s);
+		if(int rc = launchPrimary(s, cam, resx, resy, x0, y0, w, h, nullptr, 0, (float *)dt, (float *)du, (float *)dv, (int32_t *)did, stats ? hc.stats() : nullptr, hc.stream())) return rc;
 	}
-	freeAll();
-	return 0;
+	if(int rc = hc.get(t, dt, n)) return rc;
+	if(int rc = hc.get(u, du, n)) return rc;
+	if(int rc = hc.get(v, dv, n)) return rc;
+	if(int rc = hc.get(id, did, n)) return rc;
+	return hc.finish(stats);
 }
 
 
@@ -945,6 +1043,7 @@ int snail_trace_rays_dev(SnailScene *s, int nPackets, int size, int sharedOrigin
 						 const uint8_t *mask, float *distance, int32_t *object, float *bary, uint64_t *dStats, void *stream) {
 	if(int rc = checkScene(s, "snail_trace_rays_dev")) return rc;
 	DeviceGuard guard(s->device);
+	SNAIL_LOCK(s);
 	return launchRays(s, false, nPackets, size, sharedOrigin, origin, dir, idir, mask, distance, object, bary, dStats, (hipStream_t)stream);
 }
 
@@ -952,71 +1051,68 @@ int snail_trace_shadow_dev(SnailScene *s, int nPackets, int size, const float *o
 						   uint64_t *dStats, void *stream) {
 	if(int rc = checkScene(s, "snail_trace_shadow_dev")) return rc;
 	DeviceGuard guard(s->device);
+	SNAIL_LOCK(s);
 	return launchRays(s, true, nPackets, size, 1, origin3, dir, idir, nullptr, distance, nullptr, nullptr, dStats, (hipStream_t)stream);
 }
-
-namespace {
-struct DevBuf {
-	void *p = nullptr;
-	~DevBuf() { if(p) (void)hipFree(p); }
-	int upload(const void *src, size_t bytes) {
-		if(hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) return 1;
-		if(src && bytes && hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return 1;
-		return 0;
-	}
-	int download(void *dst, size_t bytes) { return hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost) != hipSuccess; }
-};
-} // namespace
 
 int snail_trace_rays(SnailScene *s, int nPackets, int size, int sharedOrigin, const float *origin, const float *dir, const float *idir,
 					 const uint8_t *mask, float *distance, int32_t *object, float *bary, uint64_t stats[4]) {
 	if(int rc = checkScene(s, "snail_trace_rays")) return rc;
 	if(nPackets <= 0) return 0;
+	if(size < 1 || size > SNAIL_PACKET_QUADS) { snail_set_error("packet size %d outside 1..%d quads", size, SNAIL_PACKET_QUADS); return 1; }
+	if(!origin || !dir || !idir || !distance || !object) { snail_set_error("null ray array"); return 1; }
 	DeviceGuard guard(s->device);
+	HostCallScope hc(s, "snail_trace_rays");
+	if(hc.rc) return hc.rc;
 	const size_t nq = (size_t)nPackets * size;
-	DevBuf o, d, i, m, ds, ob, ba;
-	if(o.upload(origin, (sharedOrigin ? (size_t)nPackets : nq) * 48) || d.upload(dir, nq * 48) || i.upload(idir, nq * 48) ||
-	   (mask && m.upload(mask, nq)) || ds.upload(distance, nq * 16) || ob.upload(object, nq * 16) || (bary && ba.upload(bary, nq * 32))) {
-		snail_set_error("snail_trace_rays: device staging failed");
-		return 2;
+	const size_t nOrg = (sharedOrigin ? (size_t)nPackets : nq) * 48;
+	typedef HostCallScope H;
+	if(int rc = hc.reserve(H::pad(nOrg) + 2 * H::pad(nq * 48) + H::pad(nq) + 2 * H::pad(nq * 16) + H::pad(nq * 32))) return rc;
+	void *o = nullptr, *d = nullptr, *i = nullptr, *m = nullptr, *ds = nullptr, *ob = nullptr, *ba = nullptr;
+	if(int rc = hc.put(&o, origin, nOrg)) return rc;
+	if(int rc = hc.put(&d, dir, nq * 48)) return rc;
+	if(int rc = hc.put(&i, idir, nq * 48)) return rc;
+	if(mask) { if(int rc = hc.put(&m, mask, nq)) return rc; }
+	if(int rc = hc.put(&ds, distance, nq * 16)) return rc;
+	if(int rc = hc.put(&ob, object, nq * 16)) return rc;
+	if(bary) { if(int rc = hc.put(&ba, bary, nq * 32)) return rc; }
+	if(stats) { if(int rc = hc.zeroStats()) return rc; }
+	{
+		SNAIL_LOCK(s);
+		if(int rc = launchRays(s, false, nPackets, size, sharedOrigin, (float *)o, (float *)d, (float *)i, (uint8_t *)m, (float *)ds, (int32_t *)ob, (float *)ba,
+							   stats ? hc.stats() : nullptr, hc.stream()))
+			return rc;
 	}
-	if(stats) HIP_TRY(hipMemset(s->dStats, 0, 32));
-	int rc = launchRays(s, false, nPackets, size, sharedOrigin, (float *)o.p, (float *)d.p, (float *)i.p, mask ? (uint8_t *)m.p : nullptr, (float *)ds.p,
-						(int32_t *)ob.p, bary ? (float *)ba.p : nullptr, stats ? (uint64_t *)s->dStats : nullptr, 0);
-	if(rc) return rc;
-	HIP_TRY(hipDeviceSynchronize());
-	if(ds.download(distance, nq * 16) || ob.download(object, nq * 16) || (bary && ba.download(bary, nq * 32))) { snail_set_error("snail_trace_rays: download failed"); return 2; }
-	if(stats) {
-		unsigned long long hs[4];
-		HIP_TRY(hipMemcpy(hs, s->dStats, 32, hipMemcpyDeviceToHost));
-		for(int k = 0; k < 4; k++) stats[k] += hs[k];
-	}
-	return 0;
+	if(int rc = hc.get(distance, ds, nq * 16)) return rc;
+	if(int rc = hc.get(object, ob, nq * 16)) return rc;
+	if(int rc = hc.get(bary, ba, nq * 32)) return rc;
+	return hc.finish(stats);
 }
 
 int snail_trace_shadow(SnailScene *s, int nPackets, int size, const float *origin3, const float *dir, const float *idir, float *distance,
 					   uint64_t stats[4]) {
 	if(int rc = checkScene(s, "snail_trace_shadow")) return rc;
 	if(nPackets <= 0) return 0;
+	if(size < 1 || size > SNAIL_PACKET_QUADS) { snail_set_error("packet size %d outside 1..%d quads", size, SNAIL_PACKET_QUADS); return 1; }
+	if(!origin3 || !dir || !idir || !distance) { snail_set_error("null ray array"); return 1; }
 	DeviceGuard guard(s->device);
+	HostCallScope hc(s, "snail_trace_shadow");
+	if(hc.rc) return hc.rc;
 	const size_t nq = (size_t)nPackets * size;
-	DevBuf o, d, i, ds;
-	if(o.upload(origin3, (size_t)nPackets * 12) || d.upload(dir, nq * 48) || i.upload(idir, nq * 48) || ds.upload(distance, nq * 16)) {
-		snail_set_error("snail_trace_shadow: device staging failed");
-		return 2;
+	typedef HostCallScope H;
+	if(int rc = hc.reserve(H::pad((size_t)nPackets * 12) + 2 * H::pad(nq * 48) + H::pad(nq * 16))) return rc;
+	void *o = nullptr, *d = nullptr, *i = nullptr, *ds = nullptr;
+	if(int rc = hc.put(&o, origin3, (size_t)nPackets * 12)) return rc;
+	if(int rc = hc.put(&d, dir, nq * 48)) return rc;
+	if(int rc = hc.put(&i, idir, nq * 48)) return rc;
+	if(int rc = hc.put(&ds, distance, nq * 16)) return rc;
+	if(stats) { if(int rc = hc.zeroStats()) return rc; }
+	{
+		SNAIL_LOCK(s);
+		if(int rc = launchRays(s, true, nPackets, size, 1, (float *)o, (float *)d, (float *)i, nullptr, (float *)ds, nullptr, nullptr, stats ? hc.stats() : nullptr, hc.stream())) return rc;
 	}
-	if(stats) HIP_TRY(hipMemset(s->dStats, 0, 32));
-	int rc = launchRays(s, true, nPackets, size, 1, (float *)o.p, (float *)d.p, (float *)i.p, nullptr, (float *)ds.p, nullptr, nullptr,
-						stats ? (uint64_t *)s->dStats : nullptr, 0);
-	if(rc) return rc;
-	HIP_TRY(hipDeviceSynchronize());
-	if(ds.download(distance, nq * 16)) { snail_set_error("snail_trace_shadow: download failed"); return 2; }
-	if(stats) {
-		unsigned long long hs[4];
-		HIP_TRY(hipMemcpy(hs, s->dStats, 32, hipMemcpyDeviceToHost));
-		for(int k = 0; k < 4; k++) stats[k] += hs[k];
-	}
-	return 0;
+	if(int rc = hc.get(distance, ds, nq * 16)) return rc;
+	return hc.finish(stats);
 }
 
 static int renderWhitted(const char *fn, SnailScene *s, const float cam[13], int resx, int resy, const int32_t *dPacketXY, int nPacketsList, const float *lights7,
@@ -1097,11 +1193,15 @@ static int renderWhitted(const char *fn, SnailScene *s, const float cam[13], int
 
 int snail_render_whitted_dev(SnailScene *s, const float cam[13], int resx, int resy, const float *lights7, int nLights, const float ambient[3],
 							 const float color[3], int flags, uint8_t *frame, int pitch, uint64_t *dStats, void *stream) {
+	if(int rc = checkScene(s, "snail_render_whitted_dev")) return rc;
+	SNAIL_LOCK(s);
 	return renderWhitted("snail_render_whitted_dev", s, cam, resx, resy, nullptr, 0, lights7, nLights, ambient, color, flags, frame, pitch, nullptr, dStats, stream);
 }
 
 int snail_render_whitted_ordered_dev(SnailScene *s, const float cam[13], int resx, int resy, const float *lights7, int nLights, const float ambient[3],
 									 const float color[3], int flags, uint8_t *frame, int pitch, uint64_t *dStats, const int32_t *dOrder, int32_t *dSlotCost, void *stream) {
+	if(int rc = checkScene(s, "snail_render_whitted_ordered_dev")) return rc;
+	SNAIL_LOCK(s);
 	return renderWhitted("snail_render_whitted_ordered_dev", s, cam, resx, resy, nullptr, 0, lights7, nLights, ambient, color, flags, frame, pitch, nullptr, dStats, stream,
 						 nullptr, dOrder, dSlotCost);
 }
@@ -1110,6 +1210,8 @@ int snail_render_whitted_packets_dev(SnailScene *s, const float cam[13], int res
 									 int nLights, const float ambient[3], const float color[3], int flags, uint8_t *bgrPackets, uint64_t *dStats, void *stream) {
 	if(!dPacketXY && nPackets > 0) { snail_set_error("snail_render_whitted_packets_dev: null packet list"); return 1; }
 	if(nPackets <= 0) return 0;
+	if(int rc = checkScene(s, "snail_render_whitted_packets_dev")) return rc;
+	SNAIL_LOCK(s);
 	return renderWhitted("snail_render_whitted_packets_dev", s, cam, resx, resy, dPacketXY, nPackets, lights7, nLights, ambient, color, flags, nullptr, 0, bgrPackets,
 						 dStats, stream);
 }
@@ -1125,6 +1227,7 @@ int snail_trace_transparency_dev(SnailScene *s, const float cam[13], int resx, i
 		return 1;
 	}
 	DeviceGuard guard(s->device);
+	SNAIL_LOCK(s);
 	dev::ShadeArgs A;
 	memset(&A, 0, sizeof(A));
 	A.nodes = s->dNodes; A.tris = s->dTris; A.pf = (const uint4 *)s->dPF;
@@ -1347,37 +1450,38 @@ int snail_debug_occupancy(int out[4]) {
 
 int snail_account_packets(SnailScene *s, const float cam[13], int resx, int resy, uint32_t *out8) {
 	if(int rc = checkScene(s, "snail_account_packets")) return rc;
-	if(!out8) { snail_set_error("snail_account_packets: null output"); return 1; }
+	if(!out8 || resx <= 0 || resy <= 0) { snail_set_error("snail_account_packets: null output or bad resolution"); return 1; }
 	DeviceGuard guard(s->device);
-	const int np = ((resx + 15) / 16) * ((resy + 15) / 16);
-	DevBuf c;
-	if(c.upload(nullptr, (size_t)np * 32)) { snail_set_error("snail_account_packets: allocation failed"); return 2; }
-	HIP_TRY(hipMemset(c.p, 0, (size_t)np * 32));
-	int rc = launchPrimary(s, cam, resx, resy, 0, 0, resx, resy, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, (unsigned *)c.p);
-	if(rc) return rc;
-	HIP_TRY(hipDeviceSynchronize());
-	if(c.download(out8, (size_t)np * 32)) { snail_set_error("snail_account_packets: download failed"); return 2; }
-	return 0;
+	HostCallScope hc(s, "snail_account_packets");
+	if(hc.rc) return hc.rc;
+	const size_t bytes = (size_t)((resx + 15) / 16) * ((resy + 15) / 16) * 32;
+	if(int rc = hc.reserve(HostCallScope::pad(bytes))) return rc;
+	void *c = hc.carve(bytes);
+	HIP_TRY(hipMemsetAsync(c, 0, bytes, hc.stream()));
+	{
+		SNAIL_LOCK(s);
+		if(int rc = launchPrimary(s, cam, resx, resy, 0, 0, resx, resy, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, hc.stream(), (unsigned *)c)) return rc;
+	}
+	if(int rc = hc.get(out8, c, bytes)) return rc;
+	return hc.finish(nullptr);
 }
 
 int snail_account_primary(SnailScene *s, const float cam[13], int resx, int resy, int x0, int y0, int w, int h, uint64_t out[4]) {
 	if(int rc = checkScene(s, "snail_account_primary")) return rc;
 	if((x0 & 15) || (y0 & 15) || w <= 0 || h <= 0 || !out) { snail_set_error("snail_account_primary: bad rect"); return 1; }
 	DeviceGuard guard(s->device);
+	HostCallScope hc(s, "snail_account_primary");
+	if(hc.rc) return hc.rc;
 	dev::AccountArgs A;
 	A.nodes = s->dNodes; A.tris = s->dTris;
 	A.g = makeGen(cam, resx, resy);
 	A.x0 = x0; A.y0 = y0; A.pw = (w + 15) / 16; A.ph = (h + 15) / 16;
-	A.out = (dev::u64 *)s->dStats;
-	HIP_TRY(hipMemset(s->dStats, 0, 32));
+	A.out = (dev::u64 *)hc.stats();
+	if(int rc = hc.zeroStats()) return rc;
 	const int np = A.pw * A.ph;
-	hipLaunchKernelGGL(dev::k_account, dim3((np + 3) / 4), dim3(256), 0, 0, A);
+	hipLaunchKernelGGL(dev::k_account, dim3((np + 3) / 4), dim3(256), 0, hc.stream(), A);
 	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipDeviceSynchronize());
-	unsigned long long hs[4];
-	HIP_TRY(hipMemcpy(hs, s->dStats, 32, hipMemcpyDeviceToHost));
-	for(int k = 0; k < 4; k++) out[k] += hs[k];
-	return 0;
+	return hc.finish(out);
 }
 
 } // extern "C"

@@ -468,6 +468,18 @@ class Scene:
         _lib.check(rc, "snail_trace_primary")
         return t, u, v, tid, stats
 
+    def trace_frame_packets_host(self, cam: Camera, resx: int, resy: int):
+        """snail_trace_frame_packets: the whole frame's primary packets with host outputs in PACKET-MAJOR order ([packets, 256], the reference's quad
+        order) -- the Context arrays a host's per-packet loop reads; rays of edge packets outside the image included.  Returns (t, u, v, triId, stats)."""
+        n = ((resx + 15) // 16) * ((resy + 15) // 16)
+        t = np.zeros((n, 256), dtype=np.float32); u = np.zeros((n, 256), dtype=np.float32); v = np.zeros((n, 256), dtype=np.float32)
+        tid = np.zeros((n, 256), dtype=np.int32)
+        stats = np.zeros(4, dtype=np.uint64)
+        cam13 = np.ascontiguousarray(cam.as_array13(), dtype=np.float32)
+        rc = _lib.lib().snail_trace_frame_packets(self._h, _lib.ptr(cam13), resx, resy, _lib.ptr(t), _lib.ptr(u), _lib.ptr(v), _lib.ptr(tid), _lib.ptr(stats))
+        _lib.check(rc, "snail_trace_frame_packets")
+        return t, u, v, tid, stats
+
     # ---- generic / shadow packets -------------------------------------------------------------
     def traverse_primary(self, ctx: Context, stats=None, stream=None) -> Context:
         rc = _lib.lib().snail_trace_rays_dev(self._h, ctx.n_packets, ctx.size, int(ctx.shared_origin), _lib.ptr(ctx.origin), _lib.ptr(ctx.dir),

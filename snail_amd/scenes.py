@@ -324,6 +324,52 @@ def patches(n: int = 6) -> np.ndarray:
     return np.asarray(tris, dtype=F32)
 
 
+OFFGRID_ORIGIN = (137.731, -61.377, 419.173)
+
+
+def offgrid(seed: int = 11, n_blob: int = 4000) -> np.ndarray:
+    """Geometry OFF every grid (the procedural scenes above are snapped to k/1024, where `ba`, `ca`, box extents and many `bmin - o` terms are
+    exact; a scanned mesh like the reference's lancia.obj is not): every coordinate is a float64 random value rounded once to float32 -- full
+    mantissas -- around an origin far from zero (|x| ~ 60 .. 420: one ulp is 4e-6 .. 3e-5, so sums and differences round), with
+      * a blob of randomly oriented triangles whose sizes span four decades (1e-3 .. 10 units),
+      * slivers (aspect ratio ~1e4) in random directions,
+      * a wavy sheet tessellated with irrational steps (coherent surfaces for the packets to narrow on),
+      * shingles: near-coplanar triangles overlapping their neighbours with offsets of a few ulps (near-ties in t between candidates).
+    Deterministic in `seed`; ~10 K triangles."""
+    rng = np.random.RandomState(seed)
+    O = np.asarray(OFFGRID_ORIGIN, dtype=np.float64)
+    parts = []
+    # blob: centre in a 30-unit cube, size log-uniform over 1e-3 .. 10
+    c = O[None, :] + rng.uniform(-15.0, 15.0, size=(n_blob, 3))
+    size = np.exp(rng.uniform(math.log(1e-3), math.log(10.0), size=n_blob))
+    e = rng.randn(n_blob, 3, 3)
+    parts.append(c[:, None, :] + e * size[:, None, None] * 0.5)
+    # slivers: a long edge of 2 .. 8 units, the third vertex 1e-4 .. 1e-3 of that off its middle
+    ns = 1500
+    a = O[None, :] + rng.uniform(-15.0, 15.0, size=(ns, 3))
+    d = rng.randn(ns, 3); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    ln = rng.uniform(2.0, 8.0, size=ns)
+    w = rng.randn(ns, 3); w -= (w * d).sum(axis=1, keepdims=True) * d; w /= np.linalg.norm(w, axis=1, keepdims=True)
+    b = a + d * ln[:, None]
+    m = a + d * (ln * rng.uniform(0.2, 0.8, size=ns))[:, None] + w * (ln * np.exp(rng.uniform(math.log(1e-4), math.log(1e-3), size=ns)))[:, None]
+    parts.append(np.stack([a, b, m], axis=1))
+    # wavy sheet, steps pi / 29 and e / 23, through the middle of the blob
+    nu, nv = 44, 36
+    us, vs = np.meshgrid(np.arange(nu + 1) * (math.pi / 29.0), np.arange(nv + 1) * (math.e / 23.0), indexing="ij")
+    p = np.stack([O[0] - 2.3 + us, O[1] - 1.9 + vs + 0.21 * np.sin(us * 3.1), O[2] + 0.37 * np.sin(us * 2.3) * np.cos(vs * 1.7) + 0.05 * us], axis=-1)
+    qa, qb, qc, qd = p[:-1, :-1], p[1:, :-1], p[1:, 1:], p[:-1, 1:]
+    parts.append(np.concatenate([np.stack([qa, qb, qc], axis=-2).reshape(-1, 3, 3), np.stack([qc, qd, qa], axis=-2).reshape(-1, 3, 3)], axis=0))
+    # shingles: rows of overlapping triangles in ONE plane (a random tilt), each a few ulps of the plane's distance above the last
+    nsh = 1200
+    nrm = np.array([0.31, 0.83, -0.46]); nrm /= np.linalg.norm(nrm)
+    t1 = np.cross(nrm, [0.0, 0.0, 1.0]); t1 /= np.linalg.norm(t1); t2 = np.cross(nrm, t1)
+    base = O + np.array([3.7, -2.1, -6.3])
+    k = np.arange(nsh)
+    org = base[None, :] + t1[None, :] * (0.173 * (k % 40))[:, None] + t2[None, :] * (0.291 * (k // 40))[:, None] + nrm[None, :] * (k * 6.0e-5)[:, None]
+    parts.append(np.stack([org, org + t1 * 0.41 + t2 * 0.07, org + t1 * 0.11 + t2 * 0.53], axis=1))
+    return np.ascontiguousarray(np.concatenate(parts, axis=0).astype(F32))
+
+
 def drop_degenerate(tri_verts: np.ndarray) -> np.ndarray:
     """Apply Object::Repair to an explicit triangle soup (generators can emit zero-area faces)."""
     tv = np.asarray(tri_verts, dtype=F32)
@@ -348,6 +394,8 @@ def scene_by_name(name: str, scenes_dir: str | None = None) -> np.ndarray:
         return chain()
     if name.startswith("patches"):
         return patches()
+    if name.startswith("offgrid"):
+        return drop_degenerate(offgrid())
     path = name
     if not os.path.exists(path) and scenes_dir:
         path = os.path.join(scenes_dir, name)

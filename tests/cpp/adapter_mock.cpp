@@ -12,10 +12,14 @@
 //   out_ry_batch.bin  all secondary packets through snail::RayBatch (one call)
 //   out_tiles.bin     Render(scene, camera, resx, resy, data, coords, offsets, options, rank, threads)   -- the reference's signature
 //   out_image.bin     Render(scene, camera, image, options, threads)                                      -- the reference's signature
+//   out_sh_thr.bin    all shadow packets, one HipBVH::TraverseShadow call each, from 8 std::threads at once on the ONE scene
+//   out_ry_thr.bin    all secondary packets, one HipBVH::TraversePrimary(Context<0,1>) call each, from the same 8 threads (the reference's
+//                     Render(..., threads) shares one const Scene over its pthread workers: src/render.cpp:214-267, src/thread_pool.cpp:151-180)
 //   stats.txt         the TreeStats each of them returned / accumulated
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <thread>
 #include <vector>
 
 // ---- mock reference types (names and members as in the reference) ----
@@ -184,6 +188,51 @@ int main(int argc, char **argv) {
 		batch.Flush(acc, &st1);
 		f = std::fopen((d + "out_ry_batch.bin").c_str(), "wb"); dump(f, dist); dump(f, obj); dump(f, bary); std::fclose(f);
 		std::fprintf(fs, "rays_imm %u %u %u %u\nrays_batch %u %u %u %u\n", st0.in, st0.it, 0u, st0.sk, st1.in, st1.it, 0u, st1.sk);
+	}
+	if(nSh > 0 && nRy > 0) { // ---- the immediate path from 8 threads at once on one scene: every thread its own packets, results and TreeStats ----
+		const std::vector<float> o3 = slurp<float>(d + "sh_origin.bin");
+		const std::vector<Vec3q> sdir = slurp<Vec3q>(d + "sh_dir.bin"), sidir = slurp<Vec3q>(d + "sh_idir.bin");
+		std::vector<floatq> sdist = slurp<floatq>(d + "sh_dist.bin");
+		std::vector<Vec3q> sorg((size_t)nSh);
+		for(int p = 0; p < nSh; p++) for(int l = 0; l < 4; l++) { sorg[p].x[l] = o3[p * 3]; sorg[p].y[l] = o3[p * 3 + 1]; sorg[p].z[l] = o3[p * 3 + 2]; }
+		const std::vector<Vec3q> rorg = slurp<Vec3q>(d + "ry_origin.bin"), rdir = slurp<Vec3q>(d + "ry_dir.bin"), ridir = slurp<Vec3q>(d + "ry_idir.bin");
+		std::vector<char> rmask = slurp<char>(d + "ry_mask.bin");
+		std::vector<floatq> rdist = slurp<floatq>(d + "ry_dist.bin");
+		std::vector<i32x4> robj((size_t)nRy * 64, i32x4{{0, 0, 0, 0}});
+		std::vector<Vec2q> rbary((size_t)nRy * 64, Vec2q{{0, 0, 0, 0}, {0, 0, 0, 0}});
+		constexpr int kThreads = 8, kRounds = 3;   // (rounds: the same packets again from a fresh copy of the inputs -- more calls in flight per thread)
+		std::vector<TreeStats> shStats(kThreads), ryStats(kThreads);
+		const std::vector<floatq> sdist0 = sdist, rdist0 = rdist;
+		const snail::HipBVH<MockBVH> &cacc = acc;
+		std::vector<std::thread> pool;
+		for(int k = 0; k < kThreads; k++)
+			pool.emplace_back([&, k] {
+				for(int round = 0; round < kRounds; round++) {
+					for(int p = k; p < nSh; p += kThreads) {
+						std::copy(sdist0.begin() + p * 64, sdist0.begin() + (p + 1) * 64, sdist.begin() + p * 64);
+						TreeStats st;
+						ShadowContext c{{&sorg[p], sdir.data() + p * 64, sidir.data() + p * 64, 64, nullptr}, sdist.data() + p * 64, &st};
+						cacc.TraverseShadow(c);
+						if(round == 0) { shStats[k].in += st.in; shStats[k].it += st.it; shStats[k].sk += st.sk; }
+					}
+					for(int p = k; p < nRy; p += kThreads) {
+						std::copy(rdist0.begin() + p * 64, rdist0.begin() + (p + 1) * 64, rdist.begin() + p * 64);
+						std::fill(robj.begin() + p * 64, robj.begin() + (p + 1) * 64, i32x4{{0, 0, 0, 0}});
+						std::fill(rbary.begin() + p * 64, rbary.begin() + (p + 1) * 64, Vec2q{{0, 0, 0, 0}, {0, 0, 0, 0}});
+						TreeStats st;
+						Context<0, 1> c{{rorg.data() + p * 64, rdir.data() + p * 64, ridir.data() + p * 64, 64, rmask.data() + p * 64}, rdist.data() + p * 64, robj.data() + p * 64,
+										 nullptr, rbary.data() + p * 64, &st};
+						cacc.TraversePrimary(c);
+						if(round == 0) { ryStats[k].in += st.in; ryStats[k].it += st.it; ryStats[k].sk += st.sk; }
+					}
+				}
+			});
+		for(std::thread &t : pool) t.join();
+		TreeStats sh, ry;
+		for(int k = 0; k < kThreads; k++) { sh.in += shStats[k].in; sh.it += shStats[k].it; sh.sk += shStats[k].sk; ry.in += ryStats[k].in; ry.it += ryStats[k].it; ry.sk += ryStats[k].sk; }
+		FILE *f = std::fopen((d + "out_sh_thr.bin").c_str(), "wb"); dump(f, sdist); std::fclose(f);
+		f = std::fopen((d + "out_ry_thr.bin").c_str(), "wb"); dump(f, rdist); dump(f, robj); dump(f, rbary); std::fclose(f);
+		std::fprintf(fs, "shadow_thr %u %u %u %u\nrays_thr %u %u %u %u\n", sh.in, sh.it, 0u, sh.sk, ry.in, ry.it, 0u, ry.sk);
 	}
 	{ // ---- the tile API with the reference's signatures ----
 		gVals[7] = meta[5]; gVals[1] = meta[6];

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
 
-MODE_IEEE, MODE_SSE = 0, 1
+MODE_IEEE, MODE_SSE, MODE_TABLE = 0, 1, 2      # MODE_TABLE: the SSE definitions over the rcpps / rsqrtps tables given to set_tables()
 
 TRI_DTYPE = np.dtype([("a", "<f4", 3), ("ba", "<f4", 3), ("ca", "<f4", 3), ("t0", "<f4"), ("it0", "<f4"),
                       ("pad", "<i4"), ("plane", "<f4", 4)])
@@ -55,6 +55,9 @@ def lib():
         for f in (L.orc_inv, L.orc_rsqrt):
             f.argtypes = [C.c_float, i32]
             f.restype = C.c_float
+        L.orc_set_tables.argtypes = [vp]
+        L.orc_tables_of_this_cpu.argtypes = [vp]
+        L.orc_raw_approx.argtypes = [i32, i32, vp, vp, i32]
         for f in (L.orc_min, L.orc_max):
             f.argtypes = [C.c_float, C.c_float]
             f.restype = C.c_float
@@ -64,6 +67,26 @@ def lib():
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def set_tables(tables) -> None:
+    """MODE_TABLE's rcpps / rsqrtps tables (uint32 [3, 4096]: tests/golden/rcp_tables.npz entries, or tables_of_this_cpu()); process-wide."""
+    tab = np.ascontiguousarray(tables, dtype=np.uint32).reshape(3 * 4096)
+    lib().orc_set_tables(_p(tab))
+
+
+def tables_of_this_cpu() -> np.ndarray:
+    tab = np.zeros((3, 4096), dtype=np.uint32)
+    lib().orc_tables_of_this_cpu(_p(tab))
+    return tab
+
+
+def raw_approx(fn: int, bits: np.ndarray, table: bool) -> np.ndarray:
+    """rcpps (fn 0) / rsqrtps (fn 1) of float bit patterns: by MODE_TABLE's rule over the tables in force, or by this host's instruction."""
+    x = np.ascontiguousarray(bits, dtype=np.uint32)
+    out = np.zeros_like(x)
+    lib().orc_raw_approx(fn, 1 if table else 0, _p(x), _p(out), len(x))
+    return out
 
 
 def tris_from_verts(tri_verts: np.ndarray) -> np.ndarray:

@@ -13,7 +13,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 focus = sys.argv[3] if len(sys.argv) > 3 else ""
 rng = np.random.RandomState(seed)
-names = ["atrium:0.05", "stress:0.05", "box", "chain", "atrium:0.02"]
+names = ["atrium:0.05", "stress:0.05", "box", "chain", "atrium:0.02", "offgrid"]   # offgrid: full-mantissa vertices, slivers, four decades of sizes, far from the origin
 scn = {}
 for n in names:
     tv, hb, osc = util.scene_pair(n)

@@ -56,6 +56,8 @@ def test_device_reproduces_the_hosts_rcpps_and_rsqrtps_for_every_float(torch_mod
     ("chain", 256, 144),          # depth-63 tree: the DEEP kernels of the second arithmetic
     ("stress:0.05", 320, 192),
     ("patches", 200, 120),        # the narrow-range leaf forms at every width
+    ("offgrid", 640, 400),        # geometry off every grid (scenes.offgrid), far camera
+    ("offgrid-in", 328, 200),     # ... and from inside
 ])
 def test_primary_frame_bit_exact_in_host_sse(torch_mod, name, resx, resy):
     tv, sc, osc = sse_scene(name)

@@ -51,6 +51,8 @@ def compare_frames(frame, oracle_out, what):
     ("stress:0.05", 320, 192),
     ("patches", 96, 96),          # squares covering 1 .. 64 quads of a packet: the narrow-range leaf forms at every width
     ("patches", 200, 120),
+    ("offgrid", 640, 400),        # full-mantissa vertices far from the origin, four decades of triangle sizes, slivers, near-coplanar shingles (scenes.offgrid)
+    ("offgrid-in", 328, 200),     # the same from inside
 ])
 def test_primary_frame_bit_exact(torch_mod, name, resx, resy):
     tv, sc, osc = gpu_scene(name)
@@ -597,7 +599,7 @@ def test_cpp_adapter_end_to_end(torch_mod, tmp_path, refl, depth_mode, host_sse)
     lights = np.array([[c[0], c[1] + 0.35 * e[1], c[2], 1.0, 0.9, 0.8, 2.0 * float(e.max())],
                        [c[0] - 0.3 * e[0], c[1] + 0.1 * e[1], c[2] + 0.2 * e[2], 0.3, 0.5, 1.0, 0.6 * float(e.max())]], dtype=np.float32)
     lights.tofile(str(d / "lights.bin"))
-    n_sh, n_ry = 5, 4
+    n_sh, n_ry = 19, 13                         # (odd counts: the 8 threads of the concurrency case get uneven shares)
     so, sd, si, sdist = util.shadow_packets(osc, n_sh, 71)
     for nm, a in (("sh_origin", so), ("sh_dir", sd), ("sh_idir", si), ("sh_dist", sdist)):
         a.tofile(str(d / (nm + ".bin")))
@@ -640,6 +642,15 @@ def test_cpp_adapter_end_to_end(torch_mod, tmp_path, refl, depth_mode, host_sse)
     raw = np.fromfile(str(d / "out_ry_imm.bin"), dtype=np.uint8)
     util.assert_bit_equal(raw[:64 * 16].view(np.float32).reshape(-1, 4), wd[:64], "rays immediate dist")
     util.assert_bit_equal(raw[64 * 16:64 * 32].view(np.int32).reshape(-1, 4), wo[:64], "rays immediate obj")
+    # the reference's concurrency contract (src/render.cpp:214-267, src/thread_pool.cpp:151-180: `threads` workers share ONE const scene): the same
+    # packets, one TraverseShadow / TraversePrimary<0,1> call each, from 8 threads at once -- every packet and the summed TreeStats are the oracle's
+    util.assert_bit_equal(np.fromfile(str(d / "out_sh_thr.bin"), dtype=np.float32).reshape(-1, 4), want, "shadow, 8 threads")
+    assert stats["shadow_thr"] == stats["shadow_batch"]
+    raw = np.fromfile(str(d / "out_ry_thr.bin"), dtype=np.uint8)
+    util.assert_bit_equal(raw[:nq * 16].view(np.float32).reshape(-1, 4), wd, "rays, 8 threads, dist")
+    util.assert_bit_equal(raw[nq * 16:nq * 32].view(np.int32).reshape(-1, 4), wo, "rays, 8 threads, obj")
+    util.assert_bit_equal(raw[nq * 32:].view(np.float32).reshape(-1, 8), wb, "rays, 8 threads, bary")
+    assert stats["rays_thr"][:2] == [int(wst[0]), int(wst[1])]
     # the tile API: planar bytes per tile and the rgb8 image, against the oracle's frame
     if depth_mode:
         want_frame = O.shade_depth(ref[0], mode=MODE).reshape(resy, resx, 3)
@@ -857,7 +868,8 @@ def test_rccl_code_path_single_rank(torch_mod):
     assert d["audit_ok"], d
 
 
-@pytest.mark.parametrize("name,resx,resy,nl,refl", [("atrium:0.05", 640, 368, 2, False), ("atrium:0.05", 250, 130, 1, False), ("box", 256, 256, 1, False),
+@pytest.mark.parametrize("name,resx,resy,nl,refl", [("offgrid-in", 328, 200, 2, True), ("offgrid", 320, 192, 1, False),
+                                                     ("atrium:0.05", 640, 368, 2, False), ("atrium:0.05", 250, 130, 1, False), ("box", 256, 256, 1, False),
                                                      ("stress:0.05", 320, 192, 3, False), ("atrium:0.05", 320, 192, 0, False),
                                                      ("atrium:0.05", 640, 368, 2, True), ("atrium:0.05", 250, 130, 0, True), ("box", 256, 256, 1, True),
                                                      ("stress:0.05", 320, 192, 3, True), ("chain", 128, 96, 1, True)])

@@ -221,7 +221,7 @@ def build_adapter_mock(tmp_path):
     import subprocess
     exe = str(tmp_path / "adapter_mock")
     libdir = os.path.join(ROOT, "snail_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", os.path.join(ROOT, "tests", "cpp", "adapter_mock.cpp"), "-o", exe,
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-pthread", os.path.join(ROOT, "tests", "cpp", "adapter_mock.cpp"), "-o", exe,
                            "-L" + libdir, "-lsnailhip", "-Wl,-rpath," + libdir])
     return exe
 

@@ -27,6 +27,8 @@ def camera_for(name: str, tv):
         return FPSCamera(pos, ang, pitch).camera()
     if name.startswith("patches"):   # head-on, one board cell = 16 x 16 pixels at 96 x 96 (board 6 x 6, plane_dist 1: the board spans +-3 at distance 3 * ...)
         return FPSCamera(np.array([3.0, 3.0, -6.0], dtype=np.float32), 0.0, 0.0).camera()
+    if name.startswith("offgrid-in"):   # inside the blob, looking +z through it (the plain name: the survey's far camera)
+        return FPSCamera((np.asarray(scenes.OFFGRID_ORIGIN, dtype=np.float32) + np.array([0.0, 0.0, -9.0], dtype=np.float32)), 0.0, 0.0).camera()
     if name.startswith("chain"):
         return FPSCamera(np.array([-0.25, 0.004, 0.002], dtype=np.float32), -math.pi / 2, 0.0).camera()   # looking down +x through the chain
     return survey_camera(tv)
