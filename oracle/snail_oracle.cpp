@@ -420,11 +420,16 @@ bool collideShadow(const OrcTri &t, const Rays &r, float *dist, int first, int l
 
 struct Stats { uint64_t intersects = 0, iters = 0, rays = 0, skips = 0; };
 
-struct StackElem { int node; short first, last; };
+struct StackElem { int node; short first, last; short failsAtPush = 0; /* instrumentation only (g_farHist) */ };
 
 // optional instrumentation (tests/range_hist.py): [0,64) inner visits by (last-first) on entry, [64,128) leaf visits likewise,
 // [128,192) leaf visits by (last-first) after the box test.  Single-threaded use only.
 uint64_t *g_rangeHist = nullptr;
+// optional instrumentation (tests/far_child_hist.py; round 5's question: how many visits would a reject-only test of the FAR child at push time save?):
+// per packet kind k (0 = shared origin, 1 = per-ray origins) and width w = last - first of the pushed range, four counters at [(k * 64 + w) * 4 + ..]:
+// +0 far-child entries popped, +1 of those whose box test fails at the pop, +2 of those that fail with the distances of the PUSH already (no lane of the
+// pushed range passes then: it cannot pass later, distances only shrink), +3 all node visits that start with that range width.  Single-threaded use only.
+uint64_t *g_farHist = nullptr;
 
 // src/bvh/traverse.cpp:14-80
 template <int MODE>
@@ -434,12 +439,23 @@ void traversePrimary(const OrcNode *nodes, const OrcTri *tris, const Rays &r, fl
 	int sign[3] = {r.D(0, 0, 0) < 0.0f, r.D(0, 1, 0) < 0.0f, r.D(0, 2, 0) < 0.0f};
 	Interval iv = makeInterval(r, nullptr);
 
+	bool root = true;
 	while(sp) {
 		int nNode = stack[--sp].node, first = stack[sp].first, last = stack[sp].last;
+		uint64_t *fh = (g_farHist && !root) ? g_farHist + ((r.shared ? 0 : 64) + (last - first)) * 4 : nullptr;   // this entry is a popped far child
+		const bool failedAtPush = stack[sp].failsAtPush != 0;
+		root = false;
+		if(fh) fh[0]++;
 		for(;;) {
 			st.iters++;
 			const OrcNode &n = nodes[nNode];
 			if(g_rangeHist) g_rangeHist[((n.sub & 0x80000000u) ? 64 : 0) + (last - first)]++;
+			if(g_farHist) g_farHist[((r.shared ? 0 : 64) + (last - first)) * 4 + 3]++;
+			if(fh) {   // the popped node's own test, repeated without side effects
+				int f2 = first, l2 = last;
+				if(!(boxTestInterval(n, iv) && boxTest<false>(n, r, dist, f2, l2))) { fh[1]++; if(failedAtPush) fh[2]++; }
+				fh = nullptr;
+			}
 			if(n.sub & 0x80000000u) {
 				int count = n.aux, firstTri = (int)(n.sub & 0x7fffffffu);
 				if(!boxTestInterval(n, iv)) break;
@@ -458,6 +474,11 @@ void traversePrimary(const OrcNode *nodes, const OrcTri *tris, const Rays &r, fl
 			if(!boxTest<false>(n, r, dist, first, last)) break;
 			int child = (int)n.sub, axis = n.aux & 0xffff, firstNode = (n.aux >> 16) ^ sign[axis];
 			stack[sp++] = StackElem{child + (firstNode ^ 1), (short)first, (short)last};
+			if(g_farHist) {
+				const OrcNode &far = nodes[child + (firstNode ^ 1)];
+				int f2 = first, l2 = last;
+				stack[sp - 1].failsAtPush = !(boxTestInterval(far, iv) && boxTest<false>(far, r, dist, f2, l2));
+			}
 			nNode = child + firstNode;
 		}
 	}
@@ -1061,6 +1082,7 @@ void orc_planar_decode_tile(const uint8_t *planes, int x, int y, int w, int h, u
 	}
 }
 void orc_debug_range_hist(uint64_t *hist) { g_rangeHist = hist; }
+void orc_debug_far_hist(uint64_t *hist512) { g_farHist = hist512; }
 unsigned orc_caller_mxcsr(void) { return _mm_getcsr(); } // diagnostics: what the calling thread runs with (0x1f80 = default)
 void orc_debug_set_mxcsr(unsigned v) { _mm_setcsr(v); } // tests: put the calling thread into flush-to-zero mode (0x9fc0) and back (0x1f80)
 // The named shading expressions on one row of eight floats (qa = in[0..3], qb = in[4..7] as two SSE quads; v1 = (qa, qa<<<1, qa<<<2),

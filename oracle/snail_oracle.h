@@ -144,6 +144,7 @@ void orc_planar_decode_tile(const uint8_t *planes, int x, int y, int w, int h, u
 
 /* instrumentation for tests/range_hist.py: hist[192] (see snail_oracle.cpp); NULL switches it off. Single-threaded only. */
 void orc_debug_range_hist(uint64_t *hist);
+void orc_debug_far_hist(uint64_t *hist512); /* tests/far_child_hist.py: [kind(2)][width(64)][4] counters, see snail_oracle.cpp g_farHist */
 void orc_debug_set_mxcsr(unsigned v); /* tests only */
 unsigned orc_caller_mxcsr(void); /* diagnostics: MXCSR of the calling thread (0x1f80 = default; every entry point above computes under the default) */
 

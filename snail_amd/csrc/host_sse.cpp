@@ -8,15 +8,25 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+#if defined(__x86_64__) || defined(__i386__)
 #include <xmmintrin.h>
+#define SNAIL_HAVE_SSE 1
+#else
+#define SNAIL_HAVE_SSE 0   // not an x86 host: no rcpps / rsqrtps to take tables from -- SNAIL_ARITH_HOST_SSE then needs GIVEN tables (snail_arith_set_tables)
+#endif
 
 namespace {
 
 inline unsigned bitsOf(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 inline float floatOf(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 // the instructions exactly as veclib reaches them: _mm_rcp_ps / _mm_rsqrt_ps on a broadcast value (veclib/sse/base.h:84-92)
+#if SNAIL_HAVE_SSE
 inline unsigned rcpInsn(unsigned x) { return bitsOf(_mm_cvtss_f32(_mm_rcp_ps(_mm_set1_ps(floatOf(x))))); }
 inline unsigned rsqrtInsn(unsigned x) { return bitsOf(_mm_cvtss_f32(_mm_rsqrt_ps(_mm_set1_ps(floatOf(x))))); }
+#else
+inline unsigned rcpInsn(unsigned) { return 0; }
+inline unsigned rsqrtInsn(unsigned) { return 0; }
+#endif
 
 struct Tables {
 	unsigned tab[3 * kHostSseEntries];
@@ -33,6 +43,7 @@ unsigned g_generation = 1;
 
 void buildTables() {
 	Tables &T = g_tables;
+	if(!SNAIL_HAVE_SSE) { snprintf(T.why, sizeof T.why, "this host is not an x86 CPU: it has no rcpps / rsqrtps (give the tables of the CPU to reproduce: snail_arith_set_tables)"); return; }
 	const unsigned base[3] = {0x3f800000u, 0x3f800000u, 0x40000000u};   // [1, 2) for rcpps and the even-exponent rsqrtps table, [2, 4) for the odd one
 	for(int f = 0; f < 3; f++) {
 		unsigned *tab = T.tab + f * kHostSseEntries;
@@ -79,20 +90,33 @@ template <class F> void parallelFor(unsigned long long n, int threads, F fn) {
 
 } // namespace
 
-const unsigned *hostSseTables(const char **why) {
-	{
-		std::lock_guard<std::mutex> lock(g_givenMu);
-		if(g_haveGiven) { if(why) *why = ""; return g_given.tab; }
-	}
+// (this CPU's own tables never change once built: the pointer may be read without the lock; GIVEN tables are only ever handed out as a copy)
+static const unsigned *ownTables(const char **why) {
 	std::call_once(g_once, buildTables);
 	if(why) *why = g_tables.why;
 	return g_tables.ok ? g_tables.tab : nullptr;
 }
 
-unsigned hostSseGeneration() {
+int hostSseSnapshot(unsigned *out, unsigned *generation, const char **why) {
+	if(why) *why = "";
+	{
+		std::lock_guard<std::mutex> lock(g_givenMu);
+		if(g_haveGiven) {
+			if(out) memcpy(out, g_given.tab, sizeof g_given.tab);
+			if(generation) *generation = g_generation;
+			return 0;
+		}
+	}
+	const unsigned *own = ownTables(why);
+	if(!own) return 2;
 	std::lock_guard<std::mutex> lock(g_givenMu);
-	return g_generation;
+	if(g_haveGiven) {   // (given between the two looks: the given ones are in force)
+		if(out) memcpy(out, g_given.tab, sizeof g_given.tab);
+	} else if(out) memcpy(out, own, sizeof g_tables.tab);
+	if(generation) *generation = g_generation;
+	return 0;
 }
+
 
 int hostSseSetTables(const unsigned *tab, const char **why) {
 	std::lock_guard<std::mutex> lock(g_givenMu);
@@ -116,8 +140,9 @@ int hostSseSetTables(const unsigned *tab, const char **why) {
 }
 
 unsigned long long hostSseMismatches(int fn, unsigned long long first, unsigned long long count, int threads, unsigned *firstBad) {
-	const unsigned *tab = hostSseTables(nullptr);
-	if(!tab) return ~0ull;
+	std::vector<unsigned> snap((size_t)3 * kHostSseEntries);
+	if(hostSseSnapshot(snap.data(), nullptr, nullptr)) return ~0ull;
+	const unsigned *tab = snap.data();
 	std::vector<unsigned long long> bad((size_t)(threads < 1 ? 1 : threads), 0ull);
 	std::vector<unsigned long long> where(bad.size(), ~0ull);
 	parallelFor(count, threads, [&](int t, unsigned long long a, unsigned long long b) {

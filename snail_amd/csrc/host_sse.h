@@ -43,14 +43,16 @@ SNAIL_HD inline unsigned sseRsqrtBits(const unsigned *tab, unsigned b) {
 	return ((unsigned)((int)(base >> 23) - half) << 23) | (base & 0x7fffffu);
 }
 
-// The tables of THIS CPU (thread-safe, built once).  Returns nullptr -- with the reason in *why -- when its rcpps / rsqrtps do not have the
-// block structure above (results that change inside an aligned block of 2^11 mantissas, or an exponent / special-case rule that differs).
-const unsigned *hostSseTables(const char **why);
-// Tables of ANOTHER CPU instead (tab = 3 x 4096 words as hostSseTables returns them; nullptr = this CPU's again): every machine of a render farm
+// The tables in force, COPIED OUT under the lock together with their generation (out: 3 x 4096 words, may be null; generation: may be null): this
+// CPU's own (taken at first use; returns 2 -- with the reason in *why -- when its rcpps / rsqrtps do not have the block structure above: results that
+// change inside an aligned block of 2^11 mantissas, or an exponent / special-case rule that differs; or when this is not an x86 host) unless
+// hostSseSetTables gave others.  The generation changes with every hostSseSetTables call: a device copy made from one snapshot is current for as long
+// as the generation it was made at is.
+int hostSseSnapshot(unsigned *out, unsigned *generation, const char **why);
+// Tables of ANOTHER CPU instead (tab = 3 x 4096 words as hostSseSnapshot returns them; nullptr = this CPU's again): every machine of a render farm
 // then computes what the reference computes on the CPU the tables came from, whatever its own CPU is.  Returns non-zero (and changes nothing)
-// for tables that are not tables of reciprocals.  hostSseGeneration() changes with every call, so that device copies are refreshed.
+// for tables that are not tables of reciprocals.
 int hostSseSetTables(const unsigned *tab, const char **why);
-unsigned hostSseGeneration();
 // Compare the emulation with the instruction over the inputs [first, first + count) on `threads` host threads; fn 0 = rcpps, 1 = rsqrtps.
 // Returns the number of inputs whose result bits differ (NaN results compare by their bits too: x86 returns the quieted input).
 unsigned long long hostSseMismatches(int fn, unsigned long long first, unsigned long long count, int threads, unsigned *firstBad);

@@ -101,6 +101,11 @@ namespace { struct TileJob; void freeTileJobs(SnailScene *); } // render_host.in
 struct SnailScene {
 	int device = 0;
 	int arith = SNAIL_ARITH_IEEE; // snail_scene_set_arith: which of the two kernel sets (dev / dev_sse) every launch of this scene takes
+	// SNAIL_ARITH_HOST_SSE: THIS scene's copy of the rcpps / rsqrtps tables (3 x 4096 words; handed to every launch as the first kernel argument word,
+	// dev_sse::hostTab()) and the generation of the process-wide tables it was filled from (host_sse.h).  Per scene, not per device: a second scene on
+	// the same device may compute with another CPU's tables, frames interleaved.
+	unsigned *dTab = nullptr;
+	unsigned tabGen = 0;
 	TileJob *tileJob = nullptr, *frameJob = nullptr;
 	int nNodes = 0, nTris = 0, depth = 0;
 	uint4 *dNodes = nullptr, *dTris = nullptr;   // the caller's records; dTris points INTO dPF (one allocation, see below)
@@ -272,21 +277,32 @@ dev::GenConst makeGen(const float cam[13], int w, int h) {
 	return g;
 }
 
-// Host-SSE arithmetic (host_sse.h): this CPU's rcpps / rsqrtps tables into the CURRENT device's copy of dev_sse::g_hostTab, once per device.
-int hostSseUpload(const char *fn) {
-	static std::mutex mu;
-	static unsigned done[64] = {};   // per device: the generation of the tables it holds (0 = none)
+// Host-SSE arithmetic (host_sse.h): the tables in force into a device buffer.  *dTab is allocated on first use (current device); when *tabGen is not
+// the generation of the tables in force, the device is drained first -- launches in flight read the buffer's old contents -- and the buffer rewritten.
+int hostSseFill(const char *fn, unsigned **dTab, unsigned *tabGen) {
 	const char *why = "";
-	const unsigned gen = hostSseGeneration();
-	const unsigned *tab = hostSseTables(&why);
-	if(!tab) { snail_set_error("%s: SNAIL_ARITH_HOST_SSE is not available on this host: %s", fn, why); return 2; }
+	std::vector<unsigned> snap((size_t)3 * kHostSseEntries);
+	unsigned gen = 0;
+	if(hostSseSnapshot(snap.data(), &gen, &why)) { snail_set_error("%s: SNAIL_ARITH_HOST_SSE is not available on this host: %s", fn, why); return 2; }
+	if(*dTab && *tabGen == gen) return 0;
+	if(!*dTab) HIP_TRY(hipMalloc((void **)dTab, snap.size() * sizeof(unsigned)));
+	HIP_TRY(hipDeviceSynchronize());   // (tables are replaced between frames, not under them: snail_arith_set_tables)
+	HIP_TRY(hipMemcpy(*dTab, snap.data(), snap.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+	*tabGen = gen;
+	return 0;
+}
+// ... for the entry points that take no scene (snail_shade_depth_arith_dev; the workbench's device check): one buffer per device, refreshed -- lazily, at
+// the call that finds it stale -- like a scene's
+int hostSseDeviceTables(const char *fn, const unsigned **out) {
+	static std::mutex mu;
+	static unsigned *tab[64] = {};
+	static unsigned gen[64] = {};
 	int devId = 0;
 	HIP_TRY(hipGetDevice(&devId));
+	if(devId < 0 || devId >= 64) { snail_set_error("%s: device index %d", fn, devId); return 1; }
 	std::lock_guard<std::mutex> lock(mu);
-	if(devId >= 0 && devId < 64 && done[devId] == gen) return 0;
-	HIP_TRY(hipDeviceSynchronize());   // (tables are replaced between frames, not under them: snail_arith_set_tables)
-	HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(dev_sse::g_hostTab), tab, sizeof(unsigned) * 3 * kHostSseEntries, 0, hipMemcpyHostToDevice));
-	if(devId >= 0 && devId < 64) done[devId] = gen;
+	if(int rc = hostSseFill(fn, &tab[devId], &gen[devId])) return rc;
+	*out = tab[devId];
 	return 0;
 }
 
@@ -423,6 +439,7 @@ int launchPrimaryFrames(SnailScene *s, const FrameSet &FS, int resx, int resy, i
 	if(FS.n < 1 || FS.n > SNAIL_MAX_BATCH || (SNAIL_BLOCK_WAVES > 1 && FS.n > 1)) { snail_set_error("snail_trace_primary: 1..%d frames per launch (got %d)", SNAIL_MAX_BATCH, FS.n); return 1; }
 	dev::PrimaryArgs A;
 	memset(&A, 0, sizeof(A));
+	A.hostTab = s->arith == SNAIL_ARITH_HOST_SSE ? s->dTab : nullptr;
 	A.nodes = s->dNodes; A.tris = s->dTris; A.pf = (const uint4 *)s->dPF;
 	A.nFrames = FS.n;
 	A.fastOK = s->fastOK;
@@ -577,6 +594,7 @@ int launchRays(SnailScene *s, bool shadow, int nPackets, int size, int sharedOri
 	if(!origin || !dir || !idir || !distance || (!shadow && !object)) { snail_set_error("null ray array"); return 1; }
 	dev::RaysArgs A;
 	memset(&A, 0, sizeof(A));
+	A.hostTab = s->arith == SNAIL_ARITH_HOST_SSE ? s->dTab : nullptr;
 	A.nodes = s->dNodes; A.tris = s->dTris; A.pf = (const uint4 *)s->dPF;
 	A.nPackets = nPackets; A.size = size; A.fastOK = s->fastOK; A.pack = stackPack(s);
 	A.origin = origin; A.dir = dir; A.idir = idir; A.mask = mask;
@@ -812,6 +830,7 @@ void snail_scene_destroy(SnailScene *s) {
 	freeTileJobs(s);
 	if(s->dNodes) (void)hipFree(s->dNodes);
 	if(s->dPF) (void)hipFree(s->dPF);   // (dTris points into it)
+	if(s->dTab) (void)hipFree(s->dTab);
 	for(auto &e : s->rel) {
 		if(e.d) (void)hipFree(e.d);
 		if(e.filled) (void)hipEventDestroy(e.filled);
@@ -854,12 +873,12 @@ int snail_scene_flags(const SnailScene *s, int *fastOK, int *nestedOK) {
 int snail_scene_set_arith(SnailScene *s, int arith) {
 	if(int rc = checkScene(s, "snail_scene_set_arith")) return rc;
 	if(arith != SNAIL_ARITH_IEEE && arith != SNAIL_ARITH_HOST_SSE) { snail_set_error("snail_scene_set_arith: unknown arithmetic %d", arith); return 1; }
+	SNAIL_LOCK(s);
 	if(arith == SNAIL_ARITH_HOST_SSE) {
 		DeviceGuard guard(s->device);
 		if(!guard.ok) { snail_set_error("snail_scene_set_arith: hipSetDevice(%d) failed", s->device); return 1; }
-		if(int rc = hostSseUpload("snail_scene_set_arith")) return rc;
+		if(int rc = hostSseFill("snail_scene_set_arith", &s->dTab, &s->tabGen)) return rc;   // the tables in force NOW: this scene's from here on
 	}
-	SNAIL_LOCK(s);
 	s->arith = arith;
 	return 0;
 }
@@ -875,15 +894,13 @@ int snail_arith_set_tables(const uint32_t *tables12288) {
 }
 int snail_host_sse_tables(uint32_t *tables12288) {
 	const char *why = "";
-	const unsigned *tab = hostSseTables(&why);
-	if(!tab) { snail_set_error("snail_host_sse_tables: %s", why); return 2; }
-	if(tables12288) memcpy(tables12288, tab, sizeof(unsigned) * 3 * kHostSseEntries);
+	if(hostSseSnapshot((unsigned *)tables12288, nullptr, &why)) { snail_set_error("snail_host_sse_tables: %s", why); return 2; }
 	return 0;
 }
 int snail_host_sse_check(int fn, uint64_t first, uint64_t count, int threads, uint64_t *mismatches, uint32_t *firstBad) {
-	if((fn != 0 && fn != 1) || first + count > (1ull << 32) || !mismatches) { snail_set_error("snail_host_sse_check: bad arguments"); return 1; }
+	if((fn != 0 && fn != 1) || first > (1ull << 32) || count > (1ull << 32) - first || !mismatches) { snail_set_error("snail_host_sse_check: bad arguments"); return 1; }
 	const char *why = "";
-	if(!hostSseTables(&why)) { snail_set_error("snail_host_sse_check: %s", why); return 2; }
+	if(hostSseSnapshot(nullptr, nullptr, &why)) { snail_set_error("snail_host_sse_check: %s", why); return 2; }
 	unsigned bad = 0;
 	*mismatches = hostSseMismatches(fn, first, count, threads, &bad);
 	if(firstBad) *firstBad = bad;
@@ -1129,6 +1146,7 @@ static int renderWhitted(const char *fn, SnailScene *s, const float cam[13], int
 	const bool refl = (flags & SNAIL_WHITTED_REFLECTIONS) != 0;
 	dev::ShadeArgs A;
 	memset(&A, 0, sizeof(A));
+	A.hostTab = s->arith == SNAIL_ARITH_HOST_SSE ? s->dTab : nullptr;
 	A.nodes = s->dNodes; A.tris = s->dTris; A.pf = (const uint4 *)s->dPF;
 	A.g = makeGen(cam, resx, resy);
 	A.resx = resx; A.resy = resy; A.pw = (resx + 15) / 16; A.ph = (resy + 15) / 16;
@@ -1230,6 +1248,7 @@ int snail_trace_transparency_dev(SnailScene *s, const float cam[13], int resx, i
 	SNAIL_LOCK(s);
 	dev::ShadeArgs A;
 	memset(&A, 0, sizeof(A));
+	A.hostTab = s->arith == SNAIL_ARITH_HOST_SSE ? s->dTab : nullptr;
 	A.nodes = s->dNodes; A.tris = s->dTris; A.pf = (const uint4 *)s->dPF;
 	A.g = makeGen(cam, resx, resy);
 	A.resx = resx; A.resy = resy; A.pw = (resx + 15) / 16; A.ph = (resy + 15) / 16;
@@ -1268,10 +1287,11 @@ int snail_shade_depth_arith_dev(const float *t, int nPackets, uint8_t *bgr, int 
 	if(nPackets <= 0) return 0;
 	if(!t || !bgr) { snail_set_error("snail_shade_depth_dev: null buffer"); return 1; }
 	if(arith != SNAIL_ARITH_IEEE && arith != SNAIL_ARITH_HOST_SSE) { snail_set_error("snail_shade_depth_arith_dev: unknown arithmetic %d", arith); return 1; }
-	if(arith == SNAIL_ARITH_HOST_SSE) { if(int rc = hostSseUpload("snail_shade_depth_arith_dev")) return rc; }
+	const unsigned *tab = nullptr;
+	if(arith == SNAIL_ARITH_HOST_SSE) { if(int rc = hostSseDeviceTables("snail_shade_depth_arith_dev", &tab)) return rc; }
 	const int n = nPackets * 256;
-	if(arith == SNAIL_ARITH_HOST_SSE) hipLaunchKernelGGL(dev_sse::k_shade_depth, dim3((n / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, n, bgr);
-	else hipLaunchKernelGGL(dev::k_shade_depth, dim3((n / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, n, bgr);
+	if(arith == SNAIL_ARITH_HOST_SSE) hipLaunchKernelGGL(dev_sse::k_shade_depth, dim3((n / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, tab, t, n, bgr);
+	else hipLaunchKernelGGL(dev::k_shade_depth, dim3((n / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, tab, t, n, bgr);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
@@ -1354,7 +1374,8 @@ int snail_debug_recip_check(uint64_t out2[2]) {
 
 int snail_debug_hostsse_device_check(int fn, int threads, uint64_t *badChunks, uint32_t *firstBadChunk) {
 	if((fn != 0 && fn != 1) || !badChunks) { snail_set_error("snail_debug_hostsse_device_check: bad arguments"); return 1; }
-	if(int rc = hostSseUpload("snail_debug_hostsse_device_check")) return rc;
+	const unsigned *tab = nullptr;
+	if(int rc = hostSseDeviceTables("snail_debug_hostsse_device_check", &tab)) return rc;
 	constexpr unsigned kBatch = 4096;   // chunks per launch (2^28 inputs)
 	unsigned long long *d = nullptr;
 	HIP_TRY(hipMalloc((void **)&d, kBatch * sizeof(unsigned long long)));
@@ -1363,7 +1384,7 @@ int snail_debug_hostsse_device_check(int fn, int threads, uint64_t *badChunks, u
 	uint32_t first = 0xffffffffu;
 	for(unsigned c0 = 0; c0 < 65536u; c0 += kBatch) {
 		hipError_t e = hipMemset(d, 0, kBatch * sizeof(unsigned long long));
-		if(e == hipSuccess) { hipLaunchKernelGGL(dev_sse::k_hostsse_sums, dim3(kBatch), dim3(256), 0, 0, fn, c0, d); e = hipGetLastError(); }
+		if(e == hipSuccess) { hipLaunchKernelGGL(dev_sse::k_hostsse_sums, dim3(kBatch), dim3(256), 0, 0, tab, fn, c0, d); e = hipGetLastError(); }
 		hostSseChunkSums(fn, c0, kBatch, threads, want.data());   // (the host's sums while the kernel runs)
 		if(e == hipSuccess) e = hipMemcpy(got.data(), d, kBatch * sizeof(unsigned long long), hipMemcpyDeviceToHost);
 		if(e != hipSuccess) { (void)hipFree(d); snail_set_error("snail_debug_hostsse_device_check: %s", hipGetErrorString(e)); return 100 + (int)e; }
@@ -1402,6 +1423,7 @@ int snail_debug_anyorder(SnailScene *s, const float cam[13], int resx, int resy,
 	DeviceGuard guard(s->device);
 	dev::PrimaryArgs A;
 	memset(&A, 0, sizeof(A));
+	A.hostTab = nullptr;
 	A.nodes = s->dNodes; A.tris = s->dTris; A.pf = (const uint4 *)s->dPF;
 	A.nFrames = 1;
 	A.g[0] = makeGen(cam, resx, resy);

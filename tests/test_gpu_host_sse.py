@@ -309,8 +309,9 @@ def test_gpu_built_tree_in_host_sse(torch_mod):
 
 def test_bench_checks_itself_on_a_cpu_without_committed_digests(torch_mod, tmp_path):
     """bench.py's `verified` on a host whose rcpps / rsqrtps tables the digest file does not know (simulated: the Xeon's tables with one entry replaced by
-    its neighbour's -- tables of no CPU): the host_sse frame has no digest to be held against, so the SAME renderer runs one more round in the IEEE
-    arithmetic, whose digests hold everywhere; `verified` comes from that round, the unchecked host_sse digest is reported beside it."""
+    its neighbour's -- tables of no CPU): the timed host_sse frame is checked LIVE against the oracle computing over the same tables (ORC_MODE_TABLE),
+    no committed digest and no detour through another arithmetic involved; with the host's own tables the live check runs this CPU's instructions
+    (ORC_MODE_SSE) and the committed digest is the second check."""
     import json
     import subprocess
     import sys
@@ -321,12 +322,73 @@ def test_bench_checks_itself_on_a_cpu_without_committed_digests(torch_mod, tmp_p
     f = str(tmp_path / "nobody.npy")
     np.save(f, tabs)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "8", "--warmup", "2", "--settle-ms", "0", "--no-cpu-baseline", "--lone-frames", "0",
-                        "--arith", "host_sse", "--arith-tables", f], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    base = [sys.executable, os.path.join(root, "bench.py"), "--steps", "8", "--warmup", "2", "--settle-ms", "0", "--no-cpu-baseline", "--lone-frames", "0", "--arith", "host_sse"]
+    r = subprocess.run(base + ["--arith-tables", f], capture_output=True, text=True, timeout=300, cwd=root, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert d["config"]["arith"] == "host_sse" and d["verified"] is True, d["verification"]
     v = d["verification"]
-    assert v["host_sse"]["verified"] is None and "no committed digest" in v["host_sse"]["note"]
-    assert v["ieee_round"]["verified"] is True and v["ieee_round"]["against"].endswith("ieee.atrium_1920x1080_c1")
-    assert v["host_sse"]["digest"]["sha_t"] != v["ieee_round"]["digest"]["sha_t"]
+    assert d["config"]["arith"] == "host_sse" and d["verified"] is True, v
+    assert v["live_oracle"] is True and "ORC_MODE_TABLE" in v["live_oracle_how"] and v.get("committed") is None and "no committed digest" in v["note"] and v["buffers_identical"], v
+    # config 3 with the bounce on this host's own tables: live against this CPU's instructions
+    r = subprocess.run(base + ["--config", "3", "--reflections"], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    v = d["verification"]
+    assert d["verified"] is True and v["live_oracle"] is True and "ORC_MODE_SSE" in v["live_oracle_how"] and v.get("committed") in (True, None), v
+
+
+def test_two_scenes_on_one_device_compute_with_two_cpus_tables(torch_mod):
+    """The arithmetic is a property of the SCENE HANDLE: its rcpps / rsqrtps tables live in a buffer of its own that every launch is handed
+    (dev_sse::hostTab()), filled by snail_scene_set_arith from the tables in force at that moment.  Two scenes on ONE device -- the Xeon's tables on one,
+    the EPYC's on the other (tests/golden/rcp_tables.npz) -- with frames interleaved on two streams: each equals the oracle computing over ITS tables
+    (ORC_MODE_TABLE; primary hit records, the config-3 frame with the bounce) and, at the bench's size, the digest committed for ITS CPU; a later
+    snail_arith_set_tables changes neither until that scene's next set_arith."""
+    import hashlib
+    import json
+    from snail_amd.scene import Scene, host_sse_tables, set_arith_tables
+    from tests.golden import full_size as FS
+    gold_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    tabs = np.load(os.path.join(gold_dir, "rcp_tables.npz"))
+    names = ["xeon_skylake_sp", "epyc_9575f"]
+    key = {n: hashlib.sha256(np.ascontiguousarray(tabs[n]).tobytes()).hexdigest()[:16] for n in names}
+    assert key[names[0]] != key[names[1]]
+    full = json.load(open(os.path.join(gold_dir, "oracle_full_size.json")))["host_sse"]
+    sha = lambda t: hashlib.sha256(np.ascontiguousarray(t.cpu().numpy()).tobytes()).hexdigest()
+    small, resx, resy = "atrium:0.05", 640, 368
+    tv, hb, osc = util.scene_pair(small)
+    cam = util.camera_for(small, tv)
+    lights = lights_for(osc, cam, 1)
+    tvb, hbb, _ = util.scene_pair("atrium")
+    camb = FS.bench_camera("atrium")
+    try:
+        sc, big = {}, {}
+        for n in names:                              # set the tables, then the scenes' arithmetic: each scene keeps what was in force at ITS call
+            set_arith_tables(tabs[n])
+            sc[n], big[n] = Scene(hb, 0), Scene(hbb, 0)
+            sc[n].set_arith("host_sse"); big[n].set_arith("host_sse")
+        set_arith_tables(None)                       # ... and whatever is set afterwards does not reach them
+        st = {n: torch_mod.cuda.Stream() for n in names}
+        frames = {n: [] for n in names}; lit = {n: [] for n in names}; bigf = {n: [] for n in names}
+        for i in range(4):                           # interleaved, two streams, no synchronisation in between
+            for n in names:
+                frames[n].append(sc[n].trace_primary(cam, resx, resy, stream=st[n]))
+                lit[n].append(sc[n].render_whitted(cam, resx, resy, lights, stream=st[n], reflections=True))
+                bigf[n].append(big[n].trace_primary(camb, 1920, 1080, stream=st[n]))
+        torch_mod.cuda.synchronize()
+        for n in names:
+            O.set_tables(tabs[n])
+            ref = osc.render_primary(cam.as_array13(), resx, resy, mode=O.MODE_TABLE)
+            want, _ = osc.render_whitted(cam.as_array13(), resx, resy, lights, mode=O.MODE_TABLE, reflections=True)
+            for f, img in zip(frames[n], lit[n]):
+                compare_frames(f, ref, "scene with %s's tables" % n)
+                assert np.array_equal(img.cpu().numpy(), want), n
+            w = full[key[n]]["atrium_1920x1080_c1"]
+            for f in bigf[n]:
+                assert (sha(f.t), sha(f.u), sha(f.v), sha(f.tri_id)) == (w["sha_t"], w["sha_u"], w["sha_v"], w["sha_id"]), n
+        # the two CPUs' last bits differ, so the two scenes' frames do
+        assert not torch_mod.equal(frames[names[0]][0].t, frames[names[1]][0].t)
+        for n in names:
+            sc[n].close(); big[n].close()
+    finally:
+        set_arith_tables(None)
+        O.set_tables(O.tables_of_this_cpu())

@@ -841,11 +841,14 @@ def test_two_rank_bench_rehearsal(torch_mod, extra, scaling, res):
     assert c["raw_stream_switch"] in (True, False)
     g = c["gather_alone"]
     assert g["bytes_per_collective"] == c["frames_per_launch"] * max(c["packets_per_rank"]) * 768 and g["ms"] > 0 and g["GBps"] > 0
-    if full:      # the gathered frame = the oracle's depth-shaded (config 3: lit) frame, by committed digest (host_sse: if the file knows this box's CPU)
-        assert d["verified"] is True or (d["config"]["arith"] == "host_sse" and d["verified"] is None), d["verification"]
+    # the gathered frame = the oracle's depth-shaded (config 3: lit) frame: checked live on rank 0 (the oracle renders the frame in the timed arithmetic)
+    # and, for the bench's own scene, by committed digest as well (host_sse: if the file knows this box's CPU)
+    assert d["verified"] is True and d["verification"]["live_oracle"] is True, d["verification"]
+    if full:
+        assert d["verification"].get("committed") in (True, None) and (d["verification"].get("committed") is True or d["config"]["arith"] == "host_sse")
         assert d["config"]["arith"] == ("ieee" if "--arith" in extra else "host_sse")      # the default arithmetic is the reference's own
     else:
-        assert d["verified"] is None and "no committed digest" in d["verification"]["note"]
+        assert d["verification"].get("committed") is None and "no committed digest" in d["verification"]["note"]
 
 
 def test_rccl_code_path_single_rank(torch_mod):
