@@ -392,3 +392,35 @@ def test_two_scenes_on_one_device_compute_with_two_cpus_tables(torch_mod):
     finally:
         set_arith_tables(None)
         O.set_tables(O.tables_of_this_cpu())
+
+
+@pytest.mark.parametrize("host_sse", [False, True])
+def test_lights_whose_lookups_meet_special_inputs(torch_mod, host_sse):
+    """The light kernel's main pass takes the table look-ups in their short form after ONE test of all their inputs per packet and hands a packet with
+    a special input (0, denormal, inf, NaN, a flushed result) to the deferred pass, which applies the full rule -- here with lights that produce such
+    inputs: a radius so small that 16 (d / r)^2 overflows (FastInv(inf) = 0), one so large that it underflows to a denormal / zero (FastInv -> inf: the
+    attenuation saturates the pixel), inside the packet's hit bounds so that the packet-level cull keeps them.  One light (the fused epilogue) and three
+    (k_final's), with and without the bounce, equal the oracle byte for byte in either arithmetic."""
+    from snail_amd.scene import Scene
+    MODE = O.MODE_SSE if host_sse else O.MODE_IEEE
+    name, resx, resy = "atrium:0.05", 320, 192
+    tv, hb, osc = util.scene_pair(name)
+    cam = util.camera_for(name, tv)
+    sc = Scene(hb, 0)
+    if host_sse:
+        sc.set_arith("host_sse")
+    bmin, bmax = osc.nodes[0]["bmin"], osc.nodes[0]["bmax"]
+    c, e = (bmin + bmax) * 0.5, (bmax - bmin)
+    pos = [c[0], c[1] + 0.2 * e[1], c[2]]
+    for radius in (1e-30, 1e-18, 1e18, 3e38):
+        one = np.array([pos + [1.0, 0.9, 0.8, radius]], dtype=np.float32)
+        three = np.array([pos + [1.0, 0.9, 0.8, radius], [c[0] - 0.3 * e[0], c[1] + 0.1 * e[1], c[2] + 0.2 * e[2], 0.3, 0.5, 1.0, 0.6 * float(e.max())],
+                          [c[0] + 0.2 * e[0], c[1] + 0.3 * e[1], c[2], 0.5, 0.5, 0.5, radius]], dtype=np.float32)
+        for lights in (one, three):
+            for refl in (False, True):
+                want, wst = osc.render_whitted(cam.as_array13(), resx, resy, lights, mode=MODE, reflections=refl)
+                stats = sc.new_stats()
+                got = sc.render_whitted(cam, resx, resy, lights, stats=stats, reflections=refl).cpu().numpy()
+                assert np.array_equal(got, want), (radius, len(lights), refl, int((got != want).sum()))
+                assert np.array_equal(stats.cpu().numpy().astype(np.uint64), wst), (radius, len(lights), refl)
+    sc.close()
