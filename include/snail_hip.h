@@ -173,6 +173,13 @@ int snail_trace_packets_ordered_dev(SnailScene *, const float cam[13], int resx,
                                     float *d_t, float *d_u, float *d_v, int32_t *d_triId, uint64_t *d_stats,
                                     const int32_t *d_order, int32_t *d_slot_cost, void *stream);
 int snail_order_from_cost_dev(const int32_t *d_slot_cost, int nSlots, int32_t *d_order, void *stream);
+/* Dispatch-order feedback WITHOUT a launch of its own (round 5): the *_reorder_dev forms of the multi-frame primary launch (below) and of the staged frame
+ * (snail_render_whitted_reorder_dev) are their *_ordered_dev forms plus d_next_order (out; same shape as d_order; needs d_slot_cost): the order(s) the NEXT
+ * such launch should use, derived from THIS launch's costs inside the launch -- by one extra workgroup of the small deferred-packet pass that follows every
+ * traversal kernel anyway -- so that a moving camera's order refresh costs no kernel launch, no stream round trip and no second pass over the costs.  d_next_order
+ * may be d_order itself (the traversal kernel that reads d_order has finished when it is rewritten).  Same classes, same descending order as
+ * snail_order_from_cost_dev would give for those costs (the order inside a class is arbitrary in both); frames with more than 20480 slots fall back to
+ * that kernel inside the call. */
 /* Multi-frame launches: ONE launch traces nFrames (1..SNAIL_MAX_BATCH) frames of the same rect / packet list, each with its own camera
  * (cams13: HOST array nFrames x 13) and its own output planes (HOST arrays of nFrames DEVICE pointers; a NULL array = that plane is not
  * wanted).  The heaviest packets of all the frames are dispatched first; a frame's tail -- ~0.2 ms whatever the launch holds -- and the
@@ -183,6 +190,9 @@ int snail_order_from_cost_dev(const int32_t *d_slot_cost, int nSlots, int32_t *d
 int snail_trace_primary_batch_dev(SnailScene *, int nFrames, const float *cams13, int resx, int resy, float *const *d_t, float *const *d_u,
                                   float *const *d_v, int32_t *const *d_triId, uint64_t *d_stats, const int32_t *d_order,
                                   int32_t *d_slot_cost, void *stream);
+int snail_trace_primary_batch_reorder_dev(SnailScene *, int nFrames, const float *cams13, int resx, int resy, float *const *d_t, float *const *d_u,
+                                          float *const *d_v, int32_t *const *d_triId, uint64_t *d_stats, const int32_t *d_order,
+                                          int32_t *d_slot_cost, int32_t *d_next_order, void *stream);
 int snail_trace_packets_shaded_batch_dev(SnailScene *, int nFrames, const float *cams13, int resx, int resy, const int32_t *d_packet_xy,
                                          int nPackets, uint8_t *const *d_bgr, uint64_t *d_stats, void *stream);
 /* Scatter packet-major planes into row-major resx*resy frame planes (clipped to the image). */
@@ -285,6 +295,12 @@ int snail_render_whitted_dev(SnailScene *, const float cam[13], int resx, int re
 int snail_render_whitted_ordered_dev(SnailScene *, const float cam[13], int resx, int resy, const float *lights7, int nLights,
                                      const float ambient[3], const float color[3], int flags, uint8_t *d_frame_bgr, int pitch, uint64_t *d_stats,
                                      const int32_t *d_order, int32_t *d_slot_cost, void *stream);
+
+/* ... and with the next orders of all four stages derived inside the launch (see snail_trace_primary_batch_reorder_dev): d_next_order = SNAIL_WHITTED_STAGES
+ * arrays of nSlots int32, back to back, as d_order; may be d_order itself. */
+int snail_render_whitted_reorder_dev(SnailScene *, const float cam[13], int resx, int resy, const float *lights7, int nLights,
+                                     const float ambient[3], const float color[3], int flags, uint8_t *d_frame_bgr, int pitch, uint64_t *d_stats,
+                                     const int32_t *d_order, int32_t *d_slot_cost, int32_t *d_next_order, void *stream);
 
 /* The same for an explicit list of packets (a rank's tiles): output = packet-major B,G,R bytes [nPackets][256][3] (4-byte aligned),
  * to be gathered and scattered with snail_packets_bgr_to_frame_dev -- a render node with the reference's simple shading on. */

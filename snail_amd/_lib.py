@@ -44,6 +44,8 @@ SIGNATURES = {
     "snail_trace_packets_shaded_dev": (_I, [_VP, _F13, _I, _I, _VP, _I, _VP, _VP, _VP]),
     "snail_trace_primary_batch_dev": (_I, [_VP, _I, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "snail_trace_packets_shaded_batch_dev": (_I, [_VP, _I, _VP, _I, _I, _VP, _I, _VP, _VP, _VP]),
+    "snail_trace_primary_batch_reorder_dev": (_I, [_VP, _I, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "snail_render_whitted_reorder_dev": (_I, [_VP, _F13, _I, _I, _VP, _I, _VP, _VP, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP]),
     "snail_primary_slots": (_I, [_I, _I]),
     "snail_trace_primary_ordered_dev": (_I, [_VP, _F13, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "snail_trace_packets_ordered_dev": (_I, [_VP, _F13, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),

@@ -433,9 +433,34 @@ struct FrameSet {
 	dev::FrameOut out[SNAIL_MAX_BATCH] = {};
 };
 
+// The deferred-packet launch that follows a traversal kernel, with or without the next dispatch order derived inside it (dev::orderSortBlock as its
+// last workgroup: *_reorder_dev).  In-launch sort: up to SORT_IN_LAUNCH_MAX slots (their 16-bit costs + the sort's 16.4 KB + the pass's own 3.3 KB fit
+// the 64 KB of LDS a workgroup gets without further ado) with 16-byte aligned costs; beyond that the order is derived by the stand-alone kernel right
+// after the pass (sortAfter) -- same result for the caller, one launch more.
+enum { SORT_IN_LAUNCH_MAX = 20480 };
+struct ExactPass {
+	dim3 grid, block;
+	size_t lds = 0;
+	int *nextOrder = nullptr;   // what the kernel's argument record gets
+	bool sortAfter = false;
+};
+ExactPass exactPassFor(int exactBlocks, const int32_t *dSlotCost, int nSlots, int32_t *dNextOrder) {
+	ExactPass e;
+	e.grid = dim3((unsigned)exactBlocks); e.block = dim3(64);
+	if(!dNextOrder || !dSlotCost || nSlots <= 0) return e;
+	if(nSlots <= SORT_IN_LAUNCH_MAX && ((uintptr_t)dSlotCost & 15) == 0) {
+		e.grid = dim3((unsigned)exactBlocks + 1); e.block = dim3(ORDER_THREADS_LDS);
+		e.lds = (size_t)((nSlots + 3) / 4 * 4) * 2;
+		e.nextOrder = (int *)dNextOrder;
+	} else e.sortAfter = true;
+	return e;
+}
+
 int launchPrimaryFrames(SnailScene *s, const FrameSet &FS, int resx, int resy, int x0, int y0, int w, int h, const int32_t *dPacketXY, int nPackets, uint64_t *dStats,
-						hipStream_t stream, unsigned *dCost = nullptr, bool packetMajor = false, const int32_t *dOrder = nullptr, int32_t *dSlotCost = nullptr) {
+						hipStream_t stream, unsigned *dCost = nullptr, bool packetMajor = false, const int32_t *dOrder = nullptr, int32_t *dSlotCost = nullptr,
+						int32_t *dNextOrder = nullptr) {
 	if(resx <= 0 || resy <= 0) { snail_set_error("snail_trace_primary: bad resolution %dx%d", resx, resy); return 1; }
+	if(dNextOrder && !dSlotCost) { snail_set_error("snail_trace_primary: the next dispatch order is derived from d_slot_cost, which is null"); return 1; }
 	if(FS.n < 1 || FS.n > SNAIL_MAX_BATCH || (SNAIL_BLOCK_WAVES > 1 && FS.n > 1)) { snail_set_error("snail_trace_primary: 1..%d frames per launch (got %d)", SNAIL_MAX_BATCH, FS.n); return 1; }
 	dev::PrimaryArgs A;
 	memset(&A, 0, sizeof(A));
@@ -508,6 +533,8 @@ int launchPrimaryFrames(SnailScene *s, const FrameSet &FS, int resx, int resy, i
 	const int exactBlocks = A.fastOK ? (blocks < 8 ? blocks : 8) : (blocks < 2048 ? blocks : 2048);
 	static_assert(128 % SNAIL_BLOCK_WAVES == 0, "the slot count is a multiple of 128");
 	const dim3 grid(gridBlocks / SNAIL_BLOCK_WAVES), block(64 * SNAIL_BLOCK_WAVES);
+	const ExactPass EP = exactPassFor(exactBlocks, dSlotCost, A.nSlots, dCost ? nullptr : dNextOrder);
+	A.nextOrder = EP.nextOrder;
 	const bool sse = s->arith == SNAIL_ARITH_HOST_SSE;
 	if(dCost) { // diagnostic launch (snail_account_packets)
 		if(useDeep(s)) SNAIL_LAUNCH(sse, PrimaryArgs, dim3(blocks), dim3(64), 0, stream, A, k_primary_diag<true>);
@@ -517,9 +544,10 @@ int launchPrimaryFrames(SnailScene *s, const FrameSet &FS, int resx, int resy, i
 	// workbench build, SNAIL_DEBUG_NO_EXACT_PASS=1: what the dependent second launch costs (an experiment: deferred packets are then never traced)
 	static const bool noExact = debugEnvInt("SNAIL_DEBUG_NO_EXACT_PASS") != 0;
 	if(noExact) { }
-	else if(useDeep(s)) SNAIL_LAUNCH(sse, PrimaryArgs, dim3(exactBlocks), dim3(64), 0, stream, A, k_primary_exact<true>);
-	else SNAIL_LAUNCH(sse, PrimaryArgs, dim3(exactBlocks), dim3(64), 0, stream, A, k_primary_exact<false>);
+	else if(useDeep(s)) SNAIL_LAUNCH(sse, PrimaryArgs, EP.grid, EP.block, EP.lds, stream, A, k_primary_exact<true>);
+	else SNAIL_LAUNCH(sse, PrimaryArgs, EP.grid, EP.block, EP.lds, stream, A, k_primary_exact<false>);
 	HIP_TRY(hipGetLastError());
+	if(EP.sortAfter) { if(int rc = snail_order_from_cost_dev(dSlotCost, A.nSlots, dNextOrder, stream)) return rc; }
 	HIP_TRY(hipEventRecord(s->deferDone[slot], stream));
 	s->deferUsed[slot] = true;
 	for(int k = 0; k < FS.n; k++)
@@ -530,11 +558,11 @@ int launchPrimaryFrames(SnailScene *s, const FrameSet &FS, int resx, int resy, i
 // one frame per launch (every entry point but the *_batch_dev ones)
 int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0, int y0, int w, int h, const int32_t *dPacketXY,
 				  int nPackets, float *t, float *u, float *v, int32_t *id, uint64_t *dStats, hipStream_t stream, unsigned *dCost = nullptr,
-				  bool packetMajor = false, uint8_t *dBgr = nullptr, const int32_t *dOrder = nullptr, int32_t *dSlotCost = nullptr) {
+				  bool packetMajor = false, uint8_t *dBgr = nullptr, const int32_t *dOrder = nullptr, int32_t *dSlotCost = nullptr, int32_t *dNextOrder = nullptr) {
 	FrameSet FS;
 	FS.n = 1; FS.cam[0] = cam;
 	FS.out[0].t = t; FS.out[0].u = u; FS.out[0].v = v; FS.out[0].id = (int *)id; FS.out[0].bgr = dBgr;
-	return launchPrimaryFrames(s, FS, resx, resy, x0, y0, w, h, dPacketXY, nPackets, dStats, stream, dCost, packetMajor, dOrder, dSlotCost);
+	return launchPrimaryFrames(s, FS, resx, resy, x0, y0, w, h, dPacketXY, nPackets, dStats, stream, dCost, packetMajor, dOrder, dSlotCost, dNextOrder);
 }
 
 // scratch of one staged frame: ONE allocation, carved (hitT is its base); grown synchronously when a larger frame or the first
@@ -572,12 +600,12 @@ int shadeScratch(SnailScene *s, SnailScene::ShadeScratch &W, size_t packets, siz
 }
 
 template <bool SHARED, bool MASK>
-void launchRaysKernels(const SnailScene *s, const dev::RaysArgs &A, int blocks, int exactBlocks, hipStream_t stream) {
+void launchRaysKernels(const SnailScene *s, const dev::RaysArgs &A, int blocks, const ExactPass &EP, hipStream_t stream) {
 	const bool deep = useDeep(s), bary = A.bary != nullptr, sse = s->arith == SNAIL_ARITH_HOST_SSE;
 #define SNAIL_RAYS_LAUNCH(D, B)                                                                                                            \
 	do {                                                                                                                                   \
 		SNAIL_LAUNCH(sse, RaysArgs, dim3(blocks), dim3(64), 0, stream, A, k_rays<SHARED, MASK, D, B>);                                      \
-		SNAIL_LAUNCH(sse, RaysArgs, dim3(exactBlocks), dim3(64), 0, stream, A, k_rays_exact<SHARED, MASK, D, B>);                           \
+		SNAIL_LAUNCH(sse, RaysArgs, EP.grid, EP.block, EP.lds, stream, A, k_rays_exact<SHARED, MASK, D, B>);                                \
 	} while(0)
 	if(deep && bary) SNAIL_RAYS_LAUNCH(true, true);
 	else if(deep) SNAIL_RAYS_LAUNCH(true, false);
@@ -588,7 +616,7 @@ void launchRaysKernels(const SnailScene *s, const dev::RaysArgs &A, int blocks, 
 
 int launchRays(SnailScene *s, bool shadow, int nPackets, int size, int sharedOrigin, const float *origin, const float *dir,
 					  const float *idir, const uint8_t *mask, float *distance, int32_t *object, float *bary, uint64_t *dStats, hipStream_t stream,
-					  const int32_t *dOrder = nullptr, int32_t *dSlotCost = nullptr, int nSlots = 0) {
+					  const int32_t *dOrder = nullptr, int32_t *dSlotCost = nullptr, int nSlots = 0, int32_t *dNextOrder = nullptr) {
 	if(nPackets <= 0) return 0;
 	if(size < 1 || size > SNAIL_PACKET_QUADS) { snail_set_error("packet size %d outside 1..%d quads", size, SNAIL_PACKET_QUADS); return 1; }
 	if(!origin || !dir || !idir || !distance || (!shadow && !object)) { snail_set_error("null ray array"); return 1; }
@@ -619,6 +647,8 @@ int launchRays(SnailScene *s, bool shadow, int nPackets, int size, int sharedOri
 	if(R.used) HIP_TRY(hipStreamWaitEvent(stream, R.done, 0));
 	A.defer = R.p;
 	const int exactBlocks = A.fastOK ? (blocks < 8 ? blocks : 8) : (blocks < 2048 ? blocks : 2048);
+	const ExactPass EP = exactPassFor(exactBlocks, A.slotCost, A.nSlots, shadow ? nullptr : dNextOrder);
+	A.nextOrder = EP.nextOrder;
 	if(shadow) {
 		if(useDeep(s)) {
 			hipLaunchKernelGGL(dev::k_shadow<true>, dim3(blocks), dim3(64), 0, stream, A);
@@ -627,18 +657,19 @@ int launchRays(SnailScene *s, bool shadow, int nPackets, int size, int sharedOri
 			hipLaunchKernelGGL(dev::k_shadow<false>, dim3(blocks), dim3(64), 0, stream, A);
 			hipLaunchKernelGGL(dev::k_shadow_exact<false>, dim3(exactBlocks), dim3(64), 0, stream, A);
 		}
-	} else if(sharedOrigin && mask) launchRaysKernels<true, true>(s, A, blocks, exactBlocks, stream);
-	else if(sharedOrigin) launchRaysKernels<true, false>(s, A, blocks, exactBlocks, stream);
-	else if(mask) launchRaysKernels<false, true>(s, A, blocks, exactBlocks, stream);
-	else launchRaysKernels<false, false>(s, A, blocks, exactBlocks, stream);
+	} else if(sharedOrigin && mask) launchRaysKernels<true, true>(s, A, blocks, EP, stream);
+	else if(sharedOrigin) launchRaysKernels<true, false>(s, A, blocks, EP, stream);
+	else if(mask) launchRaysKernels<false, true>(s, A, blocks, EP, stream);
+	else launchRaysKernels<false, false>(s, A, blocks, EP, stream);
 	HIP_TRY(hipGetLastError());
+	if(EP.sortAfter) { if(int rc = snail_order_from_cost_dev(A.slotCost, A.nSlots, dNextOrder, stream)) return rc; }
 	HIP_TRY(hipEventRecord(R.done, stream));
 	R.used = true;
 	return 0;
 }
 
 template <int SRC>
-int launchLights(SnailScene *s, dev::ShadeArgs A /* a copy: relLight is filled in here */, hipStream_t stream) {
+int launchLights(SnailScene *s, dev::ShadeArgs A /* a copy: relLight is filled in here */, hipStream_t stream, int32_t *dNextOrder = nullptr) {
 	if(A.nLights <= 0) return 0;
 	int relWhich[SNAIL_MAX_LIGHTS];
 	for(int n = 0; n < SNAIL_MAX_LIGHTS; n++) { relWhich[n] = -1; A.relLight[n] = nullptr; }
@@ -649,14 +680,17 @@ int launchLights(SnailScene *s, dev::ShadeArgs A /* a copy: relLight is filled i
 	const int total = A.nBlocks * A.nLights;
 	const int exactBlocks = A.fastOK ? (total < 8 ? total : 8) : (total < 2048 ? total : 2048);
 	const bool sse = s->arith == SNAIL_ARITH_HOST_SSE;
+	const ExactPass EP = exactPassFor(exactBlocks, A.slotCost, A.nSlots, dNextOrder);
+	A.nextOrder = EP.nextOrder;
 	if(useDeep(s)) {
 		SNAIL_LAUNCH(sse, ShadeArgs, grid, dim3(64), 0, stream, A, k_light<true, SRC>);
-		SNAIL_LAUNCH(sse, ShadeArgs, dim3(exactBlocks), dim3(64), 0, stream, A, k_light_exact<true, SRC>);
+		SNAIL_LAUNCH(sse, ShadeArgs, EP.grid, EP.block, EP.lds, stream, A, k_light_exact<true, SRC>);
 	} else {
 		SNAIL_LAUNCH(sse, ShadeArgs, grid, dim3(64), 0, stream, A, k_light<false, SRC>);
-		SNAIL_LAUNCH(sse, ShadeArgs, dim3(exactBlocks), dim3(64), 0, stream, A, k_light_exact<false, SRC>);
+		SNAIL_LAUNCH(sse, ShadeArgs, EP.grid, EP.block, EP.lds, stream, A, k_light_exact<false, SRC>);
 	}
 	HIP_TRY(hipGetLastError());
+	if(EP.sortAfter) { if(int rc = snail_order_from_cost_dev(A.slotCost, A.nSlots, dNextOrder, stream)) return rc; }
 	for(int n = 0; n < A.nLights; n++)
 		if(relWhich[n] >= 0) { if(int rc = relUsed(s, relWhich[n], stream)) return rc; }
 	return 0;
@@ -953,8 +987,16 @@ int snail_order_from_cost_dev(const int32_t *dSlotCost, int nSlots, int32_t *dOr
 	const hipStream_t st = (hipStream_t)stream;
 	const size_t stashBytes = (size_t)((nSlots + 3) / 4 * 4) * 2;
 	bool ldsForm = nSlots <= ORDER_LDS_MAX_SLOTS && ((uintptr_t)dSlotCost & 15) == 0;   // (a caller's array that is not 16-byte aligned, or a frame beyond ~6K x 4K: the multi-pass kernel)
-	if(ldsForm && stashBytes > 32768)   // more dynamic LDS than a kernel gets by default (static 16.4 KB + this)
-		ldsForm = hipFuncSetAttribute((const void *)dev::k_order_from_cost_lds, hipFuncAttributeMaxDynamicSharedMemorySize, ORDER_LDS_MAX_SLOTS * 2) == hipSuccess;
+	if(ldsForm && stashBytes > 32768) {   // more dynamic LDS than a kernel gets by default (static 16.4 KB + this): raised once per device
+		static std::mutex mu;
+		static signed char raised[64] = {};   // 0 = not tried, 1 = raised, -1 = refused
+		int devId = 0;
+		HIP_TRY(hipGetDevice(&devId));
+		std::lock_guard<std::mutex> lock(mu);
+		signed char &r = raised[devId & 63];
+		if(r == 0) r = hipFuncSetAttribute((const void *)dev::k_order_from_cost_lds, hipFuncAttributeMaxDynamicSharedMemorySize, ORDER_LDS_MAX_SLOTS * 2) == hipSuccess ? 1 : -1;
+		ldsForm = r == 1;
+	}
 	if(ldsForm)
 		hipLaunchKernelGGL(dev::k_order_from_cost_lds, dim3(1), dim3(ORDER_THREADS_LDS), stashBytes, st, dSlotCost, nSlots, dOrder);
 	else hipLaunchKernelGGL(dev::k_order_from_cost, dim3(1), dim3(ORDER_THREADS), 0, st, dSlotCost, nSlots, dOrder);
@@ -990,6 +1032,19 @@ int snail_trace_primary_batch_dev(SnailScene *s, int nFrames, const float *cams1
 	DeviceGuard guard(s->device);
 	SNAIL_LOCK(s);
 	return launchPrimaryFrames(s, FS, resx, resy, 0, 0, resx, resy, nullptr, 0, dStats, (hipStream_t)stream, nullptr, false, dOrder, dSlotCost);
+}
+
+int snail_trace_primary_batch_reorder_dev(SnailScene *s, int nFrames, const float *cams13, int resx, int resy, float *const *t, float *const *u, float *const *v,
+										  int32_t *const *id, uint64_t *dStats, const int32_t *dOrder, int32_t *dSlotCost, int32_t *dNextOrder, void *stream) {
+	if(int rc = checkScene(s, "snail_trace_primary_batch_reorder_dev")) return rc;
+	FrameSet FS;
+	if(int rc = frameSetFrom("snail_trace_primary_batch_reorder_dev", FS, nFrames, cams13)) return rc;
+	for(int k = 0; k < nFrames; k++) {
+		FS.out[k].t = t ? t[k] : nullptr; FS.out[k].u = u ? u[k] : nullptr; FS.out[k].v = v ? v[k] : nullptr; FS.out[k].id = id ? (int *)id[k] : nullptr;
+	}
+	DeviceGuard guard(s->device);
+	SNAIL_LOCK(s);
+	return launchPrimaryFrames(s, FS, resx, resy, 0, 0, resx, resy, nullptr, 0, dStats, (hipStream_t)stream, nullptr, false, dOrder, dSlotCost, dNextOrder);
 }
 
 int snail_trace_packets_shaded_batch_dev(SnailScene *s, int nFrames, const float *cams13, int resx, int resy, const int32_t *dPacketXY, int nPackets,
@@ -1134,8 +1189,9 @@ int snail_trace_shadow(SnailScene *s, int nPackets, int size, const float *origi
 
 static int renderWhitted(const char *fn, SnailScene *s, const float cam[13], int resx, int resy, const int32_t *dPacketXY, int nPacketsList, const float *lights7,
 						 int nLights, const float ambient[3], const float color[3], int flags, uint8_t *frame, int pitch, uint8_t *bgrPackets, uint64_t *dStats,
-						 void *stream, float *colPackets = nullptr, const int32_t *dOrder = nullptr, int32_t *dSlotCost = nullptr) {
+						 void *stream, float *colPackets = nullptr, const int32_t *dOrder = nullptr, int32_t *dSlotCost = nullptr, int32_t *dNextOrder = nullptr) {
 	if(int rc = checkScene(s, fn)) return rc;
+	if(dNextOrder && !dSlotCost) { snail_set_error("%s: the next dispatch orders are derived from d_slot_cost, which is null", fn); return 1; }
 	if(resx <= 0 || resy <= 0 || nLights < 0 || nLights > SNAIL_MAX_LIGHTS || (nLights && !lights7) || !ambient || !color || (flags & ~SNAIL_WHITTED_REFLECTIONS) ||
 	   (dPacketXY ? (colPackets ? false : (!bgrPackets || ((unsigned long long)bgrPackets & 3))) : (!frame || pitch < resx * 3 || colPackets))) {
 		snail_set_error("%s: bad arguments (at most %d lights; flags = SNAIL_WHITTED_REFLECTIONS or 0; 4-byte aligned output)", fn, SNAIL_MAX_LIGHTS);
@@ -1172,9 +1228,12 @@ static int renderWhitted(const char *fn, SnailScene *s, const float cam[13], int
 	// dispatch-order feedback, frame grid only: SNAIL_WHITTED_STAGES arrays of `blocks` entries, back to back -- the primary packets, the shadow
 	// packets of the primary hits (first light), the mirrored packets, the shadow packets of the mirrored hits (include/snail_hip.h)
 	const int32_t *ord[SNAIL_WHITTED_STAGES] = {};
-	int32_t *cst[SNAIL_WHITTED_STAGES] = {};
+	int32_t *cst[SNAIL_WHITTED_STAGES] = {}, *nxt[SNAIL_WHITTED_STAGES] = {};
 	if(!dPacketXY)
-		for(int k = 0; k < SNAIL_WHITTED_STAGES; k++) { ord[k] = dOrder ? dOrder + (size_t)k * blocks : nullptr; cst[k] = dSlotCost ? dSlotCost + (size_t)k * blocks : nullptr; }
+		for(int k = 0; k < SNAIL_WHITTED_STAGES; k++) {
+			ord[k] = dOrder ? dOrder + (size_t)k * blocks : nullptr; cst[k] = dSlotCost ? dSlotCost + (size_t)k * blocks : nullptr;
+			nxt[k] = dNextOrder ? dNextOrder + (size_t)k * blocks : nullptr;
+		}
 	SnailScene::ShadeScratch &W = s->shade[s->shadeCount++ % SnailScene::kDeferSlots];
 	if(int rc = shadeScratch(s, W, (size_t)packets, (size_t)blocks, refl)) return rc;
 	if(!W.done) HIP_TRY(hipEventCreateWithFlags(&W.done, hipEventDisableTiming));
@@ -1190,18 +1249,18 @@ static int renderWhitted(const char *fn, SnailScene *s, const float cam[13], int
 	// the primary packets (the bench kernel), hit records packet-major
 	if(dPacketXY) {
 		if(int rc = launchPrimary(s, cam, resx, resy, 0, 0, 0, 0, dPacketXY, packets, W.hitT, nullptr, nullptr, W.hitId, dStats, st)) return rc;
-	} else if(int rc = launchPrimary(s, cam, resx, resy, 0, 0, resx, resy, nullptr, 0, W.hitT, nullptr, nullptr, W.hitId, dStats, st, nullptr, true, nullptr, ord[0], cst[0])) return rc;
+	} else if(int rc = launchPrimary(s, cam, resx, resy, 0, 0, resx, resy, nullptr, 0, W.hitT, nullptr, nullptr, W.hitId, dStats, st, nullptr, true, nullptr, ord[0], cst[0], nxt[0])) return rc;
 	if(refl) { // the nested RayTrace of the mirrored packets
 		SNAIL_LAUNCH(sse, ShadeArgs, grid, wave, 0, st, A, k_final<dev::SRC_PRIMARY, dev::DST_MIRROR>);
 		HIP_TRY(hipGetLastError());
-		if(int rc = launchRays(s, false, packets, 64, 0, W.rOrg, W.rDir, W.rIDir, W.rMask, W.rDist, W.rObj, nullptr, dStats, st, ord[2], cst[2], dPacketXY ? 0 : blocks)) return rc;
+		if(int rc = launchRays(s, false, packets, 64, 0, W.rOrg, W.rDir, W.rIDir, W.rMask, W.rDist, W.rObj, nullptr, dStats, st, ord[2], cst[2], dPacketXY ? 0 : blocks, nxt[2])) return rc;
 		A.order = ord[3]; A.slotCost = cst[3]; A.nSlots = blocks;
-		if(int rc = launchLights<dev::SRC_MIRROR>(s, A, st)) return rc;
+		if(int rc = launchLights<dev::SRC_MIRROR>(s, A, st, nxt[3])) return rc;
 		if(!A.fuse) SNAIL_LAUNCH(sse, ShadeArgs, grid, wave, 0, st, A, k_final<dev::SRC_MIRROR, dev::DST_COLOR>);
 		HIP_TRY(hipGetLastError());
 	}
 	A.order = ord[1]; A.slotCost = cst[1]; A.nSlots = blocks;
-	if(int rc = launchLights<dev::SRC_PRIMARY>(s, A, st)) return rc;
+	if(int rc = launchLights<dev::SRC_PRIMARY>(s, A, st, nxt[1])) return rc;
 	if(!A.fuse) SNAIL_LAUNCH(sse, ShadeArgs, grid, wave, 0, st, A, k_final<dev::SRC_PRIMARY, dev::DST_FRAME>);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(W.done, st));
@@ -1222,6 +1281,15 @@ int snail_render_whitted_ordered_dev(SnailScene *s, const float cam[13], int res
 	SNAIL_LOCK(s);
 	return renderWhitted("snail_render_whitted_ordered_dev", s, cam, resx, resy, nullptr, 0, lights7, nLights, ambient, color, flags, frame, pitch, nullptr, dStats, stream,
 						 nullptr, dOrder, dSlotCost);
+}
+
+int snail_render_whitted_reorder_dev(SnailScene *s, const float cam[13], int resx, int resy, const float *lights7, int nLights, const float ambient[3],
+									 const float color[3], int flags, uint8_t *frame, int pitch, uint64_t *dStats, const int32_t *dOrder, int32_t *dSlotCost, int32_t *dNextOrder,
+									 void *stream) {
+	if(int rc = checkScene(s, "snail_render_whitted_reorder_dev")) return rc;
+	SNAIL_LOCK(s);
+	return renderWhitted("snail_render_whitted_reorder_dev", s, cam, resx, resy, nullptr, 0, lights7, nLights, ambient, color, flags, frame, pitch, nullptr, dStats, stream,
+						 nullptr, dOrder, dSlotCost, dNextOrder);
 }
 
 int snail_render_whitted_packets_dev(SnailScene *s, const float cam[13], int resx, int resy, const int32_t *dPacketXY, int nPackets, const float *lights7,

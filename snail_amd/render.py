@@ -228,7 +228,8 @@ class DistributedRenderer:
         self.pending = [None] * self.nslots
         self._outputs = {}      # (slot, index in the launch) -> the buffer a launch of this renderer last wrote there (output_buffers())
         # feedback_order: dispatch the packets of a frame heaviest first, by the node visits counted in an earlier frame of the same
-        # slot (snail_order_from_cost_dev, on the slot's own stream, so a launch never reads an order that is being rewritten).  The
+        # slot (round 5: derived INSIDE the launch whose costs it comes from -- Scene.trace_primary_batch / render_whitted next_order, the *_reorder_dev entry
+        # points -- in place, after that launch's traversal kernel has read the old order; explicit packet lists: snail_order_from_cost_dev on the slot's stream).  The
         # order of a slot is derived after its first frame and re-derived only when the camera has moved since AND `order_refresh`
         # frames of the slot have passed: node visits of a nearby view predict the heavy packets just as well, and the one-workgroup
         # sort (20 us alone, ~100 us beside four frames in flight) then never sits in a short timed region of a fixed view.
@@ -317,7 +318,13 @@ class DistributedRenderer:
         refresh = self.order_cam[slot] != key and self.order_age[slot] >= self.order_refresh
         return self.order_buf[slot], (key if refresh else None)
 
+    def _order_refreshed(self, slot, key):
+        """the launch that was just enqueued derives the slot's next order itself (next_order = the slot's order buffer: the *_reorder_dev entry
+        points -- no kernel launch of its own, round 5)"""
+        self.order_valid[slot], self.order_cam[slot], self.order_age[slot] = True, key, 0
+
     def _refresh_order(self, slot, st, key):
+        """the stand-alone sort (snail_order_from_cost_dev), for the routes without a *_reorder_dev form: explicit packet lists"""
         if self.whitted_single:
             for k in range(self.scene.WHITTED_STAGES if self.reflections else 2):     # stages 2, 3 exist with the mirrored bounce only
                 self.scene.order_from_cost(self.slot_cost[slot][k], self.order_buf[slot][k], stream=st)
@@ -345,16 +352,21 @@ class DistributedRenderer:
             if self.whitted_single:
                 order, key = self._order_for(slot, cam) if self.feedback else (None, None)
                 self.frame_rgb8 = sc.render_whitted(cam, p.resx, p.resy, self.lights7, self.ambient, self.color, out=self.frames_rgb8[slot], stats=stats, stream=st,
-                                                    reflections=self.reflections, order=order, slot_cost=self.slot_cost[slot] if self.feedback else None)
+                                                    reflections=self.reflections, order=order, slot_cost=self.slot_cost[slot] if self.feedback else None,
+                                                    next_order=self.order_buf[slot] if key is not None else None)   # (a refresh: derived inside this launch, in place)
                 self._outputs[(slot, 0)] = self.frame_rgb8
                 if events: events[1].record(st)
-                if key is not None: self._refresh_order(slot, st, key)
+                if key is not None: self._order_refreshed(slot, key)
                 return self.frame_rgb8
             if self.feedback:
                 order, key = self._order_for(slot, cam)
-                out = sc.trace_primary(cam, p.resx, p.resy, out=self.frames[slot], stats=stats, stream=st, order=order, slot_cost=self.slot_cost[slot])
+                if key is not None:      # a refresh: the one-frame form of the multi-frame launch derives the next order inside the launch, in place
+                    out = sc.trace_primary_batch([cam], p.resx, p.resy, [self.frames[slot]], stats=stats, stream=st, order=order, slot_cost=self.slot_cost[slot],
+                                                 next_order=self.order_buf[slot])[0]
+                    self._order_refreshed(slot, key)
+                else:
+                    out = sc.trace_primary(cam, p.resx, p.resy, out=self.frames[slot], stats=stats, stream=st, order=order, slot_cost=self.slot_cost[slot])
                 if events: events[1].record(st)
-                if key is not None: self._refresh_order(slot, st, key)
             else:
                 out = sc.trace_primary(cam, p.resx, p.resy, out=self.frames[slot], stats=stats, stream=st)
                 if events: events[1].record(st)
@@ -467,9 +479,10 @@ class DistributedRenderer:
         if events: events[0].record(st)
         if self.feedback:
             order, key = self._order_for(slot, cams[0])
-            sc.trace_primary_batch(cams, p.resx, p.resy, outs, stats=stats, stream=st, order=order, slot_cost=self.slot_cost[slot])
+            sc.trace_primary_batch(cams, p.resx, p.resy, outs, stats=stats, stream=st, order=order, slot_cost=self.slot_cost[slot],
+                                   next_order=self.order_buf[slot] if key is not None else None)      # (a refresh: derived inside this launch, in place)
             if events: events[1].record(st)
-            if key is not None: self._refresh_order(slot, st, key)
+            if key is not None: self._order_refreshed(slot, key)
         else:
             sc.trace_primary_batch(cams, p.resx, p.resy, outs, stats=stats, stream=st)
             if events: events[1].record(st)

@@ -205,12 +205,20 @@ class Scene:
         _lib.check(rc, "snail_trace_primary_dev")
         return out
 
-    def trace_primary_batch(self, cams, resx: int, resy: int, outs, stats=None, stream=None, order=None, slot_cost=None):
+    def trace_primary_batch(self, cams, resx: int, resy: int, outs, stats=None, stream=None, order=None, slot_cost=None, next_order=None):
         """ONE launch for len(cams) frames (<= 8) of the whole image, each with its own camera and HitFrame (snail_trace_primary_batch_dev):
-        the heaviest packets of all the frames first, one tail and one set of launch overheads for all of them."""
+        the heaviest packets of all the frames first, one tail and one set of launch overheads for all of them.  next_order (int32 device tensor of
+        primary_slots entries; may be `order` itself; needs slot_cost): the order the NEXT launch should use, derived from this launch's costs inside the
+        launch (snail_trace_primary_batch_reorder_dev: no kernel launch of its own)."""
         n = len(cams)
         cam13 = np.ascontiguousarray(np.stack([c.as_array13() for c in cams]), dtype=np.float32)
         arr = lambda xs: (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+        if next_order is not None:
+            rc = _lib.lib().snail_trace_primary_batch_reorder_dev(self._h, n, _lib.ptr(cam13), resx, resy, arr([o.t for o in outs]), arr([o.u for o in outs]),
+                                                                  arr([o.v for o in outs]), arr([o.tri_id for o in outs]), _lib.ptr(stats), _lib.ptr(order),
+                                                                  _lib.ptr(slot_cost), _lib.ptr(next_order), _stream_ptr(stream))
+            _lib.check(rc, "snail_trace_primary_batch_reorder_dev")
+            return outs
         rc = _lib.lib().snail_trace_primary_batch_dev(self._h, n, _lib.ptr(cam13), resx, resy, arr([o.t for o in outs]), arr([o.u for o in outs]),
                                                       arr([o.v for o in outs]), arr([o.tri_id for o in outs]), _lib.ptr(stats), _lib.ptr(order),
                                                       _lib.ptr(slot_cost), _stream_ptr(stream))
@@ -353,7 +361,7 @@ class Scene:
     WHITTED_STAGES = 4
 
     def render_whitted(self, cam: Camera, resx: int, resy: int, lights7, ambient=(0.1, 0.1, 0.1), color=(1.0, 1.0, 1.0), out=None, stats=None,
-                       stream=None, reflections: bool = False, order=None, slot_cost=None):
+                       stream=None, reflections: bool = False, order=None, slot_cost=None, next_order=None):
         """Scene::RayTrace in the reference's simple-shading configuration (primary + one shadow packet per point light;
         reflections=True = gVals[7], one mirrored bounce shaded the same way), staged on the device; returns the interleaved
         [resy,resx,3] uint8 (B,G,R) frame.  lights7 = n x {pos, color, radius} (class Light, src/light.h:5-16); defaults =
@@ -370,6 +378,14 @@ class Scene:
             for a in (order, slot_cost):
                 if a is not None and (tuple(a.shape) != (self.WHITTED_STAGES, n) or a.dtype != torch.int32 or not a.is_contiguous()):
                     raise ValueError(f"order / slot_cost must be contiguous int32 tensors of shape ({self.WHITTED_STAGES}, {n})")
+            if next_order is not None:      # the next orders of all four stages derived inside this launch (may be `order` itself)
+                if tuple(next_order.shape) != (self.WHITTED_STAGES, n) or next_order.dtype != torch.int32 or not next_order.is_contiguous():
+                    raise ValueError(f"next_order must be a contiguous int32 tensor of shape ({self.WHITTED_STAGES}, {n})")
+                rc = _lib.lib().snail_render_whitted_reorder_dev(self._h, _lib.ptr(cam13), resx, resy, _lib.ptr(lights), len(lights), _lib.ptr(amb), _lib.ptr(col),
+                                                                 1 if reflections else 0, _lib.ptr(out), resx * 3, _lib.ptr(stats), _lib.ptr(order), _lib.ptr(slot_cost),
+                                                                 _lib.ptr(next_order), _stream_ptr(stream))
+                _lib.check(rc, "snail_render_whitted_reorder_dev")
+                return out
             rc = _lib.lib().snail_render_whitted_ordered_dev(self._h, _lib.ptr(cam13), resx, resy, _lib.ptr(lights), len(lights), _lib.ptr(amb), _lib.ptr(col),
                                                              1 if reflections else 0, _lib.ptr(out), resx * 3, _lib.ptr(stats), _lib.ptr(order), _lib.ptr(slot_cost),
                                                              _stream_ptr(stream))

@@ -1361,6 +1361,31 @@ def test_dispatch_order_feedback_changes_nothing_but_the_order(torch_mod, name, 
         compare_frames(f2, ref, label)
         assert np.array_equal(stats2.cpu().numpy().astype(np.uint64), ref[4]), label
         assert np.array_equal(cost2.cpu().numpy(), c), label
+    # the next order derived INSIDE the launch (snail_trace_primary_batch_reorder_dev: the last workgroup of the deferred-packet pass sorts the costs the
+    # traversal kernel has just written -- no launch of its own): the same costs, a permutation with the stand-alone sort's classes in descending order,
+    # hit records untouched; also IN PLACE (next_order = the order the launch reads) and for a two-frame launch
+    def classes_descend(perm_):
+        return bool((np.diff(np.minimum(c[perm_] >> shift, 4095)) <= 0).all())
+    nxt = torch_mod.full((n,), -1, dtype=torch_mod.int32, device="cuda")
+    cost3 = torch_mod.zeros_like(cost)
+    outs = [sc.alloc_frame(resx, resy)]
+    sc.trace_primary_batch([cam], resx, resy, outs, slot_cost=cost3, next_order=nxt)
+    torch_mod.cuda.synchronize()
+    o3 = nxt.cpu().numpy()
+    compare_frames(outs[0], ref, "reorder launch")
+    assert np.array_equal(cost3.cpu().numpy(), c) and np.array_equal(np.sort(o3), np.arange(n)) and classes_descend(o3)
+    buf = torch_mod.from_numpy(o[::-1].copy()).cuda()             # read lightest first, rewritten heaviest first
+    outs2 = [sc.alloc_frame(resx, resy), sc.alloc_frame(resx, resy)]
+    st4 = sc.new_stats()
+    sc.trace_primary_batch([cam, cam], resx, resy, outs2, stats=st4, order=buf, slot_cost=cost3, next_order=buf)
+    torch_mod.cuda.synchronize()
+    o4 = buf.cpu().numpy()
+    for f in outs2:
+        compare_frames(f, ref, "reorder launch, in place, two frames")
+    assert np.array_equal(st4.cpu().numpy().astype(np.uint64), 2 * ref[4])
+    assert np.array_equal(np.sort(o4), np.arange(n)) and classes_descend(o4) and np.array_equal(cost3.cpu().numpy(), c)
+    with pytest.raises(Exception, match="d_slot_cost"):
+        sc.trace_primary_batch([cam], resx, resy, outs, next_order=nxt)
     # packet-list form
     plan = R.ShardPlan.make(resx, resy, 1)
     xy = torch_mod.from_numpy(plan.packets[0]).cuda()
@@ -1610,6 +1635,19 @@ def test_staged_pipeline_dispatch_orders_change_nothing_but_the_order(torch_mod,
         assert np.array_equal(st.cpu().numpy().astype(np.uint64), wst), (what, st.cpu().numpy(), wst)
         for k in stages:
             assert np.array_equal(c2[k].cpu().numpy(), cst[k]), (what, k)        # a packet's cost does not depend on when it ran
+    # the next orders of every stage derived inside the launch, in place (snail_render_whitted_reorder_dev): same frame, same costs, each stage's buffer a
+    # permutation whose cost classes descend
+    buf = rev.clone()
+    c3 = torch_mod.zeros((S, n), dtype=torch_mod.int32, device="cuda")
+    st = sc.new_stats()
+    g = sc.render_whitted(cam, resx, resy, lights, stats=st, reflections=refl, order=buf, slot_cost=c3, next_order=buf).cpu().numpy()
+    assert np.array_equal(g, want) and np.array_equal(st.cpu().numpy().astype(np.uint64), wst)
+    ob = buf.cpu().numpy()
+    for k in stages:
+        assert np.array_equal(c3[k].cpu().numpy(), cst[k]) and np.array_equal(np.sort(ob[k]), np.arange(n)), k
+        shift = 0
+        while (int(cst[k].max()) >> shift) > 4095: shift += 1
+        assert (np.diff(np.minimum(cst[k][ob[k]] >> shift, 4095)) <= 0).all(), k
     # the renderer with the feedback on (bench.py --config 3): frames of a moving camera equal the oracle's
     from snail_amd import render as R
     r = R.DistributedRenderer(sc, resx, resy, lights7=lights, reflections=refl, feedback_order=True, order_refresh=2)

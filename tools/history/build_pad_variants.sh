@@ -1,5 +1,5 @@
 #!/bin/bash
-# Builds the padded variants of libsnailhip.so that tools/exp_pad.sh times (run here, on the build host; the .so files travel to the
+# Builds the padded variants of libsnailhip.so that tools/history/exp_pad.sh times (run here, on the build host; the .so files travel to the
 # GPU box with the snapshot): the hand-written node loop with 20 extra instructions of one kind per node visit (SNAIL_EXP_PAD).
 set -eu
 cd "$(dirname "$0")/../snail_amd/csrc"

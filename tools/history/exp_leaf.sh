@@ -1,7 +1,7 @@
 #!/bin/bash
 # experiment: broadcast of a leaf's surviving triangle by ds_bpermute (product) vs v_readlane (-DSNAIL_EXP_LEAF_READLANE).
-# Build first, on the build host: tools/exp_leaf.sh build (-> snail_amd/exp/lib_readlane.so, travels with the snapshot); then on the GPU box:
-# tools/exp_leaf.sh.  Variants are loaded through SNAIL_LIB_PATH (snail_amd/_lib.py): the product library is never overwritten.
+# Build first, on the build host: tools/history/exp_leaf.sh build (-> snail_amd/exp/lib_readlane.so, travels with the snapshot); then on the GPU box:
+# tools/history/exp_leaf.sh.  Variants are loaded through SNAIL_LIB_PATH (snail_amd/_lib.py): the product library is never overwritten.
 set -u
 if [ "${1:-}" = build ]; then
   cd "$(dirname "$0")/../snail_amd/csrc" && mkdir -p ../exp

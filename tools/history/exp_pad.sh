@@ -1,6 +1,6 @@
 #!/bin/bash
 # experiment: throughput sensitivity to extra VALU / SALU / s_nop per node visit.  Build the variants first, on the build host:
-# tools/build_pad_variants.sh (-> snail_amd/exp/lib_*.so, which travel with the snapshot); results in profiles/README.md.  Runs on the
+# tools/history/build_pad_variants.sh (-> snail_amd/exp/lib_*.so, which travel with the snapshot); results in profiles/README.md.  Runs on the
 # GPU box.  Variants are loaded through SNAIL_LIB_PATH (snail_amd/_lib.py): the product library is never overwritten.
 set -u
 for v in base mulchain mul2 max3 subs mov salu20 nop20 vcmp rfl; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# the bench lines of tools/r2_final.sh alone (after profiles/traffic.json has been refreshed from that run's PMC passes)
+# the bench lines of tools/history/r2_final.sh alone (after profiles/traffic.json has been refreshed from that run's PMC passes)
 set -u
 O=gpurun_out/r2z; mkdir -p $O
 export TMPDIR=/tmp

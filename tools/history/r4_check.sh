@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-4 checkpoint on the GPU box: the whole -m gpu suite, then the bench lines the round's changes move.
-# usage: bash tools/r4_check.sh <tag> [notests]
+# usage: bash tools/history/r4_check.sh <tag> [notests]
 set -u
 T=${1:-a}; O=gpurun_out/r4$T; mkdir -p $O
 export TMPDIR=/tmp

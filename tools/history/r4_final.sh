@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-4 evidence of the current kernels (as tools/r3_final.sh), in TWO calls on the GPU box because of gpurun's 20-minute limit:
+# round-4 evidence of the current kernels (as tools/history/r3_final.sh), in TWO calls on the GPU box because of gpurun's 20-minute limit:
 #   bash tools/r4_final.sh pmc     PMC passes of the five workloads in BOTH arithmetics (configs 1, 4, 5 through bench.py; config 3 and the mirrored
 #                                  bounce through tools/whitted_once.py, every kernel); summaries -> gpurun_out/r4z/; then, in the build container:
 #                                  cp gpurun_out/r4z/r4_final_*pmc_summary.txt profiles/ && bash tools/r4_final.sh traffic
