@@ -3,6 +3,7 @@
 #   bash tools/r5_final.sh pmc_ieee | pmc_host_sse | pmc   PMC passes (one arithmetic per call fits gpurun's limit) of the five workloads in BOTH arithmetics (configs 1, 4, 5 through bench.py; config 3 and the mirrored
 #                                  bounce through tools/whitted_once.py, every kernel); summaries -> gpurun_out/r5z/; then, in the build container:
 #                                  cp gpurun_out/r5z/r5_final_*pmc_summary.txt profiles/ && bash tools/r5_final.sh traffic
+#   bash tools/r5_final.sh prof    rocprofv3 --kernel-trace --stats of the bench commands (kernel-stats CSVs)
 #   bash tools/r5_final.sh bench   bench lines (the driver's command x3, default long run, --arith ieee, orbit and dolly cameras, configs 3 / 3 + bounce /
 #                                  4 / 5, the two-rank rehearsal of the plain `--gpus 2` command), rocprofv3 kernel stats of the same commands, soak runs
 set -u
@@ -51,6 +52,8 @@ for f in sorted(glob.glob('gpurun_out/r5z/bench_*.json')):
         print(f.split('/')[-1], d['config']['arith'], d['value'], d['ms_per_step'], 'lone', r.get('lone_frame_ms'), d['config'].get('lone_launch_ms'), 'frac', r['frac'], r.get('frac_of_measured_issue_rate'), 'stale', r.get('counters_stale'), 'hbm', r.get('hbm_frac_traffic'), 'verified', d.get('verified'), 'other', (r.get('other_arith') or {}).get('value'), 'cpu', (d.get('cpu_baseline') or {}).get('value'), 'fpl1', (r.get('one_frame_per_launch') or {}).get('value'))
     except Exception as e: print(f, 'ERR', e)
 PY
+  ;;
+prof)
   prof() { # name, command...
     local name=$1; shift
     ( cd /tmp && timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -- "$@" > $GRAFT_REPO_ROOT/$O/prof_$name.log 2>&1 )
@@ -65,5 +68,5 @@ PY
   prof config3 python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --config 3 --steps 400
   prof config3_refl python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --config 3 --reflections --steps 200
   ;;
-*) echo "usage: bash tools/r5_final.sh pmc_ieee|pmc_host_sse|pmc|traffic|bench"; exit 1;;
+*) echo "usage: bash tools/r5_final.sh pmc_ieee|pmc_host_sse|pmc|traffic|bench|prof"; exit 1;;
 esac
