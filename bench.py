@@ -455,6 +455,14 @@ def main():
     tot = rnd.reduce_stats(st) if world > 1 else st
     total_rays = int(tot.cpu().numpy()[2]) if (rank == 0 and cfg["lights"]) else primary_rays
     node_visits = int(tot.cpu().numpy()[1]) if rank == 0 else 0
+    # the two diagnostic passes (N = 1), outside the timed region AND before the settle / warm-up frames (round 5: they used to sit between the W warm-up steps
+    # and the timed region -- several milliseconds of an almost idle GPU right before a 1.7 ms timed region, which then measured the part's clock ramp: on this
+    # round's boxes the driver's 20-step command read 23.2-23.5 Grays/s that way and 26.0-26.3 when timed straight after warm frames)
+    acc = pk = None
+    if rank == 0 and world == 1:
+        acc = scene.account_primary(cam, resx, resy)                      # single-ray accounting walk (SURVEY 8d), informational
+        pk = scene.packet_costs(cam, resx, resy)                          # per-packet {visits, ..., triangle records fetched, ...}
+    barrier()
     # settle: untimed frames of the run's own camera path for `--settle-ms`.  The count comes from a measured probe of THIS workload (two
     # rounds of the pipeline, rank 0's clock) and is the same on every rank -- the ranks' collectives must pair up -- by a MAX all-reduce
     settle_frames, settle_measured_ms = 0, 0.0
@@ -483,25 +491,19 @@ def main():
         torch.cuda.synchronize()
         settle_measured_ms = (time.perf_counter() - t1) * 1e3
     warm0 = settle_frames + (6 * rnd.nslots * rnd.batch if args.settle_ms > 0 else 0)     # the path goes on where the settle frames stopped
+    # (what the timed loop needs is made BEFORE the warm-up steps, so that nothing but the barrier + synchronize stands between them and the timed region)
+    every = -(-max(1, args.event_every) // rnd.batch) * rnd.batch
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if i % every == 0 else None for i in range(args.steps)]
+    cams_timed = [cam_at(warm0 + args.warmup + i) for i in range(args.steps)]
     for i in range(args.warmup):
         rnd.render(cam_at(warm0 + i))
     rnd.flush()
-    barrier()
-
-    # the two diagnostic passes (N = 1), outside the timed region
-    acc = pk = None
-    if rank == 0 and world == 1:
-        acc = scene.account_primary(cam, resx, resy)                      # single-ray accounting walk (SURVEY 8d), informational
-        pk = scene.packet_costs(cam, resx, resy)                          # per-packet {visits, ..., triangle records fetched, ...}
     barrier()
 
     # ---- timed region: EXACTLY K steps (frames are pipelined over the renderer's HIP streams, see DistributedRenderer) ----
     # HIP events bracket every `--event-every`-th launch on the stream it is launched on (an event record is a barrier packet in the
     # stream: bracketing every launch costs ~2 % of the frame rate; the average is taken over steps / event_every launches)
     # (a launch of B frames keeps ONE pair, that of its first frame: the stride is a multiple of B)
-    every = -(-max(1, args.event_every) // rnd.batch) * rnd.batch
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if i % every == 0 else None for i in range(args.steps)]
-    cams_timed = [cam_at(warm0 + args.warmup + i) for i in range(args.steps)]
     t0 = time.perf_counter()
     for e, c in zip(ev, cams_timed):
         rnd.render(c, events=e)
