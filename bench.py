@@ -33,7 +33,8 @@ Arithmetic: the reference's x86 build computes Inv / RSqrt / FastInv with rcpps 
 parity bar is against THAT path.  `--arith auto` (default) therefore runs the kernels in SNAIL_ARITH_HOST_SSE -- the host CPU's two instructions reproduced on
 the device from verified tables, results equal to the reference's SSE path bit for bit -- and falls back to veclib's scalar definitions (SNAIL_ARITH_IEEE,
 host-independent results, ~2 % faster) only on a host whose instructions cannot be tabulated; `config.arith` says which ran, `roofline.other_arith` carries
-the other arithmetic's rate for the same K steps (N = 1), and `verified` = the timed region's output hashed equal to the committed digest of the oracle's frame.
+the other arithmetic's rate for the same K steps (N = 1), and `verified` = the timed region's output hashed equal to the frame the oracle renders on this box after the
+timed region, in the timed arithmetic (`verification.live_oracle`), and to the committed digest of the oracle's frame where one exists (`verification.committed`).
 
 Mrays = rays launched (every lane of every traced packet, hit or miss), as TreeStats::TracingRays counts them
 (src/scene_trace.cpp:116-117): frames are padded to whole 16x16 packets (1920x1080 -> 1920x1088); config 3 adds the shadow

@@ -118,6 +118,9 @@ int snail_host_sse_tables(uint32_t *tables12288);
  * that device's work in flight): set the tables first, then the scenes' arithmetic.  snail_host_sse_tables returns the tables in force;
  * snail_host_sse_check keeps comparing with THIS host's instructions.  Returns 1 for tables that are not tables of reciprocals. */
 int snail_arith_set_tables(const uint32_t *tables12288);
+/* The CURRENT device's copy of the tables in force, for the one scene-less entry point that computes in this arithmetic (snail_shade_depth_arith_dev):
+ * made or refreshed now (synchronises the device), so that later calls -- inside a stream capture, say -- find it current. */
+int snail_arith_prepare_device(void);
 /* The table rule against the instruction itself over the float bit patterns [first, first + count) (fn 0 = rcpps, 1 = rsqrtps), on
  * `threads` host threads: *mismatches = inputs whose result bits differ, *firstBad = the lowest of them.  No device needed. */
 int snail_host_sse_check(int fn, uint64_t first, uint64_t count, int threads, uint64_t *mismatches, uint32_t *firstBad);
@@ -229,7 +232,10 @@ int snail_trace_shadow_dev(SnailScene *, int nPackets, int size, const float *d_
  * d_bgr: packet-major bytes [nPackets][256][3].  This is what a render node returns per tile in the reference
  * (RGB8, src/node.cpp:336-349) and what the multi-GPU path gathers over xGMI. */
 int snail_shade_depth_dev(const float *d_t, int nPackets, uint8_t *d_bgr, void *stream);
-/* (the same with the arithmetic of Inv(t) named: SNAIL_ARITH_*; the call above = SNAIL_ARITH_IEEE) */
+/* (the same with the arithmetic of Inv(t) named: SNAIL_ARITH_*; the call above = SNAIL_ARITH_IEEE.  This entry point takes no scene: in SNAIL_ARITH_HOST_SSE it
+ * computes with a copy of the tables in force kept per DEVICE, made at the first such call on that device and again at the first one after
+ * snail_arith_set_tables -- a synchronising refresh, which a stream capture cannot contain: there the call returns 3 unless snail_arith_prepare_device()
+ * has been called on that device since the tables last changed.  Scene-bound launches never refresh anything: their tables are the scene's.) */
 int snail_shade_depth_arith_dev(const float *d_t, int nPackets, uint8_t *d_bgr, int arith, void *stream);
 /* Scatter packet-major BGR bytes into an interleaved rgb8 frame (pitch bytes per row), clipped to the image. */
 int snail_packets_bgr_to_frame_dev(const int32_t *d_packet_xy, int nPackets, int resx, int resy, const uint8_t *d_bgr,

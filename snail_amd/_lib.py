@@ -34,6 +34,7 @@ SIGNATURES = {
     "snail_scene_arith": (_I, [_VP, _VP]),
     "snail_host_sse_tables": (_I, [_VP]),
     "snail_arith_set_tables": (_I, [_VP]),
+    "snail_arith_prepare_device": (_I, []),
     "snail_host_sse_check": (_I, [_I, C.c_uint64, C.c_uint64, _I, _VP, _VP]),
     "snail_scene_create_lbvh": (_VP, [_VP, _I, _I, _I, _VP, _VP]),
     "snail_scene_download": (_I, [_VP, _VP, _VP]),

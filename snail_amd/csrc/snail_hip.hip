@@ -293,7 +293,9 @@ int hostSseFill(const char *fn, unsigned **dTab, unsigned *tabGen) {
 }
 // ... for the entry points that take no scene (snail_shade_depth_arith_dev; the workbench's device check): one buffer per device, refreshed -- lazily, at
 // the call that finds it stale -- like a scene's
-int hostSseDeviceTables(const char *fn, const unsigned **out) {
+// `capturing`: the caller's stream is being captured into a graph -- a stale buffer cannot be refreshed there (the refresh drains the device): an error that
+// names the remedy (snail_arith_prepare_device before the capture) instead of a broken capture.
+int hostSseDeviceTables(const char *fn, const unsigned **out, bool capturing = false) {
 	static std::mutex mu;
 	static unsigned *tab[64] = {};
 	static unsigned gen[64] = {};
@@ -301,7 +303,15 @@ int hostSseDeviceTables(const char *fn, const unsigned **out) {
 	HIP_TRY(hipGetDevice(&devId));
 	if(devId < 0 || devId >= 64) { snail_set_error("%s: device index %d", fn, devId); return 1; }
 	std::lock_guard<std::mutex> lock(mu);
-	if(int rc = hostSseFill(fn, &tab[devId], &gen[devId])) return rc;
+	if(capturing) {
+		unsigned now = 0;
+		const char *why = "";
+		if(hostSseSnapshot(nullptr, &now, &why)) { snail_set_error("%s: SNAIL_ARITH_HOST_SSE is not available on this host: %s", fn, why); return 2; }
+		if(!tab[devId] || gen[devId] != now) {
+			snail_set_error("%s: this device's copy of the rcpps / rsqrtps tables is missing or stale and the stream is being captured: call snail_arith_prepare_device() before the capture", fn);
+			return 3;
+		}
+	} else if(int rc = hostSseFill(fn, &tab[devId], &gen[devId])) return rc;
 	*out = tab[devId];
 	return 0;
 }
@@ -926,6 +936,10 @@ int snail_arith_set_tables(const uint32_t *tables12288) {
 	if(hostSseSetTables(tables12288, &why)) { snail_set_error("snail_arith_set_tables: %s", why); return 1; }
 	return 0;
 }
+int snail_arith_prepare_device(void) {
+	const unsigned *tab = nullptr;
+	return hostSseDeviceTables("snail_arith_prepare_device", &tab);
+}
 int snail_host_sse_tables(uint32_t *tables12288) {
 	const char *why = "";
 	if(hostSseSnapshot((unsigned *)tables12288, nullptr, &why)) { snail_set_error("snail_host_sse_tables: %s", why); return 2; }
@@ -1356,7 +1370,11 @@ int snail_shade_depth_arith_dev(const float *t, int nPackets, uint8_t *bgr, int 
 	if(!t || !bgr) { snail_set_error("snail_shade_depth_dev: null buffer"); return 1; }
 	if(arith != SNAIL_ARITH_IEEE && arith != SNAIL_ARITH_HOST_SSE) { snail_set_error("snail_shade_depth_arith_dev: unknown arithmetic %d", arith); return 1; }
 	const unsigned *tab = nullptr;
-	if(arith == SNAIL_ARITH_HOST_SSE) { if(int rc = hostSseDeviceTables("snail_shade_depth_arith_dev", &tab)) return rc; }
+	if(arith == SNAIL_ARITH_HOST_SSE) {
+		hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+		if(stream) (void)hipStreamIsCapturing((hipStream_t)stream, &cap);
+		if(int rc = hostSseDeviceTables("snail_shade_depth_arith_dev", &tab, cap == hipStreamCaptureStatusActive)) return rc;
+	}
 	const int n = nPackets * 256;
 	if(arith == SNAIL_ARITH_HOST_SSE) hipLaunchKernelGGL(dev_sse::k_shade_depth, dim3((n / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, tab, t, n, bgr);
 	else hipLaunchKernelGGL(dev::k_shade_depth, dim3((n / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, tab, t, n, bgr);

@@ -151,8 +151,11 @@ def test_dev_entry_points_from_threads_on_their_own_streams(torch_mod):
     def body(k):
         st = torch.cuda.Stream()
         for f in range(frames):
-            outs[k][f] = sc.trace_primary(cam_of(k, f), resx, resy, stats=stats[k], stream=st)
-            lit[k][f] = sc.render_whitted(cam_of(k, f), resx, resy, light_of(k, f), stream=st, reflections=(f % 4 == 3))
+            with torch.cuda.stream(st):      # (the buffers' initial fills on the launches' stream: torch's side streams do not wait for the null stream)
+                fr = sc.alloc_frame(resx, resy)
+                img = torch.zeros((resy, resx, 3), dtype=torch.uint8, device="cuda")
+            outs[k][f] = sc.trace_primary(cam_of(k, f), resx, resy, out=fr, stats=stats[k], stream=st)
+            lit[k][f] = sc.render_whitted(cam_of(k, f), resx, resy, light_of(k, f), out=img, stream=st, reflections=(f % 4 == 3))
         st.synchronize()
 
     run_threads(body, nthreads)
