@@ -198,6 +198,7 @@ struct HostCallScope {
 	SnailScene *s;
 	SnailScene::HostCall *c = nullptr;
 	int rc = 0;
+	bool finished = false;
 	HostCallScope(SnailScene *scene, const char *fn) : s(scene) {
 		{
 			std::lock_guard<std::mutex> lock(s->mu);
@@ -217,6 +218,8 @@ struct HostCallScope {
 	}
 	~HostCallScope() {
 		if(!c) return;
+		// a call that returns early (an error after something was enqueued) must not leave copies into the CALLER's memory in flight
+		if(!finished) (void)hipStreamSynchronize(c->stream);
 		std::lock_guard<std::mutex> lock(s->mu);
 		s->hostFree.push_back(c);
 	}
@@ -253,6 +256,7 @@ struct HostCallScope {
 		unsigned long long hs[4] = {0, 0, 0, 0};
 		if(stats) HIP_TRY(hipMemcpyAsync(hs, c->dStats, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
+		finished = true;
 		if(stats) for(int k = 0; k < 4; k++) stats[k] += hs[k];
 		return 0;
 	}
