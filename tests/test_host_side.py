@@ -407,3 +407,22 @@ def test_arith_tables_of_another_cpu_are_taken_and_given_back():
         model = next((l for l in f if l.startswith("model name")), "")
     if "Xeon(R) Processor @ 2.10GHz" in model:
         assert np.array_equal(own, tabs["xeon_skylake_sp"])
+
+
+def test_header_is_a_c_header_and_the_host_entry_points_run_from_c(tmp_path):
+    """include/snail_hip.h compiles as PLAIN C (gcc -std=c99 -Wall -Werror -pedantic), every function it declares links against libsnailhip.so, and the entry
+    points that need no GPU run from a C host: the SAH builder on the reference's cube, the rcpps / rsqrtps table probe, error reporting by status + text
+    (tests/c/abi_c.c).  Any FFI a host language of the reference's world would use -- cgo, JNI, ctypes -- binds exactly this."""
+    import subprocess
+    exe = str(tmp_path / "abi_c")
+    libdir = os.path.join(ROOT, "snail_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", os.path.join(ROOT, "tests", "c", "abi_c.c"), "-o", exe, "-L" + libdir, "-lsnailhip",
+                           "-Wl,-rpath," + libdir])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "C ABI ok: 9 nodes, depth 4" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    # ... and the list of addresses taken there is the header's list of declarations
+    decl = set(re.findall(r"\b(snail_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "snail_hip.h")).read())) - {"snail_hip"}
+    used = set(re.findall(r"ADDR\((snail_[a-z0-9_]+)\)", open(os.path.join(ROOT, "tests", "c", "abi_c.c")).read()))
+    from snail_amd._lib import SIGNATURES
+    assert used == set(SIGNATURES), (sorted(set(SIGNATURES) - used), sorted(used - set(SIGNATURES)))
+    assert set(SIGNATURES) <= decl
