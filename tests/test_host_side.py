@@ -308,7 +308,7 @@ def json_budget_host_sse():
     culled packet shares the traced packet's epilogue -- 8 spilled registers where round 4 had 31; the mirrored-ray generator of k_final 51 VGPRs where it had 81)"""
     return {
         "k_primaryILb0E": {"vgprs": 80, "waves": 6},
-        "k_lightILb0ELi0E": {"vgprs": 80, "waves": 6, "vgpr_spill": 10, "sgpr_spill": 8},
+        "k_lightILb0ELi0E": {"vgprs": 80, "waves": 6, "vgpr_spill": 10, "sgpr_spill": 10},
         "k_lightILb0ELi1E": {"vgprs": 80, "waves": 6, "vgpr_spill": 4, "sgpr_spill": 4},
         "k_finalILi0ELi1E": {"vgprs": 80, "waves": 6},
         "k_raysILb0ELb1ELb0ELb0E": {"vgprs": 96, "waves": 5},
@@ -323,7 +323,7 @@ def json_budget():
         "k_shadowILb0E": {"vgprs": 88, "waves": 5},                # the compiler's own allocation: nothing spilled
         # six-wave budget; round 4: the kernel also finishes its packet when the frame has ONE light (the tail of TraceLight, the colour and the
         # store, k_final's work): what is spilled is the sample set-up before the walk and that epilogue after it, one register inside the walk as before
-        "k_lightILb0ELi0E": {"vgprs": 80, "waves": 6, "vgpr_spill": 10, "sgpr_spill": 8},
+        "k_lightILb0ELi0E": {"vgprs": 80, "waves": 6, "vgpr_spill": 10, "sgpr_spill": 10},
         "k_lightILb0ELi1E": {"vgprs": 80, "waves": 6, "vgpr_spill": 4, "sgpr_spill": 4},
         "k_finalILi0ELi1E": {"vgprs": 80, "waves": 6},
         "k_raysILb0ELb1ELb0ELb0E": {"vgprs": 96, "waves": 5},      # mirrored packets (per-ray origins, masks): the compiler's own allocation, nothing spilled

@@ -213,3 +213,39 @@ def collapsed_tree(hb, max_leaf):
     new = np.array(out, dtype=nodes.dtype)
     assert int(new["aux"][(new["sub"] & 0x80000000) != 0].max()) > 4
     return HostBVH(hb.tris, new, depth, hb.perm)
+
+
+def interleave16(b):
+    """block -> slot of the kernels' built-in dispatch order (dev::interleave16: 16 consecutive slots per XCD turn)"""
+    b = np.asarray(b)
+    xcd, j = b & 7, b >> 3
+    return (((j >> 4) << 3) + xcd) * 16 + (j & 15)
+
+
+def check_derived_order(cost, order, adaptive=3):
+    """A dispatch order the library derived from per-slot costs (snail_order_from_cost_dev, the *_reorder_dev launches; up to 49152 slots): a permutation, and
+    -- by the rule of dev::orderSortBlock -- the SORTED one (cost classes of max >> shift <= 4095, descending) when the costs are heavy-tailed (the class of the
+    slot at the 99th percentile, times the slot count, at least `adaptive` times the sum of the costs), the kernels' BUILT-IN order otherwise.  Returns which."""
+    c = np.minimum(np.maximum(np.asarray(cost, dtype=np.int64), 0), 65535)
+    o = np.asarray(order, dtype=np.int64)
+    n = len(c)
+    assert np.array_equal(np.sort(o), np.arange(n)), "order is not a permutation"
+    shift = 0
+    while (int(c.max()) >> shift) > 4095:
+        shift += 1
+    cls = 4095 - np.minimum(c >> shift, 4095)                       # class 0 = heaviest
+    counts = np.bincount(cls, minlength=4096)
+    start = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    want = max(n // 100, 1)
+    p99 = 4095
+    for k in np.flatnonzero(counts):
+        if start[k] < want <= start[k] + counts[k]:
+            p99 = int(k)
+    heavy_tailed = ((4095 - p99) << shift) * n >= adaptive * int(c.sum())
+    if heavy_tailed:
+        assert (np.diff(cls[o]) >= 0).all(), "heavy-tailed costs: cost classes must descend"
+        return "sorted"
+    n128 = (n + 127) // 128 * 128
+    nat = interleave16(np.arange(n128))
+    assert np.array_equal(o, nat[nat < n]), "costs without a heavy tail: the built-in dispatch order"
+    return "built-in"
