@@ -163,10 +163,14 @@ int snail_trace_packets_shaded_dev(SnailScene *, const float cam[13], int resx, 
  * number of its packets; some slots hold no packet) and nPackets for a list:
  *   d_slot_cost (out): node visits of each slot's packet in THIS launch (0 for an empty slot);
  *   d_order     (in) : the slot each workgroup takes, a permutation of [0, nSlots); NULL = the built-in order.
- * snail_order_from_cost_dev turns the costs of one frame into the order of the next (heaviest first: a counting sort over 4096 cost
- * classes, the order inside a class arbitrary; stream-ordered, one small kernel on the CURRENT device, no scratch; costs below zero count
- * as zero and, for inputs of up to 49152 slots, costs above 65535 as 65535).  Results never depend on the order: hit records and
- * counters are identical.
+ * snail_order_from_cost_dev turns the costs of one frame into the order of the next (stream-ordered, one small kernel on the CURRENT
+ * device, no scratch; costs below zero count as zero and, for inputs of up to 49152 slots, costs above 65535 as 65535).  The order it
+ * writes is ALWAYS a permutation of [0, nSlots); which one is the library's choice (round 5): for HEAVY-TAILED costs -- the cost of the
+ * slot at the 99th percentile at least 3x the mean cost -- heaviest first (a counting sort over 4096 cost classes, the order inside a
+ * class arbitrary), so that the launch does not end on a few long packets; for flatter costs the built-in order (neighbouring packets on
+ * the same XCD, whose L2 then holds their subtrees), which is what measures faster there and does not age when the camera moves.  Inputs
+ * of more than 49152 slots or not 16-byte aligned take a multi-pass kernel that always sorts.  The *_reorder_dev launches below apply the
+ * same rule.  Results never depend on the order: hit records and counters are identical.
  * The caller keeps d_order unchanged while a launch reading it is in flight. */
 int snail_primary_slots(int w, int h);
 int snail_trace_primary_ordered_dev(SnailScene *, const float cam[13], int resx, int resy, int x0, int y0, int w, int h,
