@@ -341,7 +341,7 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="frames in flight (HIP streams); 0 = the renderer's default (4); 1 = strictly serial frames")
     ap.add_argument("--event-every", type=int, default=8, help="bracket every n-th traversal launch with HIP events (roofline.kernel_ms)")
     ap.add_argument("--feedback-order", type=int, default=1, help="1 (default) = dispatch packets heaviest first by the node visits of an earlier frame (DistributedRenderer feedback_order)")
-    ap.add_argument("--frames-per-launch", type=int, default=0, help="trace this many frames (1..8) with one launch -- and, at N > 1, move them with one collective (DistributedRenderer frames_per_launch); 0 = enough for a launch to hold 8160 packets (one 1080p frame), at least 2, at most 8: 2 / 2 / 4 / 8 at N = 1 / 2 / 4 / 8; config 3 always 1")
+    ap.add_argument("--frames-per-launch", type=int, default=0, help="trace this many frames (1..8) with one launch -- and, at N > 1, move them with one collective (DistributedRenderer frames_per_launch); 0 = enough for a launch to hold 8160 packets (one 1080p frame), at most 8, at least 4 on one GPU and 2 on several: 4 / 2 / 4 / 8 at N = 1 / 2 / 4 / 8; config 3 always 1")
     ap.add_argument("--lone-frames", type=int, default=12, help="frames (N > 1: launches through the whole route) traced one at a time after the timed region (lone_frame_ms / lone_launch_ms); 0 = skip")
     ap.add_argument("--camera-path", default="static", choices=["static", "orbit", "dolly"], help="dolly = the camera's position advances 0.01 units along its viewing direction every step (every frame needs a new origin-relative node array); orbit = the camera turns 0.2 degrees every step (dispatch orders are then predictions from an older view, re-derived every --order-refresh frames of a slot, inside the timed region)")
     ap.add_argument("--settle-ms", type=float, default=30.0, help="untimed frames for this many milliseconds BEFORE the W warm-up steps: the part's clocks ramp for tens of ms after an idle start (2.09 -> 1.91 -> 2.2 GHz over the first 600 frames, profiles/README.md), which a 20-step timed region would otherwise measure instead of the kernel; 0 = off; reported as config.settle_ms")
@@ -431,9 +431,10 @@ def main():
         bmin, bmax = hbvh.bbox()
         c, e = (bmin + bmax) * 0.5, (bmax - bmin)
         lights7 = np.array([[c[0], c[1] + 0.35 * e[1], c[2], 1.0, 0.9, 0.8, 2.0 * float(e.max())]], dtype=np.float32)   # one point light above the nave
-    # frames per launch, unless given: enough for a launch to hold at least one 1080p frame's worth of packets (8160), at least 2, at most 8
+    # frames per launch, unless given: enough for a launch to hold at least one 1080p frame's worth of packets (8160), at most 8; at least 4 on one GPU (round 5,
+    # profiles/r5_shapes.txt: 4 streams x 4 frames against 4 x 2 -- the driver's 20-step run +3..6 %, the long run +1.4 %, 4K +0.5 %, stress-1M -0.7 %), 2 on several
     per_rank = ((resx + 15) // 16) * ((resy + 15) // 16) / float(world)
-    auto_fpl = int(min(8, max(2, math.ceil(8160.0 / max(1.0, per_rank)))))
+    auto_fpl = int(min(8, max(4 if world == 1 else 2, math.ceil(8160.0 / max(1.0, per_rank)))))
     rnd = DistributedRenderer(scene, resx, resy, rank, world, slots=args.streams if args.streams > 0 else None, stage_cpu=rehearsal,
                               feedback_order=bool(args.feedback_order), lights7=lights7, reflections=bool(args.reflections and cfg["lights"]), rank0_share=args.rank0_share,
                               frames_per_launch=args.frames_per_launch if args.frames_per_launch > 0 else auto_fpl, order_refresh=args.order_refresh)

@@ -170,7 +170,11 @@ int snail_trace_packets_shaded_dev(SnailScene *, const float cam[13], int resx, 
  * class arbitrary), so that the launch does not end on a few long packets; for flatter costs the built-in order (neighbouring packets on
  * the same XCD, whose L2 then holds their subtrees), which is what measures faster there and does not age when the camera moves.  Inputs
  * of more than 49152 slots or not 16-byte aligned take a multi-pass kernel that always sorts.  The *_reorder_dev launches below apply the
- * same rule.  Results never depend on the order: hit records and counters are identical.
+ * same rule.  A caller who KNOWS the costs to be exact for the launches that will use the order -- the same camera, a still view -- says so
+ * with SNAIL_ORDER_SORTED (snail_order_from_cost_hint_dev, the order_flags of the *_reorder_dev launches): then the order is the sorted one
+ * whatever the shape of the costs, which ends a short run of frames ~4 % sooner (the last frames' tails are their heaviest packets) and costs
+ * a long one nothing; with costs of an earlier VIEW it would be the wrong choice for flat costs, hence the default.
+ * Results never depend on the order: hit records and counters are identical.
  * The caller keeps d_order unchanged while a launch reading it is in flight. */
 int snail_primary_slots(int w, int h);
 int snail_trace_primary_ordered_dev(SnailScene *, const float cam[13], int resx, int resy, int x0, int y0, int w, int h,
@@ -179,14 +183,17 @@ int snail_trace_primary_ordered_dev(SnailScene *, const float cam[13], int resx,
 int snail_trace_packets_ordered_dev(SnailScene *, const float cam[13], int resx, int resy, const int32_t *d_packet_xy, int nPackets,
                                     float *d_t, float *d_u, float *d_v, int32_t *d_triId, uint64_t *d_stats,
                                     const int32_t *d_order, int32_t *d_slot_cost, void *stream);
-int snail_order_from_cost_dev(const int32_t *d_slot_cost, int nSlots, int32_t *d_order, void *stream);
+#define SNAIL_ORDER_AUTO 0   /* order_flags: the library's rule above */
+#define SNAIL_ORDER_SORTED 1 /*              heaviest first whatever the shape of the costs (the caller knows them to be exact) */
+int snail_order_from_cost_dev(const int32_t *d_slot_cost, int nSlots, int32_t *d_order, void *stream);   /* = ..._hint_dev(.., SNAIL_ORDER_AUTO, ..) */
+int snail_order_from_cost_hint_dev(const int32_t *d_slot_cost, int nSlots, int32_t *d_order, int order_flags, void *stream);
 /* Dispatch-order feedback WITHOUT a launch of its own (round 5): the *_reorder_dev forms of the multi-frame primary launch (below) and of the staged frame
  * (snail_render_whitted_reorder_dev) are their *_ordered_dev forms plus d_next_order (out; same shape as d_order; needs d_slot_cost): the order(s) the NEXT
  * such launch should use, derived from THIS launch's costs inside the launch -- by one extra workgroup of the small deferred-packet pass that follows every
  * traversal kernel anyway -- so that a moving camera's order refresh costs no kernel launch, no stream round trip and no second pass over the costs.  d_next_order
- * may be d_order itself (the traversal kernel that reads d_order has finished when it is rewritten).  Same classes, same descending order as
- * snail_order_from_cost_dev would give for those costs (the order inside a class is arbitrary in both); frames with more than 20480 slots fall back to
- * that kernel inside the call. */
+ * may be d_order itself (the traversal kernel that reads d_order has finished when it is rewritten).  The order snail_order_from_cost_hint_dev would
+ * give for those costs and order_flags (SNAIL_ORDER_AUTO / SNAIL_ORDER_SORTED; the order inside a class is arbitrary in both); frames with more than
+ * 20480 slots fall back to that kernel inside the call. */
 /* Multi-frame launches: ONE launch traces nFrames (1..SNAIL_MAX_BATCH) frames of the same rect / packet list, each with its own camera
  * (cams13: HOST array nFrames x 13) and its own output planes (HOST arrays of nFrames DEVICE pointers; a NULL array = that plane is not
  * wanted).  The heaviest packets of all the frames are dispatched first; a frame's tail -- ~0.2 ms whatever the launch holds -- and the
@@ -199,7 +206,7 @@ int snail_trace_primary_batch_dev(SnailScene *, int nFrames, const float *cams13
                                   int32_t *d_slot_cost, void *stream);
 int snail_trace_primary_batch_reorder_dev(SnailScene *, int nFrames, const float *cams13, int resx, int resy, float *const *d_t, float *const *d_u,
                                           float *const *d_v, int32_t *const *d_triId, uint64_t *d_stats, const int32_t *d_order,
-                                          int32_t *d_slot_cost, int32_t *d_next_order, void *stream);
+                                          int32_t *d_slot_cost, int32_t *d_next_order, int order_flags, void *stream);
 int snail_trace_packets_shaded_batch_dev(SnailScene *, int nFrames, const float *cams13, int resx, int resy, const int32_t *d_packet_xy,
                                          int nPackets, uint8_t *const *d_bgr, uint64_t *d_stats, void *stream);
 /* Scatter packet-major planes into row-major resx*resy frame planes (clipped to the image). */
@@ -310,7 +317,7 @@ int snail_render_whitted_ordered_dev(SnailScene *, const float cam[13], int resx
  * arrays of nSlots int32, back to back, as d_order; may be d_order itself. */
 int snail_render_whitted_reorder_dev(SnailScene *, const float cam[13], int resx, int resy, const float *lights7, int nLights,
                                      const float ambient[3], const float color[3], int flags, uint8_t *d_frame_bgr, int pitch, uint64_t *d_stats,
-                                     const int32_t *d_order, int32_t *d_slot_cost, int32_t *d_next_order, void *stream);
+                                     const int32_t *d_order, int32_t *d_slot_cost, int32_t *d_next_order, int order_flags, void *stream);
 
 /* The same for an explicit list of packets (a rank's tiles): output = packet-major B,G,R bytes [nPackets][256][3] (4-byte aligned),
  * to be gathered and scattered with snail_packets_bgr_to_frame_dev -- a render node with the reference's simple shading on. */

@@ -45,12 +45,13 @@ SIGNATURES = {
     "snail_trace_packets_shaded_dev": (_I, [_VP, _F13, _I, _I, _VP, _I, _VP, _VP, _VP]),
     "snail_trace_primary_batch_dev": (_I, [_VP, _I, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "snail_trace_packets_shaded_batch_dev": (_I, [_VP, _I, _VP, _I, _I, _VP, _I, _VP, _VP, _VP]),
-    "snail_trace_primary_batch_reorder_dev": (_I, [_VP, _I, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
-    "snail_render_whitted_reorder_dev": (_I, [_VP, _F13, _I, _I, _VP, _I, _VP, _VP, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP]),
+    "snail_trace_primary_batch_reorder_dev": (_I, [_VP, _I, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
+    "snail_render_whitted_reorder_dev": (_I, [_VP, _F13, _I, _I, _VP, _I, _VP, _VP, _I, _VP, _I, _VP, _VP, _VP, _VP, _I, _VP]),
     "snail_primary_slots": (_I, [_I, _I]),
     "snail_trace_primary_ordered_dev": (_I, [_VP, _F13, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "snail_trace_packets_ordered_dev": (_I, [_VP, _F13, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "snail_order_from_cost_dev": (_I, [_VP, _I, _VP, _VP]),
+    "snail_order_from_cost_hint_dev": (_I, [_VP, _I, _VP, _I, _VP]),
     "snail_packets_to_frame_dev": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "snail_trace_rays": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "snail_trace_rays_dev": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),

@@ -456,10 +456,12 @@ struct ExactPass {
 	dim3 grid, block;
 	size_t lds = 0;
 	int *nextOrder = nullptr;   // what the kernel's argument record gets
+	int orderFlags = 0;         // SNAIL_ORDER_* of the caller
 	bool sortAfter = false;
 };
-ExactPass exactPassFor(int exactBlocks, const int32_t *dSlotCost, int nSlots, int32_t *dNextOrder) {
+ExactPass exactPassFor(int exactBlocks, const int32_t *dSlotCost, int nSlots, int32_t *dNextOrder, int orderFlags) {
 	ExactPass e;
+	e.orderFlags = orderFlags;
 	e.grid = dim3((unsigned)exactBlocks); e.block = dim3(64);
 	if(!dNextOrder || !dSlotCost || nSlots <= 0) return e;
 	if(nSlots <= SORT_IN_LAUNCH_MAX && ((uintptr_t)dSlotCost & 15) == 0) {
@@ -472,7 +474,7 @@ ExactPass exactPassFor(int exactBlocks, const int32_t *dSlotCost, int nSlots, in
 
 int launchPrimaryFrames(SnailScene *s, const FrameSet &FS, int resx, int resy, int x0, int y0, int w, int h, const int32_t *dPacketXY, int nPackets, uint64_t *dStats,
 						hipStream_t stream, unsigned *dCost = nullptr, bool packetMajor = false, const int32_t *dOrder = nullptr, int32_t *dSlotCost = nullptr,
-						int32_t *dNextOrder = nullptr) {
+						int32_t *dNextOrder = nullptr, int orderFlags = 0) {
 	if(resx <= 0 || resy <= 0) { snail_set_error("snail_trace_primary: bad resolution %dx%d", resx, resy); return 1; }
 	if(dNextOrder && !dSlotCost) { snail_set_error("snail_trace_primary: the next dispatch order is derived from d_slot_cost, which is null"); return 1; }
 	if(FS.n < 1 || FS.n > SNAIL_MAX_BATCH || (SNAIL_BLOCK_WAVES > 1 && FS.n > 1)) { snail_set_error("snail_trace_primary: 1..%d frames per launch (got %d)", SNAIL_MAX_BATCH, FS.n); return 1; }
@@ -547,8 +549,8 @@ int launchPrimaryFrames(SnailScene *s, const FrameSet &FS, int resx, int resy, i
 	const int exactBlocks = A.fastOK ? (blocks < 8 ? blocks : 8) : (blocks < 2048 ? blocks : 2048);
 	static_assert(128 % SNAIL_BLOCK_WAVES == 0, "the slot count is a multiple of 128");
 	const dim3 grid(gridBlocks / SNAIL_BLOCK_WAVES), block(64 * SNAIL_BLOCK_WAVES);
-	const ExactPass EP = exactPassFor(exactBlocks, dSlotCost, A.nSlots, dCost ? nullptr : dNextOrder);
-	A.nextOrder = EP.nextOrder;
+	const ExactPass EP = exactPassFor(exactBlocks, dSlotCost, A.nSlots, dCost ? nullptr : dNextOrder, orderFlags);
+	A.nextOrder = EP.nextOrder; A.nextOrderFlags = EP.orderFlags;
 	const bool sse = s->arith == SNAIL_ARITH_HOST_SSE;
 	if(dCost) { // diagnostic launch (snail_account_packets)
 		if(useDeep(s)) SNAIL_LAUNCH(sse, PrimaryArgs, dim3(blocks), dim3(64), 0, stream, A, k_primary_diag<true>);
@@ -561,7 +563,7 @@ int launchPrimaryFrames(SnailScene *s, const FrameSet &FS, int resx, int resy, i
 	else if(useDeep(s)) SNAIL_LAUNCH(sse, PrimaryArgs, EP.grid, EP.block, EP.lds, stream, A, k_primary_exact<true>);
 	else SNAIL_LAUNCH(sse, PrimaryArgs, EP.grid, EP.block, EP.lds, stream, A, k_primary_exact<false>);
 	HIP_TRY(hipGetLastError());
-	if(EP.sortAfter) { if(int rc = snail_order_from_cost_dev(dSlotCost, A.nSlots, dNextOrder, stream)) return rc; }
+	if(EP.sortAfter) { if(int rc = snail_order_from_cost_hint_dev(dSlotCost, A.nSlots, dNextOrder, EP.orderFlags, stream)) return rc; }
 	HIP_TRY(hipEventRecord(s->deferDone[slot], stream));
 	s->deferUsed[slot] = true;
 	for(int k = 0; k < FS.n; k++)
@@ -572,11 +574,11 @@ int launchPrimaryFrames(SnailScene *s, const FrameSet &FS, int resx, int resy, i
 // one frame per launch (every entry point but the *_batch_dev ones)
 int launchPrimary(SnailScene *s, const float cam[13], int resx, int resy, int x0, int y0, int w, int h, const int32_t *dPacketXY,
 				  int nPackets, float *t, float *u, float *v, int32_t *id, uint64_t *dStats, hipStream_t stream, unsigned *dCost = nullptr,
-				  bool packetMajor = false, uint8_t *dBgr = nullptr, const int32_t *dOrder = nullptr, int32_t *dSlotCost = nullptr, int32_t *dNextOrder = nullptr) {
+				  bool packetMajor = false, uint8_t *dBgr = nullptr, const int32_t *dOrder = nullptr, int32_t *dSlotCost = nullptr, int32_t *dNextOrder = nullptr, int orderFlags = 0) {
 	FrameSet FS;
 	FS.n = 1; FS.cam[0] = cam;
 	FS.out[0].t = t; FS.out[0].u = u; FS.out[0].v = v; FS.out[0].id = (int *)id; FS.out[0].bgr = dBgr;
-	return launchPrimaryFrames(s, FS, resx, resy, x0, y0, w, h, dPacketXY, nPackets, dStats, stream, dCost, packetMajor, dOrder, dSlotCost, dNextOrder);
+	return launchPrimaryFrames(s, FS, resx, resy, x0, y0, w, h, dPacketXY, nPackets, dStats, stream, dCost, packetMajor, dOrder, dSlotCost, dNextOrder, orderFlags);
 }
 
 // scratch of one staged frame: ONE allocation, carved (hitT is its base); grown synchronously when a larger frame or the first
@@ -630,7 +632,7 @@ void launchRaysKernels(const SnailScene *s, const dev::RaysArgs &A, int blocks, 
 
 int launchRays(SnailScene *s, bool shadow, int nPackets, int size, int sharedOrigin, const float *origin, const float *dir,
 					  const float *idir, const uint8_t *mask, float *distance, int32_t *object, float *bary, uint64_t *dStats, hipStream_t stream,
-					  const int32_t *dOrder = nullptr, int32_t *dSlotCost = nullptr, int nSlots = 0, int32_t *dNextOrder = nullptr) {
+					  const int32_t *dOrder = nullptr, int32_t *dSlotCost = nullptr, int nSlots = 0, int32_t *dNextOrder = nullptr, int orderFlags = 0) {
 	if(nPackets <= 0) return 0;
 	if(size < 1 || size > SNAIL_PACKET_QUADS) { snail_set_error("packet size %d outside 1..%d quads", size, SNAIL_PACKET_QUADS); return 1; }
 	if(!origin || !dir || !idir || !distance || (!shadow && !object)) { snail_set_error("null ray array"); return 1; }
@@ -661,8 +663,8 @@ int launchRays(SnailScene *s, bool shadow, int nPackets, int size, int sharedOri
 	if(R.used) HIP_TRY(hipStreamWaitEvent(stream, R.done, 0));
 	A.defer = R.p;
 	const int exactBlocks = A.fastOK ? (blocks < 8 ? blocks : 8) : (blocks < 2048 ? blocks : 2048);
-	const ExactPass EP = exactPassFor(exactBlocks, A.slotCost, A.nSlots, shadow ? nullptr : dNextOrder);
-	A.nextOrder = EP.nextOrder;
+	const ExactPass EP = exactPassFor(exactBlocks, A.slotCost, A.nSlots, shadow ? nullptr : dNextOrder, orderFlags);
+	A.nextOrder = EP.nextOrder; A.nextOrderFlags = EP.orderFlags;
 	if(shadow) {
 		if(useDeep(s)) {
 			hipLaunchKernelGGL(dev::k_shadow<true>, dim3(blocks), dim3(64), 0, stream, A);
@@ -676,14 +678,14 @@ int launchRays(SnailScene *s, bool shadow, int nPackets, int size, int sharedOri
 	else if(mask) launchRaysKernels<false, true>(s, A, blocks, EP, stream);
 	else launchRaysKernels<false, false>(s, A, blocks, EP, stream);
 	HIP_TRY(hipGetLastError());
-	if(EP.sortAfter) { if(int rc = snail_order_from_cost_dev(A.slotCost, A.nSlots, dNextOrder, stream)) return rc; }
+	if(EP.sortAfter) { if(int rc = snail_order_from_cost_hint_dev(A.slotCost, A.nSlots, dNextOrder, EP.orderFlags, stream)) return rc; }
 	HIP_TRY(hipEventRecord(R.done, stream));
 	R.used = true;
 	return 0;
 }
 
 template <int SRC>
-int launchLights(SnailScene *s, dev::ShadeArgs A /* a copy: relLight is filled in here */, hipStream_t stream, int32_t *dNextOrder = nullptr) {
+int launchLights(SnailScene *s, dev::ShadeArgs A /* a copy: relLight is filled in here */, hipStream_t stream, int32_t *dNextOrder = nullptr, int orderFlags = 0) {
 	if(A.nLights <= 0) return 0;
 	int relWhich[SNAIL_MAX_LIGHTS];
 	for(int n = 0; n < SNAIL_MAX_LIGHTS; n++) { relWhich[n] = -1; A.relLight[n] = nullptr; }
@@ -694,8 +696,8 @@ int launchLights(SnailScene *s, dev::ShadeArgs A /* a copy: relLight is filled i
 	const int total = A.nBlocks * A.nLights;
 	const int exactBlocks = A.fastOK ? (total < 8 ? total : 8) : (total < 2048 ? total : 2048);
 	const bool sse = s->arith == SNAIL_ARITH_HOST_SSE;
-	const ExactPass EP = exactPassFor(exactBlocks, A.slotCost, A.nSlots, dNextOrder);
-	A.nextOrder = EP.nextOrder;
+	const ExactPass EP = exactPassFor(exactBlocks, A.slotCost, A.nSlots, dNextOrder, orderFlags);
+	A.nextOrder = EP.nextOrder; A.nextOrderFlags = EP.orderFlags;
 	if(useDeep(s)) {
 		SNAIL_LAUNCH(sse, ShadeArgs, grid, dim3(64), 0, stream, A, k_light<true, SRC>);
 		SNAIL_LAUNCH(sse, ShadeArgs, EP.grid, EP.block, EP.lds, stream, A, k_light_exact<true, SRC>);
@@ -704,7 +706,7 @@ int launchLights(SnailScene *s, dev::ShadeArgs A /* a copy: relLight is filled i
 		SNAIL_LAUNCH(sse, ShadeArgs, EP.grid, EP.block, EP.lds, stream, A, k_light_exact<false, SRC>);
 	}
 	HIP_TRY(hipGetLastError());
-	if(EP.sortAfter) { if(int rc = snail_order_from_cost_dev(A.slotCost, A.nSlots, dNextOrder, stream)) return rc; }
+	if(EP.sortAfter) { if(int rc = snail_order_from_cost_hint_dev(A.slotCost, A.nSlots, dNextOrder, EP.orderFlags, stream)) return rc; }
 	for(int n = 0; n < A.nLights; n++)
 		if(relWhich[n] >= 0) { if(int rc = relUsed(s, relWhich[n], stream)) return rc; }
 	return 0;
@@ -999,9 +1001,12 @@ int snail_trace_packets_ordered_dev(SnailScene *s, const float cam[13], int resx
 	return launchPrimary(s, cam, resx, resy, 0, 0, 0, 0, dPacketXY, nPackets, t, u, v, id, dStats, (hipStream_t)stream, nullptr, false, nullptr, dOrder, dSlotCost);
 }
 
-int snail_order_from_cost_dev(const int32_t *dSlotCost, int nSlots, int32_t *dOrder, void *stream) {
+int snail_order_from_cost_dev(const int32_t *dSlotCost, int nSlots, int32_t *dOrder, void *stream) { return snail_order_from_cost_hint_dev(dSlotCost, nSlots, dOrder, SNAIL_ORDER_AUTO, stream); }
+
+int snail_order_from_cost_hint_dev(const int32_t *dSlotCost, int nSlots, int32_t *dOrder, int orderFlags, void *stream) {
 	if(nSlots <= 0) return 0;
 	if(!dSlotCost || !dOrder) { snail_set_error("snail_order_from_cost_dev: null buffer"); return 1; }
+	if(orderFlags & ~SNAIL_ORDER_SORTED) { snail_set_error("snail_order_from_cost_hint_dev: unknown order flags 0x%x", orderFlags); return 1; }
 	const hipStream_t st = (hipStream_t)stream;
 	const size_t stashBytes = (size_t)((nSlots + 3) / 4 * 4) * 2;
 	bool ldsForm = nSlots <= ORDER_LDS_MAX_SLOTS && ((uintptr_t)dSlotCost & 15) == 0;   // (a caller's array that is not 16-byte aligned, or a frame beyond ~6K x 4K: the multi-pass kernel)
@@ -1016,7 +1021,7 @@ int snail_order_from_cost_dev(const int32_t *dSlotCost, int nSlots, int32_t *dOr
 		ldsForm = r == 1;
 	}
 	if(ldsForm)
-		hipLaunchKernelGGL(dev::k_order_from_cost_lds, dim3(1), dim3(ORDER_THREADS_LDS), stashBytes, st, dSlotCost, nSlots, dOrder);
+		hipLaunchKernelGGL(dev::k_order_from_cost_lds, dim3(1), dim3(ORDER_THREADS_LDS), stashBytes, st, dSlotCost, nSlots, dOrder, orderFlags);
 	else hipLaunchKernelGGL(dev::k_order_from_cost, dim3(1), dim3(ORDER_THREADS), 0, st, dSlotCost, nSlots, dOrder);
 	HIP_TRY(hipGetLastError());
 	return 0;
@@ -1053,8 +1058,9 @@ int snail_trace_primary_batch_dev(SnailScene *s, int nFrames, const float *cams1
 }
 
 int snail_trace_primary_batch_reorder_dev(SnailScene *s, int nFrames, const float *cams13, int resx, int resy, float *const *t, float *const *u, float *const *v,
-										  int32_t *const *id, uint64_t *dStats, const int32_t *dOrder, int32_t *dSlotCost, int32_t *dNextOrder, void *stream) {
+										  int32_t *const *id, uint64_t *dStats, const int32_t *dOrder, int32_t *dSlotCost, int32_t *dNextOrder, int orderFlags, void *stream) {
 	if(int rc = checkScene(s, "snail_trace_primary_batch_reorder_dev")) return rc;
+	if(orderFlags & ~SNAIL_ORDER_SORTED) { snail_set_error("snail_trace_primary_batch_reorder_dev: unknown order flags 0x%x", orderFlags); return 1; }
 	FrameSet FS;
 	if(int rc = frameSetFrom("snail_trace_primary_batch_reorder_dev", FS, nFrames, cams13)) return rc;
 	for(int k = 0; k < nFrames; k++) {
@@ -1062,7 +1068,7 @@ int snail_trace_primary_batch_reorder_dev(SnailScene *s, int nFrames, const floa
 	}
 	DeviceGuard guard(s->device);
 	SNAIL_LOCK(s);
-	return launchPrimaryFrames(s, FS, resx, resy, 0, 0, resx, resy, nullptr, 0, dStats, (hipStream_t)stream, nullptr, false, dOrder, dSlotCost, dNextOrder);
+	return launchPrimaryFrames(s, FS, resx, resy, 0, 0, resx, resy, nullptr, 0, dStats, (hipStream_t)stream, nullptr, false, dOrder, dSlotCost, dNextOrder, orderFlags);
 }
 
 int snail_trace_packets_shaded_batch_dev(SnailScene *s, int nFrames, const float *cams13, int resx, int resy, const int32_t *dPacketXY, int nPackets,
@@ -1207,7 +1213,7 @@ int snail_trace_shadow(SnailScene *s, int nPackets, int size, const float *origi
 
 static int renderWhitted(const char *fn, SnailScene *s, const float cam[13], int resx, int resy, const int32_t *dPacketXY, int nPacketsList, const float *lights7,
 						 int nLights, const float ambient[3], const float color[3], int flags, uint8_t *frame, int pitch, uint8_t *bgrPackets, uint64_t *dStats,
-						 void *stream, float *colPackets = nullptr, const int32_t *dOrder = nullptr, int32_t *dSlotCost = nullptr, int32_t *dNextOrder = nullptr) {
+						 void *stream, float *colPackets = nullptr, const int32_t *dOrder = nullptr, int32_t *dSlotCost = nullptr, int32_t *dNextOrder = nullptr, int orderFlags = 0) {
 	if(int rc = checkScene(s, fn)) return rc;
 	if(dNextOrder && !dSlotCost) { snail_set_error("%s: the next dispatch orders are derived from d_slot_cost, which is null", fn); return 1; }
 	if(resx <= 0 || resy <= 0 || nLights < 0 || nLights > SNAIL_MAX_LIGHTS || (nLights && !lights7) || !ambient || !color || (flags & ~SNAIL_WHITTED_REFLECTIONS) ||
@@ -1267,18 +1273,18 @@ static int renderWhitted(const char *fn, SnailScene *s, const float cam[13], int
 	// the primary packets (the bench kernel), hit records packet-major
 	if(dPacketXY) {
 		if(int rc = launchPrimary(s, cam, resx, resy, 0, 0, 0, 0, dPacketXY, packets, W.hitT, nullptr, nullptr, W.hitId, dStats, st)) return rc;
-	} else if(int rc = launchPrimary(s, cam, resx, resy, 0, 0, resx, resy, nullptr, 0, W.hitT, nullptr, nullptr, W.hitId, dStats, st, nullptr, true, nullptr, ord[0], cst[0], nxt[0])) return rc;
+	} else if(int rc = launchPrimary(s, cam, resx, resy, 0, 0, resx, resy, nullptr, 0, W.hitT, nullptr, nullptr, W.hitId, dStats, st, nullptr, true, nullptr, ord[0], cst[0], nxt[0], orderFlags)) return rc;
 	if(refl) { // the nested RayTrace of the mirrored packets
 		SNAIL_LAUNCH(sse, ShadeArgs, grid, wave, 0, st, A, k_final<dev::SRC_PRIMARY, dev::DST_MIRROR>);
 		HIP_TRY(hipGetLastError());
-		if(int rc = launchRays(s, false, packets, 64, 0, W.rOrg, W.rDir, W.rIDir, W.rMask, W.rDist, W.rObj, nullptr, dStats, st, ord[2], cst[2], dPacketXY ? 0 : blocks, nxt[2])) return rc;
+		if(int rc = launchRays(s, false, packets, 64, 0, W.rOrg, W.rDir, W.rIDir, W.rMask, W.rDist, W.rObj, nullptr, dStats, st, ord[2], cst[2], dPacketXY ? 0 : blocks, nxt[2], orderFlags)) return rc;
 		A.order = ord[3]; A.slotCost = cst[3]; A.nSlots = blocks;
-		if(int rc = launchLights<dev::SRC_MIRROR>(s, A, st, nxt[3])) return rc;
+		if(int rc = launchLights<dev::SRC_MIRROR>(s, A, st, nxt[3], orderFlags)) return rc;
 		if(!A.fuse) SNAIL_LAUNCH(sse, ShadeArgs, grid, wave, 0, st, A, k_final<dev::SRC_MIRROR, dev::DST_COLOR>);
 		HIP_TRY(hipGetLastError());
 	}
 	A.order = ord[1]; A.slotCost = cst[1]; A.nSlots = blocks;
-	if(int rc = launchLights<dev::SRC_PRIMARY>(s, A, st, nxt[1])) return rc;
+	if(int rc = launchLights<dev::SRC_PRIMARY>(s, A, st, nxt[1], orderFlags)) return rc;
 	if(!A.fuse) SNAIL_LAUNCH(sse, ShadeArgs, grid, wave, 0, st, A, k_final<dev::SRC_PRIMARY, dev::DST_FRAME>);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(W.done, st));
@@ -1303,11 +1309,12 @@ int snail_render_whitted_ordered_dev(SnailScene *s, const float cam[13], int res
 
 int snail_render_whitted_reorder_dev(SnailScene *s, const float cam[13], int resx, int resy, const float *lights7, int nLights, const float ambient[3],
 									 const float color[3], int flags, uint8_t *frame, int pitch, uint64_t *dStats, const int32_t *dOrder, int32_t *dSlotCost, int32_t *dNextOrder,
-									 void *stream) {
+									 int orderFlags, void *stream) {
 	if(int rc = checkScene(s, "snail_render_whitted_reorder_dev")) return rc;
+	if(orderFlags & ~SNAIL_ORDER_SORTED) { snail_set_error("snail_render_whitted_reorder_dev: unknown order flags 0x%x", orderFlags); return 1; }
 	SNAIL_LOCK(s);
 	return renderWhitted("snail_render_whitted_reorder_dev", s, cam, resx, resy, nullptr, 0, lights7, nLights, ambient, color, flags, frame, pitch, nullptr, dStats, stream,
-						 nullptr, dOrder, dSlotCost, dNextOrder);
+						 nullptr, dOrder, dSlotCost, dNextOrder, orderFlags);
 }
 
 int snail_render_whitted_packets_dev(SnailScene *s, const float cam[13], int resx, int resy, const int32_t *dPacketXY, int nPackets, const float *lights7,

@@ -250,6 +250,7 @@ class DistributedRenderer:
             self.order_valid = [False] * self.nslots
             self.order_cam = [None] * self.nslots       # camera the slot's order was derived from
             self.order_age = [0] * self.nslots          # frames of the slot since then
+            self.order_exact = [False] * self.nslots    # the slot's order was derived (sorted) from the costs of the camera it is used for
             if n == 0:
                 self.feedback = False
         if self.multi:
@@ -310,12 +311,23 @@ class DistributedRenderer:
         return [self._outputs[k] for k in sorted(self._outputs)]
 
     def _order_for(self, slot, cam):
-        """the dispatch order this frame uses (or None), and whether to re-derive the slot's order from this frame's costs"""
+        """the dispatch order this frame uses (or None), and whether to re-derive the slot's order from this frame's costs (key or None).  self.order_exact[slot]
+        then says what kind the derivation is to be: a camera that has NOT moved since the slot's order was derived gets -- once -- the order of its own exact
+        costs, sorted whatever their shape (SNAIL_ORDER_SORTED: the last frames of a run end on their heaviest packets, which then started first); a moving
+        camera's orders are predictions and take the library's rule (sorted only for heavy-tailed costs)."""
         key = cam.as_array13().tobytes()
         if not self.order_valid[slot]:
+            self.order_exact[slot] = False
             return None, key
         self.order_age[slot] += 1
-        refresh = self.order_cam[slot] != key and self.order_age[slot] >= self.order_refresh
+        if self.order_cam[slot] == key:
+            if self.order_exact[slot]:
+                return self.order_buf[slot], None
+            self.order_exact[slot] = True
+            return self.order_buf[slot], key
+        refresh = self.order_age[slot] >= self.order_refresh
+        if refresh:
+            self.order_exact[slot] = False
         return self.order_buf[slot], (key if refresh else None)
 
     def _order_refreshed(self, slot, key):
@@ -327,9 +339,9 @@ class DistributedRenderer:
         """the stand-alone sort (snail_order_from_cost_dev), for the routes without a *_reorder_dev form: explicit packet lists"""
         if self.whitted_single:
             for k in range(self.scene.WHITTED_STAGES if self.reflections else 2):     # stages 2, 3 exist with the mirrored bounce only
-                self.scene.order_from_cost(self.slot_cost[slot][k], self.order_buf[slot][k], stream=st)
+                self.scene.order_from_cost(self.slot_cost[slot][k], self.order_buf[slot][k], stream=st, exact=self.order_exact[slot])
         else:
-            self.scene.order_from_cost(self.slot_cost[slot], self.order_buf[slot], stream=st)
+            self.scene.order_from_cost(self.slot_cost[slot], self.order_buf[slot], stream=st, exact=self.order_exact[slot])
         self.order_valid[slot], self.order_cam[slot], self.order_age[slot] = True, key, 0
 
     def render(self, cam, stats=None, events=None):
@@ -353,7 +365,7 @@ class DistributedRenderer:
                 order, key = self._order_for(slot, cam) if self.feedback else (None, None)
                 self.frame_rgb8 = sc.render_whitted(cam, p.resx, p.resy, self.lights7, self.ambient, self.color, out=self.frames_rgb8[slot], stats=stats, stream=st,
                                                     reflections=self.reflections, order=order, slot_cost=self.slot_cost[slot] if self.feedback else None,
-                                                    next_order=self.order_buf[slot] if key is not None else None)   # (a refresh: derived inside this launch, in place)
+                                                    next_order=self.order_buf[slot] if key is not None else None, order_exact=self.feedback and self.order_exact[slot])   # (a refresh: derived inside this launch, in place)
                 self._outputs[(slot, 0)] = self.frame_rgb8
                 if events: events[1].record(st)
                 if key is not None: self._order_refreshed(slot, key)
@@ -362,7 +374,7 @@ class DistributedRenderer:
                 order, key = self._order_for(slot, cam)
                 if key is not None:      # a refresh: the one-frame form of the multi-frame launch derives the next order inside the launch, in place
                     out = sc.trace_primary_batch([cam], p.resx, p.resy, [self.frames[slot]], stats=stats, stream=st, order=order, slot_cost=self.slot_cost[slot],
-                                                 next_order=self.order_buf[slot])[0]
+                                                 next_order=self.order_buf[slot], order_exact=self.order_exact[slot])[0]
                     self._order_refreshed(slot, key)
                 else:
                     out = sc.trace_primary(cam, p.resx, p.resy, out=self.frames[slot], stats=stats, stream=st, order=order, slot_cost=self.slot_cost[slot])
@@ -480,7 +492,7 @@ class DistributedRenderer:
         if self.feedback:
             order, key = self._order_for(slot, cams[0])
             sc.trace_primary_batch(cams, p.resx, p.resy, outs, stats=stats, stream=st, order=order, slot_cost=self.slot_cost[slot],
-                                   next_order=self.order_buf[slot] if key is not None else None)      # (a refresh: derived inside this launch, in place)
+                                   next_order=self.order_buf[slot] if key is not None else None, order_exact=self.order_exact[slot])      # (a refresh: derived inside this launch, in place)
             if events: events[1].record(st)
             if key is not None: self._order_refreshed(slot, key)
         else:

@@ -205,18 +205,19 @@ class Scene:
         _lib.check(rc, "snail_trace_primary_dev")
         return out
 
-    def trace_primary_batch(self, cams, resx: int, resy: int, outs, stats=None, stream=None, order=None, slot_cost=None, next_order=None):
+    def trace_primary_batch(self, cams, resx: int, resy: int, outs, stats=None, stream=None, order=None, slot_cost=None, next_order=None, order_exact=False):
         """ONE launch for len(cams) frames (<= 8) of the whole image, each with its own camera and HitFrame (snail_trace_primary_batch_dev):
         the heaviest packets of all the frames first, one tail and one set of launch overheads for all of them.  next_order (int32 device tensor of
         primary_slots entries; may be `order` itself; needs slot_cost): the order the NEXT launch should use, derived from this launch's costs inside the
-        launch (snail_trace_primary_batch_reorder_dev: no kernel launch of its own)."""
+        launch (snail_trace_primary_batch_reorder_dev: no kernel launch of its own); order_exact = the caller knows the costs to be exact for the launches
+        that will use the order (a still camera): SNAIL_ORDER_SORTED."""
         n = len(cams)
         cam13 = np.ascontiguousarray(np.stack([c.as_array13() for c in cams]), dtype=np.float32)
         arr = lambda xs: (C.c_void_p * n)(*[x.data_ptr() for x in xs])
         if next_order is not None:
             rc = _lib.lib().snail_trace_primary_batch_reorder_dev(self._h, n, _lib.ptr(cam13), resx, resy, arr([o.t for o in outs]), arr([o.u for o in outs]),
                                                                   arr([o.v for o in outs]), arr([o.tri_id for o in outs]), _lib.ptr(stats), _lib.ptr(order),
-                                                                  _lib.ptr(slot_cost), _lib.ptr(next_order), _stream_ptr(stream))
+                                                                  _lib.ptr(slot_cost), _lib.ptr(next_order), self.ORDER_SORTED if order_exact else self.ORDER_AUTO, _stream_ptr(stream))
             _lib.check(rc, "snail_trace_primary_batch_reorder_dev")
             return outs
         rc = _lib.lib().snail_trace_primary_batch_dev(self._h, n, _lib.ptr(cam13), resx, resy, arr([o.t for o in outs]), arr([o.u for o in outs]),
@@ -242,12 +243,13 @@ class Scene:
         return int(_lib.lib().snail_primary_slots(w, h))
 
     @staticmethod
-    def order_from_cost(slot_cost, order=None, stream=None):
-        """Heaviest-first dispatch order (a permutation, int32) from the per-slot costs of a previous launch; stream-ordered."""
+    def order_from_cost(slot_cost, order=None, stream=None, exact=False):
+        """Dispatch order (a permutation, int32) from the per-slot costs of a previous launch; stream-ordered.  Heaviest first when the costs are heavy-tailed
+        or the caller knows them to be exact (exact=True: SNAIL_ORDER_SORTED), the built-in order otherwise (include/snail_hip.h)."""
         torch = _torch()
         order = order if order is not None else torch.empty_like(slot_cost)
         with torch.cuda.device(slot_cost.device):
-            rc = _lib.lib().snail_order_from_cost_dev(_lib.ptr(slot_cost), int(slot_cost.numel()), _lib.ptr(order), _stream_ptr(stream))
+            rc = _lib.lib().snail_order_from_cost_hint_dev(_lib.ptr(slot_cost), int(slot_cost.numel()), _lib.ptr(order), Scene.ORDER_SORTED if exact else Scene.ORDER_AUTO, _stream_ptr(stream))
         _lib.check(rc, "snail_order_from_cost_dev")
         return order
 
@@ -359,9 +361,10 @@ class Scene:
         return frame_rgb8
 
     WHITTED_STAGES = 4
+    ORDER_AUTO, ORDER_SORTED = 0, 1      # SNAIL_ORDER_* (include/snail_hip.h)
 
     def render_whitted(self, cam: Camera, resx: int, resy: int, lights7, ambient=(0.1, 0.1, 0.1), color=(1.0, 1.0, 1.0), out=None, stats=None,
-                       stream=None, reflections: bool = False, order=None, slot_cost=None, next_order=None):
+                       stream=None, reflections: bool = False, order=None, slot_cost=None, next_order=None, order_exact=False):
         """Scene::RayTrace in the reference's simple-shading configuration (primary + one shadow packet per point light;
         reflections=True = gVals[7], one mirrored bounce shaded the same way), staged on the device; returns the interleaved
         [resy,resx,3] uint8 (B,G,R) frame.  lights7 = n x {pos, color, radius} (class Light, src/light.h:5-16); defaults =
@@ -383,7 +386,7 @@ class Scene:
                     raise ValueError(f"next_order must be a contiguous int32 tensor of shape ({self.WHITTED_STAGES}, {n})")
                 rc = _lib.lib().snail_render_whitted_reorder_dev(self._h, _lib.ptr(cam13), resx, resy, _lib.ptr(lights), len(lights), _lib.ptr(amb), _lib.ptr(col),
                                                                  1 if reflections else 0, _lib.ptr(out), resx * 3, _lib.ptr(stats), _lib.ptr(order), _lib.ptr(slot_cost),
-                                                                 _lib.ptr(next_order), _stream_ptr(stream))
+                                                                 _lib.ptr(next_order), self.ORDER_SORTED if order_exact else self.ORDER_AUTO, _stream_ptr(stream))
                 _lib.check(rc, "snail_render_whitted_reorder_dev")
                 return out
             rc = _lib.lib().snail_render_whitted_ordered_dev(self._h, _lib.ptr(cam13), resx, resy, _lib.ptr(lights), len(lights), _lib.ptr(amb), _lib.ptr(col),

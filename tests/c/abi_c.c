@@ -13,7 +13,7 @@ int main(void) {
 	ADDR(snail_scene_create_lbvh) ADDR(snail_scene_download) ADDR(snail_scene_info) ADDR(snail_scene_flags) ADDR(snail_scene_set_arith) ADDR(snail_scene_arith)
 	ADDR(snail_host_sse_tables) ADDR(snail_arith_set_tables) ADDR(snail_arith_prepare_device) ADDR(snail_host_sse_check) ADDR(snail_trace_primary)
 	ADDR(snail_trace_primary_dev) ADDR(snail_trace_frame_packets) ADDR(snail_trace_packets_dev) ADDR(snail_trace_packets_shaded_dev) ADDR(snail_primary_slots)
-	ADDR(snail_trace_primary_ordered_dev) ADDR(snail_trace_packets_ordered_dev) ADDR(snail_order_from_cost_dev) ADDR(snail_trace_primary_batch_dev)
+	ADDR(snail_trace_primary_ordered_dev) ADDR(snail_trace_packets_ordered_dev) ADDR(snail_order_from_cost_dev) ADDR(snail_order_from_cost_hint_dev) ADDR(snail_trace_primary_batch_dev)
 	ADDR(snail_trace_primary_batch_reorder_dev) ADDR(snail_trace_packets_shaded_batch_dev) ADDR(snail_packets_to_frame_dev) ADDR(snail_trace_rays) ADDR(snail_trace_rays_dev)
 	ADDR(snail_trace_shadow) ADDR(snail_trace_shadow_dev) ADDR(snail_shade_depth_dev) ADDR(snail_shade_depth_arith_dev) ADDR(snail_packets_bgr_to_frame_dev)
 	ADDR(snail_packets_bgr_to_frame_chunked_dev) ADDR(snail_packets_bgr_to_planar_dev) ADDR(snail_planar_to_frame_dev) ADDR(snail_render_whitted_dev)

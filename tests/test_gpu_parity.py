@@ -1387,6 +1387,11 @@ def test_dispatch_order_feedback_changes_nothing_but_the_order(torch_mod, name, 
         compare_frames(f, ref, "reorder launch, in place, two frames")
     assert np.array_equal(st4.cpu().numpy().astype(np.uint64), 2 * ref[4])
     assert np.array_equal(np.sort(o4), np.arange(n)) and classes_descend(o4) and np.array_equal(cost3.cpu().numpy(), c)
+    # ... and with the costs declared exact (SNAIL_ORDER_SORTED: the same camera will use the order): sorted whatever their shape
+    sc.trace_primary_batch([cam], resx, resy, outs, slot_cost=cost3, next_order=nxt, order_exact=True)
+    torch_mod.cuda.synchronize()
+    compare_frames(outs[0], ref, "reorder launch, exact costs")
+    assert util.check_derived_order(c, nxt.cpu().numpy(), exact=True) == "sorted"
     with pytest.raises(Exception, match="d_slot_cost"):
         sc.trace_primary_batch([cam], resx, resy, outs, next_order=nxt)
     # packet-list form
@@ -1439,6 +1444,8 @@ def test_dispatch_order_feedback_changes_nothing_but_the_order(torch_mod, name, 
             kind = util.check_derived_order(cst[off:], od)
             if 100 <= m2 and hi <= 65535:
                 assert kind == ("sorted" if tailed else "built-in"), (m2, hi, tailed, kind)
+            # costs the caller declares exact (SNAIL_ORDER_SORTED): sorted whatever their shape
+            assert util.check_derived_order(cst[off:], sc.order_from_cost(dev_c, exact=True).cpu().numpy(), exact=True) == "sorted"
         else:                                                     # the multi-pass kernel: 32-bit costs, always sorted
             assert np.array_equal(np.sort(od), np.arange(m2)), (m2, off)
             c2 = cst[off:]
@@ -1462,6 +1469,19 @@ def test_dispatch_order_feedback_changes_nothing_but_the_order(torch_mod, name, 
             outs = []
     rnd.flush()
     assert all(rnd.order_valid)
+    # a camera that stands still: each slot re-derives its order ONCE from that camera's own (exact) costs, sorted whatever their shape; then no more refreshes
+    for _ in range(4 * rnd.nslots):
+        rnd.render(cam)
+    rnd.flush()
+    torch_mod.cuda.synchronize()
+    assert all(rnd.order_exact) and all(a > 0 for a in rnd.order_age)
+    for k in range(rnd.nslots):
+        assert util.check_derived_order(rnd.slot_cost[k].cpu().numpy(), rnd.order_buf[k].cpu().numpy(), exact=True) == "sorted"
+        assert np.array_equal(rnd.slot_cost[k].cpu().numpy(), c), "the slot's costs are this camera's"
+    for _ in range(rnd.nslots):                  # the camera moves again: the orders are predictions, the library's rule
+        compare_frames(rnd.render(cams[-1]), osc.render_primary(cams[-1].as_array13(), resx, resy, mode=O.MODE_IEEE), "renderer feedback, moved again")
+    rnd.flush()
+    assert not any(rnd.order_exact)
     sc.close()
 
 
@@ -1660,6 +1680,11 @@ def test_staged_pipeline_dispatch_orders_change_nothing_but_the_order(torch_mod,
     for k in stages:
         assert np.array_equal(c3[k].cpu().numpy(), cst[k]), k
         assert util.check_derived_order(cst[k], ob[k]) == util.check_derived_order(cst[k], fed[k].cpu().numpy()), k      # (the stand-alone sort decides the same)
+    g = sc.render_whitted(cam, resx, resy, lights, reflections=refl, order=buf, slot_cost=c3, next_order=buf, order_exact=True).cpu().numpy()   # costs declared exact
+    assert np.array_equal(g, want)
+    ob = buf.cpu().numpy()
+    for k in stages:
+        assert util.check_derived_order(cst[k], ob[k], exact=True) == "sorted", k
     # the renderer with the feedback on (bench.py --config 3): frames of a moving camera equal the oracle's
     from snail_amd import render as R
     r = R.DistributedRenderer(sc, resx, resy, lights7=lights, reflections=refl, feedback_order=True, order_refresh=2)

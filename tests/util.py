@@ -222,10 +222,10 @@ def interleave16(b):
     return (((j >> 4) << 3) + xcd) * 16 + (j & 15)
 
 
-def check_derived_order(cost, order, adaptive=3):
+def check_derived_order(cost, order, adaptive=3, exact=False):
     """A dispatch order the library derived from per-slot costs (snail_order_from_cost_dev, the *_reorder_dev launches; up to 49152 slots): a permutation, and
     -- by the rule of dev::orderSortBlock -- the SORTED one (cost classes of max >> shift <= 4095, descending) when the costs are heavy-tailed (the class of the
-    slot at the 99th percentile, times the slot count, at least `adaptive` times the sum of the costs), the kernels' BUILT-IN order otherwise.  Returns which."""
+    slot at the 99th percentile, times the slot count, at least `adaptive` times the sum of the costs) or the caller declared them exact (SNAIL_ORDER_SORTED), the kernels' BUILT-IN order otherwise.  Returns which."""
     c = np.minimum(np.maximum(np.asarray(cost, dtype=np.int64), 0), 65535)
     o = np.asarray(order, dtype=np.int64)
     n = len(c)
@@ -242,8 +242,8 @@ def check_derived_order(cost, order, adaptive=3):
         if start[k] < want <= start[k] + counts[k]:
             p99 = int(k)
     heavy_tailed = ((4095 - p99) << shift) * n >= adaptive * int(c.sum())
-    if heavy_tailed:
-        assert (np.diff(cls[o]) >= 0).all(), "heavy-tailed costs: cost classes must descend"
+    if heavy_tailed or exact:
+        assert (np.diff(cls[o]) >= 0).all(), "heavy-tailed or exact costs: cost classes must descend"
         return "sorted"
     n128 = (n + 127) // 128 * 128
     nat = interleave16(np.arange(n128))
