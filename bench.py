@@ -433,8 +433,9 @@ def main():
         lights7 = np.array([[c[0], c[1] + 0.35 * e[1], c[2], 1.0, 0.9, 0.8, 2.0 * float(e.max())]], dtype=np.float32)   # one point light above the nave
     # frames per launch, unless given: enough for a launch to hold at least one 1080p frame's worth of packets (8160), at most 8; at least 4 on one GPU (round 5,
     # profiles/r5_shapes.txt: 4 streams x 4 frames against 4 x 2 -- the driver's 20-step run +3..6 %, the long run +1.4 %, 4K +0.5 %, stress-1M -0.7 %), 2 on several
+    # and for the dolly camera (every frame walks its own origin-relative node array: 16 of them in flight instead of 8 cost 3.5 %, profiles/r5_dolly.txt)
     per_rank = ((resx + 15) // 16) * ((resy + 15) // 16) / float(world)
-    auto_fpl = int(min(8, max(4 if world == 1 else 2, math.ceil(8160.0 / max(1.0, per_rank)))))
+    auto_fpl = int(min(8, max(4 if (world == 1 and args.camera_path != "dolly") else 2, math.ceil(8160.0 / max(1.0, per_rank)))))
     rnd = DistributedRenderer(scene, resx, resy, rank, world, slots=args.streams if args.streams > 0 else None, stage_cpu=rehearsal,
                               feedback_order=bool(args.feedback_order), lights7=lights7, reflections=bool(args.reflections and cfg["lights"]), rank0_share=args.rank0_share,
                               frames_per_launch=args.frames_per_launch if args.frames_per_launch > 0 else auto_fpl, order_refresh=args.order_refresh)

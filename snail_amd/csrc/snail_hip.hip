@@ -125,7 +125,8 @@ struct SnailScene {
 		hipEvent_t used[kStreams] = {};
 		int nUsed = 0;
 	};
-	enum { kRelSlots = 16 };
+	enum { kRelSlots = 40 };   // (allocated on first use.  More than the frames a renderer keeps in flight -- 4 launches x 8 frames -- so that a camera whose POSITION
+	                           // moves every frame never recycles an array a running launch still reads; 16 until round 5)
 	RelNodes rel[kRelSlots];
 	unsigned long long relClock = 0;
 	int pfOK = 0;     // the prefetching loop may walk this tree: nested, every child pair starts at an odd index, offsets fit (stackPack)

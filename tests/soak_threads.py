@@ -25,7 +25,7 @@ for name, mode, arith in (("atrium:0.05", O.MODE_IEEE, "ieee"), ("offgrid-in", O
     base = util.camera_for(name, tv)
     bmin, bmax = osc.nodes[0]["bmin"], osc.nodes[0]["bmax"]
     c, e = (bmin + bmax) * 0.5, (bmax - bmin)
-    for k in range(6):      # moving cameras and lights: more origins than the origin-relative node cache holds
+    for k in range(22):     # moving cameras and lights: more origins (44 per scene) than the origin-relative node cache holds (40)
         cam = FPSCamera(np.asarray(base.pos, dtype=np.float32) + np.float32(0.013 * k) * np.asarray(base.front, dtype=np.float32), *( (scenes.atrium_camera()[1:]) if name.startswith("atrium") else (0.0, 0.0))).camera()
         lights = np.array([[c[0] + 0.02 * k * e[0], c[1] + 0.35 * e[1], c[2], 1.0, 0.9, 0.8, 2.0 * float(e.max())]], dtype=np.float32)
         ref = osc.render_primary(cam.as_array13(), resx, resy, mode=mode)

@@ -123,7 +123,7 @@ def test_host_pointer_entry_points_from_eight_threads(torch_mod, host_sse):
 
 def test_dev_entry_points_from_threads_on_their_own_streams(torch_mod):
     """Four host threads, each with its own HIP stream and its own moving camera and light, issue *_dev launches on ONE scene with no
-    synchronisation between them: more distinct origins than the origin-relative node cache holds (16), the 8 scratch slots recycled across
+    synchronisation between them: more distinct origins than the origin-relative node cache holds (40), the 8 scratch slots recycled across
     threads, staged light frames beside plain primary frames.  Every frame equals what the same call gives alone afterwards -- and the first
     frame of each thread the oracle's."""
     torch = torch_mod
