@@ -1,7 +1,9 @@
 """Long seeded fuzz run (not collected by pytest; uses the oracle, hence lives under tests/): random cameras, frame sizes, lights,
 scenes and tree builders, GPU hit records / staged config-3 frames / counters against the oracle, bit for bit.
 Usage: python tests/soak_fuzz.py [cases] [seed] [focus]   (focus = "refl": the stress scene with the mirrored bounce only, differences printed;
-focus = "sse": every case in SNAIL_ARITH_HOST_SSE against the oracle's ORC_MODE_SSE -- this CPU's rcpps / rsqrtps on both sides)"""
+focus = "sse": every case in SNAIL_ARITH_HOST_SSE against the oracle's ORC_MODE_SSE -- this CPU's rcpps / rsqrtps on both sides;
+focus = "ref" / "refsse": the REFERENCE'S OWN MESHES -- lancia, feline, barracks from tests/golden/<name>_tris.npz, scanned / modelled geometry with
+full-mantissa coordinates -- under random cameras and lights, in the IEEE / the host's SSE arithmetic)"""
 import math, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -15,11 +17,20 @@ focus = sys.argv[3] if len(sys.argv) > 3 else ""
 rng = np.random.RandomState(seed)
 names = ["atrium:0.05", "stress:0.05", "box", "chain", "atrium:0.02", "offgrid"]   # offgrid: full-mantissa vertices, slivers, four decades of sizes, far from the origin
 scn = {}
-for n in names:
-    tv, hb, osc = util.scene_pair(n)
-    scn[n] = (tv, Scene(hb, 0), osc)
-    if focus == "sse": scn[n][1].set_arith("host_sse")
-MODE = O.MODE_SSE if focus == "sse" else O.MODE_IEEE
+SSE = focus in ("sse", "refsse")
+if focus in ("ref", "refsse"):
+    from snail_amd import HostBVH
+    names = ["lancia", "feline", "barracks"]
+    for n in names:
+        tv = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", n + "_tris.npz"))["tris"]
+        scn[n] = (tv, Scene(HostBVH.build(tv), 0), O.OracleScene(tv))
+else:
+    for n in names:
+        tv, hb, osc = util.scene_pair(n)
+        scn[n] = (tv, Scene(hb, 0), osc)
+if SSE:
+    for n in names: scn[n][1].set_arith("host_sse")
+MODE = O.MODE_SSE if SSE else O.MODE_IEEE
 L_ = O.lib(); L_.orc_caller_mxcsr.restype = __import__("ctypes").c_uint
 print("caller MXCSR 0x%04x (0x1f80 = default); float32 denormals in numpy: %s" % (L_.orc_caller_mxcsr(), "kept" if float(np.float32(1e-40) * np.float32(0.5)) != 0.0 else "FLUSHED"), flush=True)
 bad = 0; t0 = time.time()
@@ -49,7 +60,7 @@ for case in range(cases):
     ok2 = np.array_equal(img.cpu().numpy(), wimg) and np.array_equal(st.cpu().numpy().astype(np.uint64), wst)
     if not (ok and ok2):
         bad += 1
-        if focus:
+        if focus in ("refl", "sse"):
             g = img.cpu().numpy(); w = np.flatnonzero((g != wimg).any(axis=-1).ravel()) if g.shape == wimg.shape else []
             print("  pixels differing: %d of %d, first %s; stats gpu %s oracle %s" % (len(w), g.shape[0] * g.shape[1], w[:6], st.cpu().numpy().astype(np.uint64), wst), flush=True)
             # a second run of the same frame: does the device agree with itself?
