@@ -1418,7 +1418,8 @@ def test_dispatch_order_feedback_changes_nothing_but_the_order(torch_mod, name, 
     torch_mod.cuda.synchronize()
     # the sort alone: sizes around the block size, constant / negative / huge costs
     for m2, gen in ((1, lambda k: np.zeros(k)), (1023, lambda k: rng.integers(0, 50, k)), (1025, lambda k: rng.integers(-5, 3, k)),
-                    (200_003, lambda k: rng.integers(0, 2**31 - 1, k)), (4096, lambda k: np.full(k, 17))):
+                    (200_003, lambda k: rng.integers(0, 2**31 - 1, k)), (4096, lambda k: np.full(k, 17)),
+                    (49152, lambda k: np.full(k, 70000))):      # (the largest sum the one-read form can meet: 49152 x 65535 > 2^31)
         cst = gen(m2).astype(np.int32)
         od = sc.order_from_cost(torch_mod.from_numpy(cst).cuda()).cpu().numpy()
         # (up to 49152 slots: sorted for heavy-tailed costs, the built-in order otherwise; beyond: the multi-pass kernel, always sorted)
