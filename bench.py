@@ -45,8 +45,8 @@ config.settle_frames / settle_measured_ms): from an
 idle start the part's shader clock ramps for tens of milliseconds (profiles/README.md), and a short timed region would measure that ramp.  W warm-up
 steps, the barrier + synchronize, and EXACTLY K timed steps follow as the contract says.
 
-Launches: frames are pipelined over 4 HIP streams, and `--frames-per-launch B` frames (default: enough for a launch to hold a 1080p frame's worth of packets, i.e. 2 / 2 / 4 / 8 at N = 1 / 2 / 4 / 8;
-always 1 for config 3)
+Launches: frames are pipelined over 4 HIP streams, and `--frames-per-launch B` frames (default: enough for a launch to hold a 1080p frame's worth of packets, at least 4 on one GPU and 2 on several, i.e. 4 / 2 / 4 / 8 at
+N = 1 / 2 / 4 / 8 -- 2 for the dolly camera; always 1 for config 3)
 share ONE launch -- the heaviest packets of all of them first, one tail and one set of launch overheads (and, at N > 1, one collective)
 for B frames; results are those of B single-frame launches.
 
