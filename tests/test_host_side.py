@@ -217,6 +217,20 @@ def test_scene_create_rejects_runaway_trees():
     h, msg = create(oob, hb.depth); assert not h and "child" in msg, msg
 
 
+def test_order_flags_are_validated_before_anything_is_launched():
+    """snail_order_from_cost_hint_dev (include/snail_hip.h: SNAIL_ORDER_AUTO / SNAIL_ORDER_SORTED) refuses unknown order flags and null buffers on the
+    host, before any device call; an empty input is a no-op."""
+    import ctypes
+    from snail_amd import _lib
+    L = _lib.lib()
+    buf = (ctypes.c_int32 * 8)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert L.snail_order_from_cost_hint_dev(p, 0, p, 0, None) == 0
+    assert L.snail_order_from_cost_hint_dev(p, 8, p, 2, None) == 1 and "order flags" in L.snail_last_error().decode()
+    assert L.snail_order_from_cost_hint_dev(None, 8, p, 1, None) == 1 and "null buffer" in L.snail_last_error().decode()
+    assert L.snail_order_from_cost_dev(p, 8, None, None) == 1
+
+
 def build_adapter_mock(tmp_path):
     import subprocess
     exe = str(tmp_path / "adapter_mock")
