@@ -12,14 +12,16 @@
 #   steps20c    frames per launch that divide the 20 steps evenly                                                                                                      -> profiles/r5_steps20c.txt
 #   shapes      streams x frames per launch (nine shapes, four workloads); streams for config 3                                                                         -> profiles/r5_shapes.txt
 #   dolly       the dolly camera at 2 / 4 / 8 frames per launch                                                                                                        -> profiles/r5_dolly.txt
+#   reltri      reltri (-DSNAIL_REL_TRI_PREFETCH=1): a leaf's triangle line requested ahead in the walks over origin-relative arrays; parity tests of the variant first -> profiles/r5_tri_prefetch.txt
+#   notri       notri (-DSNAIL_TRI_PREFETCH=0): no such request in the walks over the loop's own copy (mirrored packets)                                               -> profiles/r5_tri_prefetch.txt
 set -u
-ROUNDS=2; VARIANTS="product"; PRE=""; CASES=()
+ROUNDS=2; VARIANTS="product"; PRE=""; CASES=(); TAILFLAGS="--lone-frames 0 --no-live-check"; PARITY=""
 run() { # variant, bench arguments...
   local v=$1; shift
   local L="SNAIL_AB=1" F=""
   case $v in product) ;; none) F="--feedback-order 0" ;; *) L="SNAIL_LIB_PATH=$PWD/snail_amd/exp/lib_$v.so" ;; esac
-  env $L timeout -k 10 200 python bench.py $PRE "$@" $F --no-cpu-baseline --lone-frames 0 --no-live-check 2>/dev/null |
-    python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$R $v [$PRE $*]', d['value'], d['ms_per_step'], d['verified'])"
+  env $L timeout -k 10 200 python bench.py $PRE "$@" $F --no-cpu-baseline $TAILFLAGS 2>/dev/null |
+    python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$R $v [$PRE $*]', d['value'], d['ms_per_step'], 'lone', d['roofline'].get('lone_frame_ms'), d['verified'])"
 }
 C3="--config 3 --steps 800"; C3R="--config 3 --reflections --steps 300"; C4="--config 4 --steps 800"; C5="--config 5 --steps 800"
 case "${1:-}" in
@@ -36,8 +38,15 @@ steps20c)  ROUNDS=3; PRE="--steps 20 --warmup 5"
 shapes)    for sh in "4 2" "3 4" "2 8" "3 8" "2 4" "3 3" "3 6" "4 4" "2 6"; do set -- $sh; for c in "--steps 20 --warmup 5" "" "$C5" "$C4"; do CASES+=("$c --streams $1 --frames-per-launch $2"); done; done
            for s in 2 3 4 5 6; do CASES+=("$C3 --streams $s" "$C3R --streams $s"); done ;;
 dolly)     CASES=("--camera-path dolly --frames-per-launch 4" "--camera-path dolly --frames-per-launch 2" "--camera-path dolly --frames-per-launch 8" "--camera-path orbit" "") ;;
-*) echo "usage: bash tools/r5_ab.sh prio|natural|adaptive|threshold|steps20|steps20b|steps20c|shapes|dolly"; exit 2 ;;
+reltri)    ROUNDS=3; VARIANTS="product reltri"; TAILFLAGS="--lone-frames 12"; PARITY='tests/test_gpu_parity.py tests/test_gpu_ref_meshes.py -k "primary or whitted or config3 or reference_mesh or full_size"'
+           CASES=("" "--steps 20 --warmup 5" "$C5" "$C3" "$C4" "$C3R" "--camera-path orbit") ;;
+notri)     ROUNDS=3; VARIANTS="product notri"; TAILFLAGS="--lone-frames 12"; PARITY='tests/test_gpu_parity.py -k "rays or shadow or whitted or refl or transp"'
+           CASES=("$C3R" "$C3R --scene stress") ;;
+*) echo "usage: bash tools/r5_ab.sh prio|natural|adaptive|threshold|steps20|steps20b|steps20c|shapes|dolly|reltri|notri"; exit 2 ;;
 esac
+if [ -n "$PARITY" ]; then   # the GPU parity tests under the (last) variant before anything is timed
+  eval "SNAIL_LIB_PATH=$PWD/snail_amd/exp/lib_${VARIANTS##* }.so timeout -k 10 600 python -m pytest -x -q $PARITY" 2>&1 | tail -2
+fi
 for R in $(seq 1 $ROUNDS); do
   for c in "${CASES[@]}"; do
     for v in $VARIANTS; do run $v $c; done
