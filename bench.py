@@ -70,11 +70,14 @@ import os
 # four frames in flight want four hardware queues of their own: with the runtime's default of 4 queues per process, streams share
 # queues with each other and with the runtime's own work (measured: 20.5 G with 3 streams / 4 queues, 22.1 G with 4 streams / >= 6
 # queues, 5 or more streams slower again; profiles/README.md).  Must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# The frame with the mirrored bounce is nine dependent launches on its stream (primary, deferred, mirrored-ray generation, mirrored packets, deferred, their shadow
+# packets, deferred, the primary hits' shadow packets, deferred): more frames in flight fill the gaps between them -- 8 streams on 16 queues 11.6 G against 10.8 G with
+# 4 on 8, 7 on 8 11.3 G, 8 on 8 9.1 G (round 5, profiles/r5_streams.txt); every other workload is fastest with 4 streams, on 8 or 16 queues alike.
+import sys
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if "--reflections" in sys.argv else "8")
 import argparse
 import json
 import math
-import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -338,7 +341,7 @@ def main():
     ap.add_argument("--no-live-check", action="store_true", help="skip the live oracle check of the timed output (rank 0, after the timed region); `verified` then rests on the committed digests alone")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal only: all ranks share GPU 0 and the per-frame gather is staged through host memory")
-    ap.add_argument("--streams", type=int, default=0, help="frames in flight (HIP streams); 0 = the renderer's default (4); 1 = strictly serial frames")
+    ap.add_argument("--streams", type=int, default=0, help="frames in flight (HIP streams); 0 = the renderer's default (4; 8 -- on 16 hardware queues -- for --reflections on one GPU); 1 = strictly serial frames")
     ap.add_argument("--event-every", type=int, default=8, help="bracket every n-th traversal launch with HIP events (roofline.kernel_ms)")
     ap.add_argument("--feedback-order", type=int, default=1, help="1 (default) = dispatch packets heaviest first by the node visits of an earlier frame (DistributedRenderer feedback_order)")
     ap.add_argument("--frames-per-launch", type=int, default=0, help="trace this many frames (1..8) with one launch -- and, at N > 1, move them with one collective (DistributedRenderer frames_per_launch); 0 = enough for a launch to hold 8160 packets (one 1080p frame), at most 8, at least 4 on one GPU and 2 on several: 4 / 2 / 4 / 8 at N = 1 / 2 / 4 / 8; config 3 always 1")
@@ -436,7 +439,7 @@ def main():
     # and for the dolly camera (every frame walks its own origin-relative node array: 16 of them in flight instead of 8 cost 3.5 %, profiles/r5_dolly.txt)
     per_rank = ((resx + 15) // 16) * ((resy + 15) // 16) / float(world)
     auto_fpl = int(min(8, max(4 if (world == 1 and args.camera_path != "dolly") else 2, math.ceil(8160.0 / max(1.0, per_rank)))))
-    rnd = DistributedRenderer(scene, resx, resy, rank, world, slots=args.streams if args.streams > 0 else None, stage_cpu=rehearsal,
+    rnd = DistributedRenderer(scene, resx, resy, rank, world, slots=args.streams if args.streams > 0 else (8 if (args.reflections and cfg["lights"] and world == 1) else None), stage_cpu=rehearsal,
                               feedback_order=bool(args.feedback_order), lights7=lights7, reflections=bool(args.reflections and cfg["lights"]), rank0_share=args.rank0_share,
                               frames_per_launch=args.frames_per_launch if args.frames_per_launch > 0 else auto_fpl, order_refresh=args.order_refresh)
     primary_rays = rnd.rays_per_frame() if world > 1 else resx * ((resy + 15) // 16 * 16)
