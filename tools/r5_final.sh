@@ -40,6 +40,7 @@ bench)
   b dolly --no-cpu-baseline --camera-path dolly
   b config3 --no-cpu-baseline --config 3 --steps 800
   b config3_refl --no-cpu-baseline --config 3 --reflections --steps 300
+  b config3_refl_orbit --no-cpu-baseline --config 3 --reflections --steps 300 --camera-path orbit
   b config4 --no-cpu-baseline --config 4 --steps 800
   b config5 --no-cpu-baseline --config 5 --steps 800
   b gloo2 --gpus 2 --backend gloo --steps 200 --warmup 20
@@ -66,7 +67,7 @@ prof)
   prof dolly python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --camera-path dolly
   prof stress python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --config 5 --steps 400
   prof config3 python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --config 3 --steps 400
-  prof config3_refl python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --config 3 --reflections --steps 200
+  GPU_MAX_HW_QUEUES=16 prof config3_refl python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --config 3 --reflections --steps 200   # (bench.py's own choice for this workload, made before the profiler's library starts HIP)
   ;;
 *) echo "usage: bash tools/r5_final.sh pmc_ieee|pmc_host_sse|pmc|traffic|bench|prof"; exit 1;;
 esac
