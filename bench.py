@@ -590,7 +590,7 @@ def main():
     # ---- the same K steps with ONE frame per launch (N = 1, when the timed region used several): the rate without the batching ----
     fpl1 = None
     if rank == 0 and world == 1 and rnd.batch > 1 and args.lone_frames > 0:
-        r1 = DistributedRenderer(scene, resx, resy, 0, 1, slots=args.streams if args.streams > 0 else None, feedback_order=bool(args.feedback_order),
+        r1 = DistributedRenderer(scene, resx, resy, 0, 1, slots=rnd.nslots, feedback_order=bool(args.feedback_order),
                                  frames_per_launch=1, order_refresh=args.order_refresh)
         for i in range(max(8, settle_frames + args.warmup)):      # the same settle + warm-up as the timed region had
             r1.render(cam_at(i))
@@ -611,7 +611,7 @@ def main():
         other_name = "host_sse" if args.arith == "ieee" else "ieee"
         try:
             scene.set_arith(other_name)
-            r2 = DistributedRenderer(scene, resx, resy, 0, 1, slots=args.streams if args.streams > 0 else None, feedback_order=bool(args.feedback_order), lights7=lights7,
+            r2 = DistributedRenderer(scene, resx, resy, 0, 1, slots=rnd.nslots, feedback_order=bool(args.feedback_order), lights7=lights7,
                                      reflections=bool(args.reflections and cfg["lights"]), frames_per_launch=rnd.batch, order_refresh=args.order_refresh)
             for i in range(max(8 * rnd.batch, (settle_frames + args.warmup) // rnd.batch * rnd.batch)):      # the same settle + warm-up as the timed region had
                 r2.render(cam_at(i))
