@@ -45,7 +45,8 @@ config.settle_frames / settle_measured_ms): from an
 idle start the part's shader clock ramps for tens of milliseconds (profiles/README.md), and a short timed region would measure that ramp.  W warm-up
 steps, the barrier + synchronize, and EXACTLY K timed steps follow as the contract says.
 
-Launches: frames are pipelined over 4 HIP streams, and `--frames-per-launch B` frames (default: enough for a launch to hold a 1080p frame's worth of packets, at least 4 on one GPU and 2 on several, i.e. 4 / 2 / 4 / 8 at
+Launches: frames are pipelined over 4 HIP streams (`--streams`; on one GPU 8 for the frame with the mirrored bounce and 3 for a burst of at most 64 primary frames,
+such as the round driver's 20 steps: measured, profiles/r5_streams.txt, r5_burst.txt), and `--frames-per-launch B` frames (default: enough for a launch to hold a 1080p frame's worth of packets, at least 4 on one GPU and 2 on several, i.e. 4 / 2 / 4 / 8 at
 N = 1 / 2 / 4 / 8 -- 2 for the dolly camera; always 1 for config 3)
 share ONE launch -- the heaviest packets of all of them first, one tail and one set of launch overheads (and, at N > 1, one collective)
 for B frames; results are those of B single-frame launches.
@@ -341,7 +342,7 @@ def main():
     ap.add_argument("--no-live-check", action="store_true", help="skip the live oracle check of the timed output (rank 0, after the timed region); `verified` then rests on the committed digests alone")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal only: all ranks share GPU 0 and the per-frame gather is staged through host memory")
-    ap.add_argument("--streams", type=int, default=0, help="frames in flight (HIP streams); 0 = the renderer's default (4; 8 -- on 16 hardware queues -- for --reflections on one GPU); 1 = strictly serial frames")
+    ap.add_argument("--streams", type=int, default=0, help="frames in flight (HIP streams); 0 = the renderer's default (4) except on one GPU: 8 -- on 16 hardware queues -- for --reflections, 3 for a burst of at most 64 primary frames; 1 = strictly serial frames")
     ap.add_argument("--event-every", type=int, default=8, help="bracket every n-th traversal launch with HIP events (roofline.kernel_ms)")
     ap.add_argument("--feedback-order", type=int, default=1, help="1 (default) = dispatch packets heaviest first by the node visits of an earlier frame (DistributedRenderer feedback_order)")
     ap.add_argument("--frames-per-launch", type=int, default=0, help="trace this many frames (1..8) with one launch -- and, at N > 1, move them with one collective (DistributedRenderer frames_per_launch); 0 = enough for a launch to hold 8160 packets (one 1080p frame), at most 8, at least 4 on one GPU and 2 on several: 4 / 2 / 4 / 8 at N = 1 / 2 / 4 / 8; config 3 always 1")
@@ -439,7 +440,15 @@ def main():
     # and for the dolly camera (every frame walks its own origin-relative node array: 16 of them in flight instead of 8 cost 3.5 %, profiles/r5_dolly.txt)
     per_rank = ((resx + 15) // 16) * ((resy + 15) // 16) / float(world)
     auto_fpl = int(min(8, max(4 if (world == 1 and args.camera_path != "dolly") else 2, math.ceil(8160.0 / max(1.0, per_rank)))))
-    rnd = DistributedRenderer(scene, resx, resy, rank, world, slots=args.streams if args.streams > 0 else (8 if (args.reflections and cfg["lights"] and world == 1) else None), stage_cpu=rehearsal,
+    # launches in flight, unless given: the renderer's default (4; 3 with an asynchronous gather) -- except on one GPU: 8 for the frame with the mirrored bounce (nine
+    # dependent launches per frame: profiles/r5_streams.txt), and 3 for a BURST of primary frames (a timed region of at most 64 frames: 20 frames are five four-frame
+    # launches, and three in flight finish them 4.5 % sooner and far more evenly than four -- eight alternating runs on one box, 25.0-25.9 against 23.6-25.3 Grays/s,
+    # profiles/r5_burst.txt; in a long run four are ahead by 0-2 %)
+    auto_slots = None
+    if world == 1:
+        if args.reflections and cfg["lights"]: auto_slots = 8
+        elif not cfg["lights"] and args.steps <= 64: auto_slots = 3
+    rnd = DistributedRenderer(scene, resx, resy, rank, world, slots=args.streams if args.streams > 0 else auto_slots, stage_cpu=rehearsal,
                               feedback_order=bool(args.feedback_order), lights7=lights7, reflections=bool(args.reflections and cfg["lights"]), rank0_share=args.rank0_share,
                               frames_per_launch=args.frames_per_launch if args.frames_per_launch > 0 else auto_fpl, order_refresh=args.order_refresh)
     primary_rays = rnd.rays_per_frame() if world > 1 else resx * ((resy + 15) // 16 * 16)
