@@ -134,7 +134,10 @@ struct SnailScene {
 	int nestedOK = 1; // every child box lies inside its parent's (stackPack)
 	int pfOKButNesting = 0;
 	int lastBlocks = 0, lastThreads = 0;
-	enum { kDeferSlots = 8 };
+#ifndef SNAIL_DEFER_SLOTS
+#define SNAIL_DEFER_SLOTS 8 // launches in flight per scene handle before a scratch slot is recycled (a recycled slot waits for its previous user)
+#endif
+	enum { kDeferSlots = SNAIL_DEFER_SLOTS };
 	int *dDefer[kDeferSlots] = {};        // deferred-packet lists, one per launch in flight (round-robin)
 	// a slot's buffers are reused by the 8th launch after it, possibly on another stream and possibly while the host runs far
 	// ahead of the device: each slot carries an event recorded after its last kernel, and the next user's stream waits for it
