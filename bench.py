@@ -34,7 +34,8 @@ parity bar is against THAT path.  `--arith auto` (default) therefore runs the ke
 the device from verified tables, results equal to the reference's SSE path bit for bit -- and falls back to veclib's scalar definitions (SNAIL_ARITH_IEEE,
 host-independent results, ~2 % faster) only on a host whose instructions cannot be tabulated; `config.arith` says which ran, `roofline.other_arith` carries
 the other arithmetic's rate for the same K steps (N = 1), and `verified` = the timed region's output hashed equal to the frame the oracle renders on this box after the
-timed region, in the timed arithmetic (`verification.live_oracle`), and to the committed digest of the oracle's frame where one exists (`verification.committed`).
+timed region, in the timed arithmetic (`verification.live_oracle`), and to the committed digest of the oracle's frame where one exists (`verification.committed`).  The renderer's output
+buffers are overwritten with all-ones after the warm-up steps (outside the timed region), so what is hashed was written by the timed launches.
 
 Mrays = rays launched (every lane of every traced packet, hit or miss), as TreeStats::TracingRays counts them
 (src/scene_trace.cpp:116-117): frames are padded to whole 16x16 packets (1920x1080 -> 1920x1088); config 3 adds the shadow
@@ -513,6 +514,8 @@ def main():
     for i in range(args.warmup):
         rnd.render(cam_at(warm0 + i))
     rnd.flush()
+    if rank == 0 and not rehearsal:
+        rnd.poison_outputs()      # what verify_outputs() hashes after the timed region was written INSIDE it: the settle / warm-up frames' results are gone
     barrier()
 
     # ---- timed region: EXACTLY K steps (frames are pipelined over the renderer's HIP streams, see DistributedRenderer) ----
@@ -539,6 +542,7 @@ def main():
     vkey = "%d%s" % (args.config, "r" if (args.reflections and cfg["lights"]) else "")
     if rank == 0:
         verify = verify_outputs(rnd, scene_name, resx, resy, vkey, args.arith, cfg["lights"])
+        verify["buffers_poisoned_before_timed_region"] = not rehearsal      # (DistributedRenderer.poison_outputs: nothing a settle / warm-up frame wrote survives into this check)
         verify["what"] = ("one more round of the fixed view through the timed renderer after the timed region (the timed frames each hold another view)" if len(path) > 1
                           else "the last frame each slot traced inside the timed region")
     timed = [e for e in ev if e is not None]

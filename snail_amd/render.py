@@ -310,6 +310,17 @@ class DistributedRenderer:
         timed region."""
         return [self._outputs[k] for k in sorted(self._outputs)]
 
+    def poison_outputs(self):
+        """Overwrite every buffer output_buffers() names with a poison pattern (all bits set) and forget them: what output_buffers() returns afterwards was
+        written by launches issued AFTER this call.  Call between flush() and the next render(); synchronises the device.  bench.py does this in front of its
+        timed region, so that a launch that silently skipped work inside it could not pass on a buffer an earlier (warm-up) frame had filled."""
+        torch = self.torch
+        for b in self.output_buffers():
+            for t in ((b.t, b.u, b.v, b.tri_id) if hasattr(b, "tri_id") else (b,)):
+                t.view(torch.uint8).fill_(0xff) if t.dtype != torch.uint8 else t.fill_(0xff)
+        torch.cuda.synchronize()
+        self._outputs = {}
+
     def _order_for(self, slot, cam):
         """the dispatch order this frame uses (or None), and whether to re-derive the slot's order from this frame's costs (key or None).  self.order_exact[slot]
         then says what kind the derivation is to be: a camera that has NOT moved since the slot's order was derived gets -- once -- the order of its own exact

@@ -1479,9 +1479,21 @@ def test_dispatch_order_feedback_changes_nothing_but_the_order(torch_mod, name, 
     for k in range(rnd.nslots):
         assert util.check_derived_order(rnd.slot_cost[k].cpu().numpy(), rnd.order_buf[k].cpu().numpy(), exact=True) == "sorted"
         assert np.array_equal(rnd.slot_cost[k].cpu().numpy(), c), "the slot's costs are this camera's"
-    for _ in range(rnd.nslots):                  # the camera moves again: the orders are predictions, the library's rule
-        compare_frames(rnd.render(cams[-1]), osc.render_primary(cams[-1].as_array13(), resx, resy, mode=O.MODE_IEEE), "renderer feedback, moved again")
+    # poison_outputs (bench.py, in front of its timed region): every buffer the renderer has written becomes all-ones and is forgotten; what
+    # output_buffers() names afterwards was written after the call
+    assert len(rnd.output_buffers()) == rnd.nslots
+    old = rnd.output_buffers()
+    rnd.poison_outputs()
+    assert rnd.output_buffers() == [] and all(bool((f.tri_id == -1).all()) and bool((f.t.view(torch_mod.int32) == -1).all()) for f in old)
+    f = rnd.render(cam)
     rnd.flush()
+    compare_frames(f, ref, "after the poison")
+    assert len(rnd.output_buffers()) == 1
+    moved = osc.render_primary(cams[-1].as_array13(), resx, resy, mode=O.MODE_IEEE)
+    for _ in range(rnd.nslots):                  # the camera moves again: the orders are predictions, the library's rule
+        f = rnd.render(cams[-1])
+        rnd.flush()
+        compare_frames(f, moved, "renderer feedback, moved again")
     assert not any(rnd.order_exact)
     sc.close()
 
